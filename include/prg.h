@@ -1,0 +1,183 @@
+/* prg.h — C-ABI of libprg_hip.so: the MI355X (gfx950) implementation of PointRegGPT's generative data path.
+ *
+ * The reference (Chen-Suyi/PointRegGPT) has no FFI: this path sits behind plain Python callables.  Each
+ * entry point below replaces one of those callables; the reference interface it stands in for is cited as
+ *   sd = denoising_diffusion_pytorch/successive_ddnm_diffusion.py      dc = depth_correction_pytorch/depth_correction.py
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add to bind them.
+ *
+ * Conventions
+ *   - extern "C", C types only.  Every function returns 0 on success or a negative PRG_E_* code and never
+ *     throws or aborts across the boundary; prg_last_error() returns a thread-local message.
+ *   - The CALLER owns all tensor memory.  Unless a parameter is documented "host", pointers are DEVICE
+ *     pointers (hipMalloc / torch.empty(device='cuda').data_ptr()).  Images are dense row-major float32
+ *     (B,1,H,W) exactly as the reference passes them; depth unit: the caller's (the kernels are unit-free).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous with
+ *     respect to it and do not synchronise, except *_create / *_destroy / *_reserve.
+ *   - The library allocates device memory only inside opaque handles (weights, workspaces, graphs).
+ *     Handles are not thread-safe; use one per (process, device).
+ */
+#ifndef PRG_H
+#define PRG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRG_ABI_VERSION 1
+
+enum {
+  PRG_OK = 0,
+  PRG_E_INVALID = -1,   /* bad argument (null pointer, size mismatch, unsupported shape) */
+  PRG_E_HIP = -2,       /* a HIP runtime call failed; message has hipGetErrorString */
+  PRG_E_NOMEM = -3,     /* device allocation failed */
+  PRG_E_STATE = -4      /* handle used in the wrong state */
+};
+
+enum { PRG_F32 = 0, PRG_BF16 = 1 };          /* storage + MFMA input type of a U-Net handle */
+
+int prg_abi_version(void);
+const char* prg_last_error(void);
+/* Name and compute-unit count of the current HIP device (diagnostics; fails loudly when there is none). */
+int prg_device_info(char* name, size_t name_len, int* compute_units);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Geometry (memory-bound kernels)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* depth2pc_tensor (sd:176-209): depth (B,1,H,W) + K (B,3,3) -> pc (B,H*W,3), valid (B,H*W) as bytes.
+ * valid = clip_lo < depth < clip_hi (pass clip_lo > clip_hi to disable clipping, i.e. clip=None);
+ * invalid points are filled with `invalid_value` (the reference default is NaN).                          */
+int prg_depth2pc(const float* depth, const float* K, float* pc, uint8_t* valid, int B, int H, int W,
+                 float clip_lo, float clip_hi, float invalid_value, void* stream);
+
+/* pc2depth_tensor (sd:212-265): z-buffer.  pc (B,N,3), valid (B,N) bytes or NULL (= all valid), K (B,3,3)
+ * -> depth (B,1,H,W) nearest z per pixel (0 where nothing lands), mask (B,1,H,W) bytes.
+ * Pixel = round-half-even(x*fx/z + cx, y*fy/z + cy); a point counts iff in frame, valid and z > 0.         */
+int prg_pc2depth(const float* pc, const uint8_t* valid, const float* K, float* depth, uint8_t* mask,
+                 int B, int N, int H, int W, void* stream);
+
+/* Generator.generate's per-scene form (sd:2531-2547): ragged clouds, CSR offsets (B+1, int64, device),
+ * each moved by its pose (B,4,4) as p R^T + t (NULL = identity) and z-buffered with its K.
+ * `depth_scale` multiplies the stored depth (the reference multiplies by 0.1 right after, sd:2552).          */
+int prg_project_points_zbuffer(const float* points, const int64_t* offsets, const float* pose, const float* K,
+                               float* depth, uint8_t* mask, int B, int H, int W, float depth_scale,
+                               void* stream);
+
+/* reproject_tensor (sd:268-286) fused: unproject depth*depth_unit, move by pose, z-buffer into the same
+ * camera, store z*out_scale.  One kernel, no intermediate point cloud in HBM.                              */
+int prg_reproject_zbuffer(const float* depth, const float* K, const float* pose, float* depth_out,
+                          uint8_t* mask_out, int B, int H, int W, float depth_unit, float clip_lo,
+                          float clip_hi, float out_scale, void* stream);
+
+/* numpy point_cloud + inverse pose (sd:122-143, sd:2627-2628) in float64 like the reference's numpy path:
+ * depth (B,1,H,W) float32 * depth_unit -> xyz (B,H*W,3) float64 in the common frame, R^T (p - t), pose NULL =
+ * camera frame; rows of invalid pixels are NaN and valid (B,H*W) bytes says which to keep (row-major order
+ * is the reference's order after compaction).                                                              */
+int prg_unproject_f64(const float* depth, const float* K, const float* pose, double* xyz, uint8_t* valid,
+                      int B, int H, int W, float depth_unit, float clip_lo, float clip_hi, void* stream);
+
+/* DepthAugment (dc:577-604): depth (B,1,H,W) -> (B,3,H,W) [depth, 3x3 min over non-zero, difference].   */
+int prg_depth_augment(const float* depth, float* out, int B, int H, int W, void* stream);
+
+/* Generator.generate's mask application (sd:2564-2570): keep = prob > thr; depth[~keep] = 0 (in place when
+ * depth_out == depth); hit &= keep; img_cond (B,2,H,W) = cat[depth, hit] * 2 - 1 (NULL to skip).
+ * `hit` may be NULL (treated as all true, the post-sampling use at sd:2579-2581).                          */
+int prg_apply_mask(const float* prob, const float* depth, const uint8_t* hit, float thr, float* depth_out,
+                   uint8_t* hit_out, float* img_cond, int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * U-Nets (MFMA kernels)
+ * ---------------------------------------------------------------------------------------------------- */
+
+typedef struct prg_unet prg_unet;
+
+typedef struct prg_unet_config {
+  int32_t dim;               /* base width (64) */
+  int32_t n_levels;          /* len(dim_mults) (4) */
+  int32_t dim_mults[8];      /* (1,2,4,8) */
+  int32_t in_channels;       /* Unet 1 ; MaskUnet 3 (DepthAugment is applied inside prg_maskunet_forward) */
+  int32_t conditional;       /* 1: time + camera-parameter conditioning (Unet, sd:802) ; 0: MaskUnet (dc:807) */
+  int32_t param_cond_dim;    /* 4 */
+  int32_t groups;            /* GroupNorm groups (8) */
+  int32_t sigmoid_out;       /* 1: final Sigmoid (MaskUnet) */
+} prg_unet_config;
+
+/* Number of float32 parameters the config implies (= sum of the reference module's state_dict sizes).    */
+int64_t prg_unet_param_count(const prg_unet_config* cfg);
+
+/* weights: HOST pointer to n_floats float32 = every state_dict tensor of the reference module, flattened and
+ * concatenated in state_dict order (sd:802-918 / dc:807-869; pointreggpt_amd.weights.param_spec lists it).
+ * The library standardises the Block conv weights (sd:601-616, eps 1e-5), repacks everything for its
+ * kernels in `dtype` and uploads it.                                                                        */
+int prg_unet_create(const prg_unet_config* cfg, const float* weights, int64_t n_floats, int dtype,
+                    prg_unet** out);
+int prg_unet_destroy(prg_unet* h);
+/* Pre-size the activation workspace for (B, S) so later forwards never allocate.                          */
+int prg_unet_reserve(prg_unet* h, int B, int S);
+
+/* Unet.forward (sd:920-964): x (B,1,S,S), time (B,) int64 DEVICE, param_cond (B,4) -> out (B,1,S,S).      */
+int prg_unet_forward(prg_unet* h, const float* x, const int64_t* time, const float* param_cond, float* out,
+                     int B, int S, void* stream);
+/* MaskUnet.forward (dc:871-906): depth (B,1,S,S) -> keep-probability (B,1,S,S).                            */
+int prg_maskunet_forward(prg_unet* h, const float* depth, float* prob, int B, int S, void* stream);
+
+/* Debug taps for kernel unit tests: after a forward, copy an internal activation (converted to float32 NCHW)
+ * into `out` (device).  Names: "init_conv","down0_block0","down0_attn","down0_out","mid_attn","up0_out",
+ * "final_res","augment".  *C,*H,*W receive its shape.  Enabled by prg_unet_set_taps(h, 1).                  */
+int prg_unet_set_taps(prg_unet* h, int enable);
+int prg_unet_get_tap(prg_unet* h, const char* name, float* out, int64_t out_capacity_floats, int* C, int* H,
+                     int* W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Sampler: GaussianDiffusion.sample / p_sample_loop / ddim_sample (sd:1283-1409), DDNM replacement included
+ * ---------------------------------------------------------------------------------------------------- */
+
+typedef struct prg_sampler prg_sampler;
+
+/* One denoising transition.  With u = Unet(x, t, param_cond):
+ *     x0p = clip_pred ? clamp(u,-1,1) : u                                    (sd:1199-1201)
+ *     eps = (sqrt_recip * x - x0p) / sqrt_recipm1                            (sd:1158-1162; used iff c_eps != 0)
+ *     x0  = known ? cond_depth : x0p ;  x0 = clamp(x0,-1,1)                  (sd:1210-1218, sd:1250-1251)
+ *     x'  = c_x0 * x0 + c_x * x + c_eps * eps + sigma * noise                (sd:1173-1180,1280 / sd:1369-1373)
+ * Ancestral step t: c_x0 = posterior_mean_coef1[t], c_x = coef2[t], c_eps = 0, sigma = exp(0.5 logvar[t])
+ * (0 at t = 0).  DDIM pair (t, t'): c_x0 = sqrt(ac[t']), c_x = 0, c_eps = c, sigma = sigma; last pair:
+ * c_x0 = 1, everything else 0.  The host (pointreggpt_amd.diffusion) fills this table from the float64
+ * schedule exactly as the reference computes it.                                                            */
+typedef struct prg_step {
+  int32_t t;            /* timestep fed to the U-Net */
+  int32_t clip_pred;    /* clamp the network output before deriving eps (ddim: clip_denoised=True) */
+  float c_x0, c_x, c_eps, sigma;
+  float sqrt_recip, sqrt_recipm1;
+} prg_step;
+
+/* steps: HOST array of n_steps transitions, executed in order.  The handle owns the state image, the
+ * per-step conditioning table and one captured hipGraph of a full transition (U-Net + update) that is
+ * replayed n_steps times; the step index lives in device memory so no host sync occurs inside a run.      */
+int prg_sampler_create(prg_unet* unet, const prg_step* steps, int n_steps, int B, int S, prg_sampler** out);
+int prg_sampler_destroy(prg_sampler* h);
+/* 1 (default): replay the captured hipGraph; 0: launch every kernel eagerly (debug / profiling).          */
+int prg_sampler_set_graph(prg_sampler* h, int enable);
+
+/* param_cond (B,4); img_cond (B,2,S,S) in [-1,1] or NULL (unconditional: no DDNM replacement);
+ * noise: NULL -> on-device Philox4x32-10 keyed per scene by seeds[b] (HOST array of B uint64; results do
+ * not depend on batch composition or rank) ; else DEVICE float32 (n_steps+1, B, S, S): slab 0 is the start
+ * image, slab k feeds transition k-1 (unused where sigma == 0) — the reference's draw order (sd:1293,1279).
+ * out (B,1,S,S) = (x_final + 1) * 0.5  (sd:1316).                                                          */
+int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_cond, const float* noise,
+                    const uint64_t* seeds, float* out, void* stream);
+
+/* Wall-clock free timing hook for bench.py: average duration in milliseconds of the dominant kernel class
+ * (implicit-GEMM convolution launches) measured with HIP events on the run's own stream during the last
+ * prg_sampler_run when profiling was enabled with prg_sampler_set_profile(h, 1) (forces eager launches).
+ * conv_ms = total time inside conv launches, conv_launches = their count, conv_flops = their 2*MAC count. */
+int prg_sampler_set_profile(prg_sampler* h, int enable);
+int prg_sampler_get_profile(prg_sampler* h, double* conv_ms, int64_t* conv_launches, double* conv_flops,
+                            double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRG_H */

@@ -1,0 +1,58 @@
+// blocks.h — launch interface of the non-conv U-Net kernels (all HBM-bound): GroupNorm statistics / apply,
+// channel LayerNorm, linear attention, full attention, the small conditioning MLPs.
+#pragma once
+#include "common.h"
+
+namespace prg {
+
+constexpr int kHeads = 4, kDimHead = 32, kHidden = 128;   // sd:738, sd:773
+constexpr int kGnMaxSplit = 64;
+
+// GroupNorm (sd:685, eps 1e-5) over NHWC x (B, HW, C).  Pass 1 writes per-slab (sum, sumsq) partials
+// [B][nsplit][G][2]; pass 2 reduces them in a fixed order (deterministic), normalises, applies the optional
+// conditioning (scale+1, shift) (sd:692-694), SiLU, and an optional residual add (sd:734).
+// Returns nsplit chosen by pass 1 through *nsplit.
+template <typename T>
+int launch_gn_stats(const T* x, float* partials, int B, int HW, int C, int G, int* nsplit, hipStream_t s);
+
+struct GnApply {
+  const float* gamma;     // [C]
+  const float* beta;      // [C]
+  const float* ss_a;      // conditioning (scale | shift) rows of 2C floats, or null.  value = ss_a[b or step] + ss_b[b]
+  const float* ss_b;      // second addend (per image), or null
+  int64_t ss_b_stride;    // row stride of ss_b per image
+  int64_t ss_a_stride;    // row stride of ss_a per image (0 when shared by the whole batch)
+  const int* ss_a_row;    // optional device int: row index into ss_a added on top (sampler: current step), or null
+  int64_t ss_a_row_stride;
+};
+template <typename T>
+int launch_gn_apply(const T* x, const float* partials, int nsplit, const GnApply& p, const T* residual, T* out, int B,
+                    int HW, int C, int G, hipStream_t s);
+
+// Channel LayerNorm with gain (sd:619-628) + optional residual add (sd:589).
+template <typename T>
+int launch_layernorm(const T* x, const float* g, const T* residual, T* out, int64_t M, int C, hipStream_t s);
+
+// LinearAttention core (sd:755-768) on qkv NHWC (B, N, 384) -> out NHWC (B, N, 128).
+// ws: float workspace of at least linattn_ws_floats(B, N) floats.
+size_t linattn_ws_floats(int B, int N);
+template <typename T>
+int launch_linear_attention(const T* qkv, T* out, float* ws, int B, int N, hipStream_t s);
+
+// Attention core (sd:789-795) on qkv NHWC (B, N, 384) -> out NHWC (B, N, 128).
+template <typename T>
+int launch_full_attention(const T* qkv, T* out, int B, int N, hipStream_t s);
+
+// y[r][o] = act_out( sum_i act_in(x[r][xoff + i]) * W[o][woff + i] + bias[o] ),  float32, tiny.
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
+int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, int woff, const float* bias, float* y,
+                  int ldy, int R, int I, int O, int act_in, int act_out, hipStream_t s);
+// sinusoidal embedding (sd:645-657): t (R,) int64 -> (R, dim) float32
+int launch_sinusoidal(const int64_t* t, float* out, int R, int dim, hipStream_t s);
+int launch_sinusoidal_i32(const int32_t* t, float* out, int R, int dim, hipStream_t s);
+
+// float32 NCHW <- T NHWC (debug taps)
+template <typename T>
+int launch_nhwc_to_nchw_f32(const T* x, float* out, int B, int HW, int C, hipStream_t s);
+
+}  // namespace prg

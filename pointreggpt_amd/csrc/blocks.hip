@@ -1,0 +1,624 @@
+// blocks.hip — the HBM-bound kernels between the convolutions (NHWC activations of type T, fp32 math):
+// GroupNorm statistics + apply (+conditioning, SiLU, residual), channel LayerNorm (+residual), the linear-attention
+// core, the bottleneck attention core, and the tiny conditioning MLPs.  Reductions are wave-level (64 lanes) and
+// every cross-workgroup reduction is done in a fixed order, so results are run-to-run deterministic.
+//
+// sd = denoising_diffusion_pytorch/successive_ddnm_diffusion.py
+#include "blocks.h"
+
+namespace prg {
+
+template <typename T>
+struct Acc {  // statistics accumulator: float32 activations (parity mode) accumulate in float64
+  using type = float;
+};
+template <>
+struct Acc<float> {
+  using type = double;
+};
+
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// =============================================================================================
+// GroupNorm
+// =============================================================================================
+// grid (nsplit, B); thread owns channel-vector `vc = tid % (C/VEC)` and walks pixels with stride 256/(C/VEC)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ partials, int HW,
+                                                       int C, int G, int slab) {
+  constexpr int VEC = Elem<T>::kVec;
+  using A = typename Acc<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  A* red = reinterpret_cast<A*>(smem);  // [psub][C][2]
+  const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
+  const int nvc = C / VEC, psub = 256 / nvc;
+  const int vc = threadIdx.x % nvc, ps = threadIdx.x / nvc;
+  const int p0 = sp * slab, p1 = min(HW, p0 + slab);
+  A s[VEC], q[VEC];
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) { s[u] = 0; q[u] = 0; }
+  const T* xb = x + (size_t)b * HW * C;
+  for (int p = p0 + ps; p < p1; p += psub) {
+    Vec16<T> v = vec_load(xb + (size_t)p * C + vc * VEC);
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      A f = (A)Elem<T>::load(v.e[u]);
+      s[u] += f;
+      q[u] += f * f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) {
+    red[((size_t)ps * C + vc * VEC + u) * 2 + 0] = s[u];
+    red[((size_t)ps * C + vc * VEC + u) * 2 + 1] = q[u];
+  }
+  __syncthreads();
+  // fixed-order reduction: channel c over pixel sub-lanes, then group g over its channels
+  for (int c = threadIdx.x; c < C; c += 256) {
+    A ss = 0, qq = 0;
+    for (int k = 0; k < psub; ++k) {
+      ss += red[((size_t)k * C + c) * 2 + 0];
+      qq += red[((size_t)k * C + c) * 2 + 1];
+    }
+    red[(size_t)c * 2 + 0] = ss;  // row 0 of red reused (each thread only overwrites the column it just summed)
+    red[(size_t)c * 2 + 1] = qq;
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int cpg = C / G, g = threadIdx.x;
+    A ss = 0, qq = 0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      ss += red[(size_t)c * 2 + 0];
+      qq += red[(size_t)c * 2 + 1];
+    }
+    float* o = partials + (((size_t)b * nsplit + sp) * G + g) * 2;
+    o[0] = (float)ss;
+    o[1] = (float)qq;
+  }
+}
+
+template <typename T>
+int launch_gn_stats(const T* x, float* partials, int B, int HW, int C, int G, int* nsplit, hipStream_t s) {
+  constexpr int VEC = Elem<T>::kVec;
+  using A = typename Acc<T>::type;
+  const int nvc = C / VEC;
+  PRG_CHECK(C % VEC == 0 && is_pow2(nvc) && nvc <= 256, "groupnorm: C/VEC must be a power of two <= 256");
+  PRG_CHECK(C % G == 0 && G <= 64, "groupnorm: bad group count");
+  const int psub = 256 / nvc;
+  // slabs of >= 8 pixel rows per thread, at most kGnMaxSplit slabs per image
+  int ns = ceil_div(HW, psub * 8);
+  if (ns > kGnMaxSplit) ns = kGnMaxSplit;
+  if (ns < 1) ns = 1;
+  const int slab = ceil_div(HW, ns);
+  ns = ceil_div(HW, slab);
+  *nsplit = ns;
+  const size_t lds = (size_t)psub * C * 2 * sizeof(A);
+  gn_stats_kernel<T><<<dim3(ns, B), 256, lds, s>>>(x, partials, HW, C, G, slab);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_gn_stats<float>(const float*, float*, int, int, int, int, int*, hipStream_t);
+template int launch_gn_stats<bf16_t>(const bf16_t*, float*, int, int, int, int, int*, hipStream_t);
+
+// grid (chunks, B).  y = silu( gn(x) * (scale + 1) + shift ) + residual
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ partials,
+                                                       int nsplit, GnApply p, const T* __restrict__ residual,
+                                                       T* __restrict__ out, int HW, int C, int G, int slab) {
+  constexpr int VEC = Elem<T>::kVec;
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.y;
+  if (threadIdx.x < G) {
+    double ss = 0, qq = 0;
+    const float* pp = partials + ((size_t)b * nsplit * G + threadIdx.x) * 2;
+    for (int k = 0; k < nsplit; ++k) {
+      ss += (double)pp[(size_t)k * G * 2 + 0];
+      qq += (double)pp[(size_t)k * G * 2 + 1];
+    }
+    const double n = (double)HW * (C / G);
+    const double mean = ss / n;
+    double var = qq / n - mean * mean;
+    if (var < 0) var = 0;
+    s_mean[threadIdx.x] = (float)mean;
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  const int nvc = C / VEC, psub = 256 / nvc;
+  const int vc = threadIdx.x % nvc, ps = threadIdx.x / nvc;
+  const int cpg = C / G;
+  float a[VEC], bb[VEC], sc[VEC], sh[VEC];
+  const float* ssa = nullptr;
+  const float* ssb = nullptr;
+  if (p.ss_a) {
+    ssa = p.ss_a + (size_t)b * p.ss_a_stride;
+    if (p.ss_a_row) ssa += (size_t)(*p.ss_a_row) * p.ss_a_row_stride;
+    if (p.ss_b) ssb = p.ss_b + (size_t)b * p.ss_b_stride;
+  }
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) {
+    const int c = vc * VEC + u, g = c / cpg;
+    const float scale = s_rstd[g] * p.gamma[c];
+    a[u] = scale;
+    bb[u] = p.beta[c] - s_mean[g] * scale;
+    sc[u] = 1.0f;
+    sh[u] = 0.0f;
+    if (ssa) {
+      float s0 = ssa[c], s1 = ssa[C + c];
+      if (ssb) { s0 += ssb[c]; s1 += ssb[C + c]; }
+      sc[u] = s0 + 1.0f;
+      sh[u] = s1;
+    }
+  }
+  const int p0 = blockIdx.x * slab, p1 = min(HW, p0 + slab);
+  const size_t base = (size_t)b * HW * C;
+  for (int px = p0 + ps; px < p1; px += psub) {
+    const size_t o = base + (size_t)px * C + vc * VEC;
+    Vec16<T> v = vec_load(x + o), r, w;
+    if (residual) r = vec_load(residual + o);
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      float y = fmaf(Elem<T>::load(v.e[u]), a[u], bb[u]);
+      if (ssa) y = fmaf(y, sc[u], sh[u]);
+      y = silu_f(y);
+      if (residual) y += Elem<T>::load(r.e[u]);
+      w.e[u] = Elem<T>::store(y);
+    }
+    vec_store(out + o, w);
+  }
+}
+
+template <typename T>
+int launch_gn_apply(const T* x, const float* partials, int nsplit, const GnApply& p, const T* residual, T* out, int B,
+                    int HW, int C, int G, hipStream_t s) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int nvc = C / VEC;
+  PRG_CHECK(C % VEC == 0 && is_pow2(nvc) && nvc <= 256, "groupnorm: C/VEC must be a power of two <= 256");
+  const int psub = 256 / nvc;
+  int chunks = ceil_div(HW, psub * 4);
+  if (chunks > 512) chunks = 512;
+  if (chunks < 1) chunks = 1;
+  const int slab = ceil_div(HW, chunks);
+  chunks = ceil_div(HW, slab);
+  gn_apply_kernel<T><<<dim3(chunks, B), 256, 0, s>>>(x, partials, nsplit, p, residual, out, HW, C, G, slab);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_gn_apply<float>(const float*, const float*, int, const GnApply&, const float*, float*, int, int, int,
+                                    int, hipStream_t);
+template int launch_gn_apply<bf16_t>(const bf16_t*, const float*, int, const GnApply&, const bf16_t*, bf16_t*, int, int,
+                                     int, int, hipStream_t);
+
+// =============================================================================================
+// channel LayerNorm (per pixel over C, biased variance, eps 1e-5, gain only) + optional residual
+// =============================================================================================
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ g,
+                                                        const T* __restrict__ residual, T* __restrict__ out,
+                                                        int64_t M, int C, int L) {
+  constexpr int VEC = Elem<T>::kVec;
+  // L lanes (power of two <= 64) share one pixel; each holds up to MAXV 16-byte vectors (stride L)
+  const int sub = threadIdx.x % L;
+  const int per_block = 256 / L;
+  const int nv = C / VEC;
+  for (int64_t m = (int64_t)blockIdx.x * per_block + threadIdx.x / L; m < M; m += (int64_t)gridDim.x * per_block) {
+    float v[MAXV][VEC];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int iv = sub + k * L;
+      if (iv < nv) {
+        Vec16<T> t = vec_load(x + m * C + (size_t)iv * VEC);
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) { v[k][u] = Elem<T>::load(t.e[u]); s += v[k][u]; }
+      }
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int iv = sub + k * L;
+      if (iv < nv) {
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) { float dlt = v[k][u] - mean; q = fmaf(dlt, dlt, q); }
+      }
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int iv = sub + k * L;
+      if (iv < nv) {
+        const size_t o = (size_t)m * C + (size_t)iv * VEC;
+        Vec16<T> w, r;
+        if (residual) r = vec_load(residual + o);
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+          float y = (v[k][u] - mean) * rstd * g[iv * VEC + u];
+          if (residual) y += Elem<T>::load(r.e[u]);
+          w.e[u] = Elem<T>::store(y);
+        }
+        vec_store(out + o, w);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_layernorm(const T* x, const float* g, const T* residual, T* out, int64_t M, int C, hipStream_t s) {
+  constexpr int VEC = Elem<T>::kVec;
+  PRG_CHECK(C % VEC == 0, "layernorm: C must be a multiple of the vector width");
+  const int nv = C / VEC;
+  int L = 1;
+  while (L < nv && L < 64) L <<= 1;
+  const int need = ceil_div(nv, L);
+  PRG_CHECK(need <= 4, "layernorm: C too large");
+  const int per_block = 256 / L;
+  int grid = (int)((M + per_block - 1) / per_block);
+  if (grid > 16384) grid = 16384;
+  if (need <= 1)
+    layernorm_kernel<T, 1><<<grid, 256, 0, s>>>(x, g, residual, out, M, C, L);
+  else if (need <= 2)
+    layernorm_kernel<T, 2><<<grid, 256, 0, s>>>(x, g, residual, out, M, C, L);
+  else
+    layernorm_kernel<T, 4><<<grid, 256, 0, s>>>(x, g, residual, out, M, C, L);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_layernorm<float>(const float*, const float*, const float*, float*, int64_t, int, hipStream_t);
+template int launch_layernorm<bf16_t>(const bf16_t*, const float*, const bf16_t*, bf16_t*, int64_t, int, hipStream_t);
+
+// =============================================================================================
+// linear attention core (sd:755-768).  qkv (B, N, 384): q = [0,128) k = [128,256) v = [256,384), head-major.
+//   k' = softmax_n(k)   q' = softmax_d(q) / sqrt(32)   v' = v / N
+//   ctx[d][e] = sum_n k'[n][d] v'[n][e]     out[n][e] = sum_d ctx[d][e] q'[n][d]
+// ws layout (floats): kmax [B][128] | ctxp [B][4][NS][1024] | sump [B][4][NS][32] | ctx [B][4][1024]
+// =============================================================================================
+constexpr int kLaMaxSplit = 128;
+static inline int la_nsplit(int N) {
+  int ns = ceil_div(N, 256);
+  if (ns > kLaMaxSplit) ns = kLaMaxSplit;
+  return ns < 1 ? 1 : ns;
+}
+size_t linattn_ws_floats(int B, int N) {
+  const size_t ns = la_nsplit(N);
+  return (size_t)B * 128 + (size_t)B * 4 * ns * 1024 + (size_t)B * 4 * ns * 32 + (size_t)B * 4 * 1024;
+}
+
+__device__ inline void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.0f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// grid (ns, B): column max of k over a slab of pixels, merged with an order-independent atomic max
+template <typename T>
+__global__ __launch_bounds__(256) void la_kmax_kernel(const T* __restrict__ qkv, float* __restrict__ kmax, int N,
+                                                      int slab) {
+  __shared__ float sm[256];
+  const int b = blockIdx.y, c = threadIdx.x & 127, sub = threadIdx.x >> 7;
+  const int p0 = blockIdx.x * slab, p1 = min(N, p0 + slab);
+  float m = -INFINITY;
+  const T* base = qkv + (size_t)b * N * 384 + 128 + c;
+  for (int n = p0 + sub; n < p1; n += 2) m = fmaxf(m, Elem<T>::load(base[(size_t)n * 384]));
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  if (sub == 0) {
+    m = fmaxf(m, sm[threadIdx.x + 128]);
+    if (m > -INFINITY) atomic_max_f32(kmax + (size_t)b * 128 + c, m);
+  }
+}
+
+// grid (ns, 4, B): partial context of one head over a slab: thread (d = tid/8, e0 = (tid%8)*4)
+template <typename T>
+__global__ __launch_bounds__(256) void la_ctx_kernel(const T* __restrict__ qkv, const float* __restrict__ kmax,
+                                                     float* __restrict__ ctxp, float* __restrict__ sump, int N,
+                                                     int slab) {
+  constexpr int P = 64;
+  __shared__ __attribute__((aligned(16))) float ek[P][32];
+  __shared__ __attribute__((aligned(16))) float vv[P][32];
+  const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z, ns = gridDim.x;
+  const int tid = threadIdx.x, d = tid >> 3, e0 = (tid & 7) * 4;
+  const int p0 = sp * slab, p1 = min(N, p0 + slab);
+  const float km = kmax[(size_t)b * 128 + h * 32 + (tid & 31)];  // for the staging role below: channel = tid % 32
+  float acc[4] = {0, 0, 0, 0}, ssum = 0.0f;
+  const T* base = qkv + (size_t)b * N * 384;
+  for (int t0 = p0; t0 < p1; t0 += P) {
+    // stage P pixels: thread loads channel (tid % 32) of pixels (tid / 32) + 8 i
+#pragma unroll
+    for (int i = 0; i < P / 8; ++i) {
+      const int pp = (tid >> 5) + i * 8, n = t0 + pp, ch = tid & 31;
+      float kvv = 0.0f, vvv = 0.0f;
+      if (n < p1) {
+        kvv = expf(Elem<T>::load(base[(size_t)n * 384 + 128 + h * 32 + ch]) - km);
+        vvv = Elem<T>::load(base[(size_t)n * 384 + 256 + h * 32 + ch]);
+      }
+      ek[pp][ch] = kvv;
+      vv[pp][ch] = vvv;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int pp = 0; pp < P; ++pp) {
+      const float a = ek[pp][d];
+      const float4 w = *reinterpret_cast<const float4*>(&vv[pp][e0]);
+      ssum += a;
+      acc[0] = fmaf(a, w.x, acc[0]);
+      acc[1] = fmaf(a, w.y, acc[1]);
+      acc[2] = fmaf(a, w.z, acc[2]);
+      acc[3] = fmaf(a, w.w, acc[3]);
+    }
+    __syncthreads();
+  }
+  float* o = ctxp + (((size_t)b * 4 + h) * ns + sp) * 1024 + d * 32 + e0;
+  o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+  if ((tid & 7) == 0) sump[(((size_t)b * 4 + h) * ns + sp) * 32 + d] = ssum;
+}
+
+// grid (4, B), 256 threads x 4 entries: ctx = (sum_split ctxp) / (sum_split sump[d]) / N
+__global__ __launch_bounds__(256) void la_fin_kernel(const float* __restrict__ ctxp, const float* __restrict__ sump,
+                                                     float* __restrict__ ctx, int ns, int N) {
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const size_t bh = (size_t)b * 4 + h;
+  const float invN = 1.0f / (float)N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * 256, d = idx >> 5;
+    float s = 0.0f, a = 0.0f;
+    for (int k = 0; k < ns; ++k) {
+      a += ctxp[(bh * ns + k) * 1024 + idx];
+      s += sump[(bh * ns + k) * 32 + d];
+    }
+    ctx[bh * 1024 + idx] = a / s * invN;
+  }
+}
+
+// grid (chunks, B): thread = (pixel, head); ctx of the image's 4 heads in LDS (head pitch 1028 floats: 16-byte aligned
+// and the four heads a wave touches fall on different bank quads)
+template <typename T>
+__global__ __launch_bounds__(256) void la_out_kernel(const T* __restrict__ qkv, const float* __restrict__ ctx,
+                                                     T* __restrict__ out, int N) {
+  constexpr int VEC = Elem<T>::kVec;
+  __shared__ __attribute__((aligned(16))) float cs[4 * 1028];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < 4096; i += 256) cs[(i >> 10) * 1028 + (i & 1023)] = ctx[(size_t)b * 4096 + i];
+  __syncthreads();
+  const int h = tid & 3;
+  const float* c = cs + h * 1028;
+  for (int n = blockIdx.x * 64 + (tid >> 2); n < N; n += gridDim.x * 64) {
+    const T* qp = qkv + ((size_t)b * N + n) * 384 + h * 32;
+    float q[32];
+#pragma unroll
+    for (int k = 0; k < 32 / VEC; ++k) {
+      Vec16<T> t = vec_load(qp + k * VEC);
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) q[k * VEC + u] = Elem<T>::load(t.e[u]);
+    }
+    float m = q[0];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) m = fmaxf(m, q[k]);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { q[k] = expf(q[k] - m); s += q[k]; }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) q[k] = q[k] * inv * 0.17677669529663687f;  // softmax, then * 32^-0.5
+    float o[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) o[e] = 0.0f;
+#pragma unroll 2
+    for (int dd = 0; dd < 32; ++dd) {
+      const float qd = q[dd];
+#pragma unroll
+      for (int e4 = 0; e4 < 8; ++e4) {
+        const float4 cv = *reinterpret_cast<const float4*>(c + dd * 32 + e4 * 4);
+        o[e4 * 4 + 0] = fmaf(cv.x, qd, o[e4 * 4 + 0]);
+        o[e4 * 4 + 1] = fmaf(cv.y, qd, o[e4 * 4 + 1]);
+        o[e4 * 4 + 2] = fmaf(cv.z, qd, o[e4 * 4 + 2]);
+        o[e4 * 4 + 3] = fmaf(cv.w, qd, o[e4 * 4 + 3]);
+      }
+    }
+    T* op = out + ((size_t)b * N + n) * 128 + h * 32;
+#pragma unroll
+    for (int k = 0; k < 32 / VEC; ++k) {
+      Vec16<T> w;
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) w.e[u] = Elem<T>::store(o[k * VEC + u]);
+      vec_store(op + k * VEC, w);
+    }
+  }
+}
+
+template <typename T>
+int launch_linear_attention(const T* qkv, T* out, float* ws, int B, int N, hipStream_t s) {
+  PRG_CHECK(qkv && out && ws && B > 0 && N > 0, "linear attention: bad arguments");
+  const int ns = la_nsplit(N);
+  const int slab = ceil_div(N, ns);
+  float* kmax = ws;
+  float* ctxp = kmax + (size_t)B * 128;
+  float* sump = ctxp + (size_t)B * 4 * ns * 1024;
+  float* ctx = sump + (size_t)B * 4 * ns * 32;
+  fill_u32_kernel<<<ceil_div(B * 128, 256), 256, 0, s>>>(reinterpret_cast<uint32_t*>(kmax), 0xFF800000u,
+                                                        (size_t)B * 128);
+  PRG_LAUNCH_CHECK();
+  la_kmax_kernel<T><<<dim3(ns, B), 256, 0, s>>>(qkv, kmax, N, slab);
+  PRG_LAUNCH_CHECK();
+  la_ctx_kernel<T><<<dim3(ns, 4, B), 256, 0, s>>>(qkv, kmax, ctxp, sump, N, slab);
+  PRG_LAUNCH_CHECK();
+  la_fin_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctx, ns, N);
+  PRG_LAUNCH_CHECK();
+  int chunks = ceil_div(N, 64);
+  if (chunks > 256) chunks = 256;
+  la_out_kernel<T><<<dim3(chunks, B), 256, 0, s>>>(qkv, ctx, out, N);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_linear_attention<float>(const float*, float*, float*, int, int, hipStream_t);
+template int launch_linear_attention<bf16_t>(const bf16_t*, bf16_t*, float*, int, int, hipStream_t);
+
+// =============================================================================================
+// bottleneck attention core (sd:789-795): one thread per query, keys/values of a (b, head) staged through LDS in
+// chunks of 256; two passes (row max, then exp / sum / PV) = the reference's softmax order.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void full_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N) {
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int KC = 128;
+  __shared__ __attribute__((aligned(16))) float Ks[KC][32];
+  __shared__ __attribute__((aligned(16))) float Vs[KC][32];
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  const int iq = i < N ? i : N - 1;
+  const T* base = qkv + (size_t)b * N * 384;
+  float q[32];
+  {
+    const T* qp = base + (size_t)iq * 384 + h * 32;
+#pragma unroll
+    for (int k = 0; k < 32 / VEC; ++k) {
+      Vec16<T> t = vec_load(qp + k * VEC);
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) q[k * VEC + u] = Elem<T>::load(t.e[u]) * 0.17677669529663687f;
+    }
+  }
+  float m = -INFINITY, l = 0.0f, acc[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) acc[e] = 0.0f;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int j0 = 0; j0 < N; j0 += KC) {
+      const int cnt = min(KC, N - j0);
+      __syncthreads();
+      for (int idx = tid; idx < KC * 32; idx += 256) {
+        const int j = idx >> 5, ch = idx & 31;
+        float kvv = 0.0f, vvv = 0.0f;
+        if (j < cnt) {
+          kvv = Elem<T>::load(base[(size_t)(j0 + j) * 384 + 128 + h * 32 + ch]);
+          if (pass) vvv = Elem<T>::load(base[(size_t)(j0 + j) * 384 + 256 + h * 32 + ch]);
+        }
+        Ks[j][ch] = kvv;
+        if (pass) Vs[j][ch] = vvv;
+      }
+      __syncthreads();
+      for (int j = 0; j < cnt; ++j) {
+        float sdot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sdot = fmaf(q[k], Ks[j][k], sdot);
+        if (pass == 0) {
+          m = fmaxf(m, sdot);
+        } else {
+          const float pj = expf(sdot - m);
+          l += pj;
+#pragma unroll
+          for (int e = 0; e < 32; ++e) acc[e] = fmaf(pj, Vs[j][e], acc[e]);
+        }
+      }
+    }
+  }
+  if (i < N) {
+    const float inv = 1.0f / l;
+    T* op = out + ((size_t)b * N + i) * 128 + h * 32;
+#pragma unroll
+    for (int k = 0; k < 32 / VEC; ++k) {
+      Vec16<T> w;
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) w.e[u] = Elem<T>::store(acc[k * VEC + u] * inv);
+      vec_store(op + k * VEC, w);
+    }
+  }
+}
+
+template <typename T>
+int launch_full_attention(const T* qkv, T* out, int B, int N, hipStream_t s) {
+  PRG_CHECK(qkv && out && B > 0 && N > 0, "attention: bad arguments");
+  full_attn_kernel<T><<<dim3(ceil_div(N, 256), 4, B), 256, 0, s>>>(qkv, out, N);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_full_attention<float>(const float*, float*, int, int, hipStream_t);
+template int launch_full_attention<bf16_t>(const bf16_t*, bf16_t*, int, int, hipStream_t);
+
+// =============================================================================================
+// conditioning MLP pieces (float32, tiny)
+// =============================================================================================
+__device__ inline float act_apply(float v, int act) {
+  if (act == ACT_SILU) return silu_f(v);
+  if (act == ACT_GELU) return gelu_erf_f(v);
+  return v;
+}
+
+__global__ void linear_kernel(const float* __restrict__ x, int ldx, int xoff, const float* __restrict__ W, int ldw,
+                              int woff, const float* __restrict__ bias, float* __restrict__ y, int ldy, int R, int I,
+                              int O, int act_in, int act_out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)R * O) return;
+  const int r = (int)(idx / O), o = (int)(idx - (int64_t)r * O);
+  const float* xr = x + (size_t)r * ldx + xoff;
+  const float* wr = W + (size_t)o * ldw + woff;
+  float acc = 0.0f;
+  for (int i = 0; i < I; ++i) acc = fmaf(act_apply(xr[i], act_in), wr[i], acc);
+  if (bias) acc += bias[o];
+  y[(size_t)r * ldy + o] = act_apply(acc, act_out);
+}
+
+int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, int woff, const float* bias, float* y,
+                  int ldy, int R, int I, int O, int act_in, int act_out, hipStream_t s) {
+  PRG_CHECK(x && W && y && R > 0 && I > 0 && O > 0, "linear: bad arguments");
+  linear_kernel<<<ceil_div((int64_t)R * O, 256), 256, 0, s>>>(x, ldx, xoff, W, ldw, woff, bias, y, ldy, R, I, O, act_in,
+                                                             act_out);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+template <typename TI>
+__global__ void sinusoidal_kernel(const TI* __restrict__ t, float* __restrict__ out, int R, int dim) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (idx >= R * half) return;
+  const int r = idx / half, i = idx - r * half;
+  const float step = -(float)(9.210340371976184 / (double)(half - 1));  // -ln(1e4)/(half-1), rounded to f32 like torch
+  const float f = expf((float)i * step);
+  const float a = (float)t[r] * f;
+  out[(size_t)r * dim + i] = sinf(a);
+  out[(size_t)r * dim + half + i] = cosf(a);
+}
+
+int launch_sinusoidal(const int64_t* t, float* out, int R, int dim, hipStream_t s) {
+  PRG_CHECK(t && out && R > 0 && dim >= 4 && dim % 2 == 0, "sinusoidal: bad arguments");
+  sinusoidal_kernel<int64_t><<<ceil_div(R * (dim / 2), 256), 256, 0, s>>>(t, out, R, dim);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+int launch_sinusoidal_i32(const int32_t* t, float* out, int R, int dim, hipStream_t s) {
+  PRG_CHECK(t && out && R > 0 && dim >= 4 && dim % 2 == 0, "sinusoidal: bad arguments");
+  sinusoidal_kernel<int32_t><<<ceil_div(R * (dim / 2), 256), 256, 0, s>>>(t, out, R, dim);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+// =============================================================================================
+// debug taps
+// =============================================================================================
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ out, int HW, int C, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / ((size_t)HW * C), rem = i - b * HW * C;
+    const int c = (int)(rem / HW), p = (int)(rem - (size_t)c * HW);
+    out[i] = Elem<T>::load(x[(b * HW + p) * C + c]);
+  }
+}
+template <typename T>
+int launch_nhwc_to_nchw_f32(const T* x, float* out, int B, int HW, int C, hipStream_t s) {
+  const size_t n = (size_t)B * HW * C;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  nhwc_to_nchw_kernel<T><<<grid, 256, 0, s>>>(x, out, HW, C, n);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_nhwc_to_nchw_f32<float>(const float*, float*, int, int, int, hipStream_t);
+template int launch_nhwc_to_nchw_f32<bf16_t>(const bf16_t*, float*, int, int, int, hipStream_t);
+
+}  // namespace prg

@@ -1,0 +1,135 @@
+// common.h — shared device/host helpers for libprg_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/prg.h"
+
+namespace prg {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (thread-local message behind prg_last_error)
+// ---------------------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define PRG_HIP(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      return ::prg::fail(PRG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+  } while (0)
+
+#define PRG_CHECK(cond, msg)                                                                     \
+  do {                                                                                           \
+    if (!(cond)) return ::prg::fail(PRG_E_INVALID, std::string(msg) + " [" #cond "]");           \
+  } while (0)
+
+#define PRG_LAUNCH_CHECK()                                                                       \
+  do {                                                                                           \
+    hipError_t _e = hipGetLastError();                                                           \
+    if (_e != hipSuccess) return ::prg::fail(PRG_E_HIP, std::string("launch: ") + hipGetErrorString(_e)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// bf16 storage type (raw 16 bits; conversions round-to-nearest-even, NaN preserved)
+// ---------------------------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+
+__host__ __device__ inline float bf16_to_f32(bf16_t b) {
+  union {
+    uint32_t u;
+    float f;
+  } x;
+  x.u = ((uint32_t)b.v) << 16;
+  return x.f;
+}
+
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  union {
+    uint32_t u;
+    float f;
+  } x;
+  x.f = f;
+  bf16_t r;
+  if ((x.u & 0x7fffffffu) > 0x7f800000u) {  // NaN
+    r.v = (uint16_t)((x.u >> 16) | 0x40);
+    return r;
+  }
+  uint32_t lsb = (x.u >> 16) & 1u;
+  x.u += 0x7fffu + lsb;
+  r.v = (uint16_t)(x.u >> 16);
+  return r;
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int kVec = 4;  // elements per 16-byte vector
+  __host__ __device__ static inline float load(float v) { return v; }
+  __host__ __device__ static inline float store(float v) { return v; }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int kVec = 8;
+  __host__ __device__ static inline float load(bf16_t v) { return bf16_to_f32(v); }
+  __host__ __device__ static inline bf16_t store(float v) { return f32_to_bf16(v); }
+};
+
+// 16-byte vector of T with element access as float
+template <typename T>
+struct alignas(16) Vec16 {
+  T e[Elem<T>::kVec];
+};
+
+template <typename T>
+__device__ inline Vec16<T> vec_zero() {
+  Vec16<T> v;
+  uint4 z = make_uint4(0, 0, 0, 0);
+  *reinterpret_cast<uint4*>(&v) = z;
+  return v;
+}
+template <typename T>
+__device__ inline Vec16<T> vec_load(const T* p) {
+  Vec16<T> v;
+  *reinterpret_cast<uint4*>(&v) = *reinterpret_cast<const uint4*>(p);
+  return v;
+}
+template <typename T>
+__device__ inline void vec_store(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (wave = 64)
+// ---------------------------------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// activations
+// ---------------------------------------------------------------------------------------------
+__device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ inline float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace prg

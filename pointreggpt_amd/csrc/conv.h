@@ -1,0 +1,62 @@
+// conv.h — launch interface of the implicit-GEMM convolution and its weight packing.
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+namespace prg {
+
+// K-chunk (elements of one tap's channel range staged per main-loop iteration): 64 bytes per tile row.
+template <typename T>
+struct ConvTile {
+  static constexpr int BK = 64 / (int)sizeof(T);  // bf16: 32, f32: 16
+};
+
+// Optional prologue applied to the INPUT of a convolution while it is staged into LDS — this is how
+// GroupNorm + (scale+1, shift) + SiLU of the previous Block is fused into the consuming conv.
+struct ConvDesc {
+  // geometry
+  int B, Hin, Win;          // source tensors' spatial size (before optional x2 nearest upsample)
+  int C0, C1;               // channels of src0 / src1 (virtual concat [src0, src1]); C1 = 0 when unused
+  int ups;                  // 1: conv runs on the 2x nearest-upsampled image (Upsample, sd:592-594)
+  int KH, KW, stride, pad;
+  int Hout, Wout;
+  int Cout, CoutPad;        // CoutPad = Cout rounded up to 64: packed weight rows (zeros beyond Cout)
+  int kchunks;              // ceil((C0+C1) / BK)
+};
+
+// Packed weights: [tap = kh*KW+kw][chunk][CoutPad][BK] of T, zero padded in both Cout and channel.
+template <typename T>
+void pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, std::vector<T>& out, int* CoutPad,
+                      int* kchunks);
+
+template <typename T>
+struct ConvLaunch {
+  ConvDesc d;
+  const T* src0;
+  const T* src1;
+  const T* w;            // packed
+  const float* bias;     // [Cout] or null
+  const T* residual;     // NHWC (M, Cout) added in the epilogue, or null
+  T* out;                // NHWC (M, Cout)
+};
+
+template <typename T>
+int launch_conv(const ConvLaunch<T>& L, hipStream_t s);
+
+inline double conv_flops(const ConvDesc& d) {
+  return 2.0 * (double)d.B * d.Hout * d.Wout * d.Cout * (double)(d.C0 + d.C1) * d.KH * d.KW;
+}
+
+// Direct (VALU) stem conv 7x7 pad 3: float32 NCHW (B,Cin,H,W) with Cin in {1,3} -> T NHWC (B,H,W,Cout).
+// wk = float32 [49*Cin][Cout] (tap-major, then cin), bias float32 [Cout].
+template <typename T>
+int launch_stem_conv(const float* x, const float* wk, const float* bias, T* out, int B, int Cin, int H, int W,
+                     int Cout, hipStream_t s);
+
+// Head: 1x1 conv to ONE channel (+ optional sigmoid): T NHWC (M, C) -> float32 (M,).
+template <typename T>
+int launch_head_conv(const T* x, const float* w, const float* bias, float* out, int64_t M, int C, int sigmoid,
+                     hipStream_t s);
+
+}  // namespace prg

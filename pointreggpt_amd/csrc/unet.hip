@@ -1,0 +1,919 @@
+// unet.hip — host side of the two U-Nets and of the sampler: weight arena, layer walk, workspace, hipGraph.
+//
+// Mirrors (structure only) Unet.forward sd:920-964, MaskUnet.forward dc:871-906, GaussianDiffusion.sample
+// sd:1283-1409.  Activations live as NHWC tensors of T (bf16_t or float) in a stack arena owned by the handle;
+// the skip `torch.cat` never materialises (two source pointers into the conv), `nn.Upsample` is folded into the
+// following conv's gather, weight standardisation is folded into the packed weights at load time.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "blocks.h"
+#include "conv.h"
+#include "sampler.h"
+
+namespace prg {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(int code, const std::string& m) {
+  g_err = m;
+  return code;
+}
+const char* last_error() { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// device stack arena
+// ---------------------------------------------------------------------------------------------
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, top = 0, high = 0;
+  bool dry = false;  // dry run: only measure
+  void* alloc(size_t bytes) {
+    size_t a = (top + 255) & ~(size_t)255;
+    top = a + bytes;
+    if (top > high) high = top;
+    if (dry) return reinterpret_cast<void*>((uintptr_t)0x1000 + a);  // never dereferenced
+    return (top <= cap) ? base + a : nullptr;
+  }
+  size_t mark() const { return top; }
+  void reset(size_t m) { top = m; }
+};
+
+struct ProfileSink {  // per-launch conv timing (bench roofline)
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+  double conv_ms = 0, conv_flops = 0;
+  int64_t launches = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// parameter walk: the flat float32 array is the reference state_dict in order (weights.param_spec)
+// ---------------------------------------------------------------------------------------------
+struct ConvP {
+  int Cout = 0, Cin = 0, KH = 0, KW = 0, CoutPad = 0, kchunks = 0;
+  size_t w_off = 0;        // element offset into the packed-T arena
+  int64_t b_off = -1;      // float offset of the bias in the flat array (-1: none)
+  int64_t w_flat = -1;     // float offset of the raw OIHW weight in the flat array
+  bool ws = false;         // weight-standardised (Block.proj)
+};
+struct ResP {
+  int cin = 0, cout = 0;
+  int64_t mlp_w = -1, mlp_b = -1;  // Linear(2*emb -> 2*cout)
+  int ss_off = 0;                  // column offset of this block's (scale|shift) in the conditioning row
+  ConvP c1, c2, res;
+  int64_t g1 = 0, b1 = 0, g2 = 0, b2 = 0;
+  bool has_res = false;
+};
+struct AttnP {
+  int C = 0;
+  bool linear = true;
+  ConvP qkv, out;
+  int64_t out_g = -1, norm_g = -1;
+};
+struct LevelP {
+  ResP r0, r1;
+  AttnP at;
+  ConvP resample;
+  bool strided = false;  // down: 4x4 s2 ; up: nearest x2 + 3x3
+};
+
+struct Cursor {
+  int64_t pos = 0;
+  int64_t take(int64_t n) {
+    int64_t p = pos;
+    pos += n;
+    return p;
+  }
+};
+
+static void walk_conv(Cursor& c, ConvP& p, int Cout, int Cin, int K, bool bias, bool ws) {
+  p.Cout = Cout; p.Cin = Cin; p.KH = K; p.KW = K; p.ws = ws;
+  p.w_flat = c.take((int64_t)Cout * Cin * K * K);
+  p.b_off = bias ? c.take(Cout) : -1;
+}
+static void walk_res(Cursor& c, ResP& r, int cin, int cout, bool cond, int emb, int& ss_total) {
+  r.cin = cin; r.cout = cout;
+  if (cond) {
+    r.mlp_w = c.take((int64_t)2 * cout * 2 * emb);
+    r.mlp_b = c.take(2 * cout);
+    r.ss_off = ss_total;
+    ss_total += 2 * cout;
+  }
+  walk_conv(c, r.c1, cout, cin, 3, true, true);
+  r.g1 = c.take(cout); r.b1 = c.take(cout);
+  walk_conv(c, r.c2, cout, cout, 3, true, true);
+  r.g2 = c.take(cout); r.b2 = c.take(cout);
+  r.has_res = cin != cout;
+  if (r.has_res) walk_conv(c, r.res, cout, cin, 1, true, false);
+}
+static void walk_attn(Cursor& c, AttnP& a, int C, bool linear) {
+  a.C = C; a.linear = linear;
+  walk_conv(c, a.qkv, 3 * kHidden, C, 1, false, false);
+  walk_conv(c, a.out, C, kHidden, 1, true, false);
+  if (linear) a.out_g = c.take(C);
+  a.norm_g = c.take(C);
+}
+
+struct Layout {
+  prg_unet_config cfg;
+  int emb = 0, ss_total = 0, L = 0;
+  std::vector<int> dims;
+  int64_t stem_w = 0, stem_b = 0;
+  int64_t tm1_w = 0, tm1_b = 0, tm3_w = 0, tm3_b = 0, pm0_w = 0, pm0_b = 0, pm2_w = 0, pm2_b = 0;
+  std::vector<LevelP> downs, ups;
+  ResP mid1, mid2, fin;
+  AttnP mid_at;
+  int64_t head_w = 0, head_b = 0;
+  int64_t total = 0;
+};
+
+static int build_layout(const prg_unet_config& cfg, Layout& L) {
+  PRG_CHECK(cfg.dim >= 8 && cfg.dim % 8 == 0, "config: dim must be a multiple of 8");
+  PRG_CHECK(cfg.n_levels >= 1 && cfg.n_levels <= 8, "config: n_levels out of range");
+  PRG_CHECK(cfg.in_channels == 1 || cfg.in_channels == 3, "config: in_channels must be 1 or 3");
+  PRG_CHECK(cfg.groups >= 1 && cfg.groups <= 64, "config: groups out of range");
+  L.cfg = cfg;
+  L.L = cfg.n_levels;
+  L.emb = cfg.dim * 4;
+  L.dims.assign(1, cfg.dim);
+  for (int i = 0; i < cfg.n_levels; ++i) {
+    PRG_CHECK(cfg.dim_mults[i] >= 1, "config: bad dim_mult");
+    L.dims.push_back(cfg.dim * cfg.dim_mults[i]);
+  }
+  for (size_t i = 0; i < L.dims.size(); ++i) PRG_CHECK(L.dims[i] % cfg.groups == 0, "config: width not divisible by groups");
+  const bool cond = cfg.conditional != 0;
+  Cursor c;
+  const int d0 = cfg.dim, e = L.emb;
+  L.stem_w = c.take((int64_t)d0 * cfg.in_channels * 49);
+  L.stem_b = c.take(d0);
+  if (cond) {
+    L.tm1_w = c.take((int64_t)e * d0); L.tm1_b = c.take(e);
+    L.tm3_w = c.take((int64_t)e * e);  L.tm3_b = c.take(e);
+    L.pm0_w = c.take((int64_t)e * cfg.param_cond_dim); L.pm0_b = c.take(e);
+    L.pm2_w = c.take((int64_t)e * e);  L.pm2_b = c.take(e);
+  }
+  L.downs.resize(L.L);
+  L.ups.resize(L.L);
+  for (int i = 0; i < L.L; ++i) {
+    const int ci = L.dims[i], co = L.dims[i + 1];
+    LevelP& lv = L.downs[i];
+    walk_res(c, lv.r0, ci, ci, cond, e, L.ss_total);
+    walk_res(c, lv.r1, ci, ci, cond, e, L.ss_total);
+    walk_attn(c, lv.at, ci, true);
+    lv.strided = i != L.L - 1;
+    walk_conv(c, lv.resample, co, ci, lv.strided ? 4 : 3, true, false);
+  }
+  for (int i = 0; i < L.L; ++i) {
+    const int ci = L.dims[L.L - 1 - i], co = L.dims[L.L - i];
+    LevelP& lv = L.ups[i];
+    walk_res(c, lv.r0, co + ci, co, cond, e, L.ss_total);
+    walk_res(c, lv.r1, co + ci, co, cond, e, L.ss_total);
+    walk_attn(c, lv.at, co, true);
+    lv.strided = i != L.L - 1;  // here: "followed by x2 upsample"
+    walk_conv(c, lv.resample, ci, co, 3, true, false);
+  }
+  const int mid = L.dims.back();
+  walk_res(c, L.mid1, mid, mid, cond, e, L.ss_total);
+  walk_attn(c, L.mid_at, mid, false);
+  walk_res(c, L.mid2, mid, mid, cond, e, L.ss_total);
+  walk_res(c, L.fin, 2 * d0, d0, cond, e, L.ss_total);
+  L.head_w = c.take(d0);
+  L.head_b = c.take(1);
+  L.total = c.pos;
+  return PRG_OK;
+}
+
+// conditioning source for the ResnetBlocks of one forward
+struct CondSrc {
+  const float* ss_a = nullptr;
+  const float* ss_b = nullptr;
+  int64_t ss_a_stride = 0, ss_b_stride = 0;
+  const int* row = nullptr;
+  int64_t row_stride = 0;
+};
+
+struct Tap {
+  const void* ptr;
+  int C, H, W, B;
+  bool nchw_f32;
+};
+
+}  // namespace prg
+
+using namespace prg;
+
+// ---------------------------------------------------------------------------------------------
+// handle types
+// ---------------------------------------------------------------------------------------------
+struct prg_unet {
+  Layout lay;
+  int dtype = PRG_F32;
+  float* d_flat = nullptr;      // the float32 state_dict on device (biases, norm gains, MLPs read in place)
+  void* d_packed = nullptr;     // packed conv weights of T
+  float* d_stem = nullptr;      // stem weights [49*Cin][dim]
+  Arena arena;
+  int resB = 0, resS = 0;
+  bool taps_on = false;
+  std::map<std::string, Tap> taps;
+  ProfileSink* prof = nullptr;
+  virtual ~prg_unet() {}
+  virtual int measure(int B, int S, size_t* bytes) = 0;
+  virtual int forward(const float* x_nchw, const CondSrc& cond, float* out, int B, int S, hipStream_t s) = 0;
+  virtual int cond_general(const int64_t* time, const float* param_cond, int B, CondSrc* out, hipStream_t s) = 0;
+  virtual int tap_copy(const Tap& t, float* out, hipStream_t s) = 0;
+};
+
+namespace prg {
+
+template <typename T>
+struct UnetImpl : prg_unet {
+  // -------- small helpers --------
+  const float* F(int64_t off) const { return off < 0 ? nullptr : d_flat + off; }
+  const T* W(const ConvP& p) const { return reinterpret_cast<const T*>(d_packed) + p.w_off; }
+  template <typename U>
+  U* alloc(size_t n) { return reinterpret_cast<U*>(arena.alloc(n * sizeof(U))); }
+
+  int conv(const ConvP& p, const T* s0, int C0, const T* s1, int C1, int B, int Hin, int Win, int stride, int pad,
+           int ups, const T* residual, T* out, hipStream_t s) {
+    ConvLaunch<T> L;
+    L.d.B = B; L.d.Hin = Hin; L.d.Win = Win; L.d.C0 = C0; L.d.C1 = C1; L.d.ups = ups;
+    L.d.KH = p.KH; L.d.KW = p.KW; L.d.stride = stride; L.d.pad = pad;
+    const int Hl = ups ? 2 * Hin : Hin, Wl = ups ? 2 * Win : Win;
+    L.d.Hout = (Hl + 2 * pad - p.KH) / stride + 1;
+    L.d.Wout = (Wl + 2 * pad - p.KW) / stride + 1;
+    L.d.Cout = p.Cout; L.d.CoutPad = p.CoutPad; L.d.kchunks = p.kchunks;
+    L.src0 = s0; L.src1 = s1; L.w = W(p); L.bias = F(p.b_off); L.residual = residual; L.out = out;
+    PRG_CHECK(C0 + C1 == p.Cin, "conv: channel mismatch");
+    if (arena.dry) return PRG_OK;
+    if (prof && prof->on) {
+      if (prof->used == prof->pool.size()) {
+        hipEvent_t a, b;
+        PRG_HIP(hipEventCreate(&a));
+        PRG_HIP(hipEventCreate(&b));
+        prof->pool.push_back({a, b});
+      }
+      auto& ev = prof->pool[prof->used++];
+      PRG_HIP(hipEventRecord(ev.first, s));
+      int rc = launch_conv<T>(L, s);
+      PRG_HIP(hipEventRecord(ev.second, s));
+      prof->conv_flops += conv_flops(L.d);
+      prof->launches += 1;
+      return rc;
+    }
+    return launch_conv<T>(L, s);
+  }
+
+  // GroupNorm + cond + SiLU (+ residual), in place on h
+  int gn(T* h, int64_t g_off, int64_t b_off, const CondSrc* cs, int ss_off, const T* residual, int B, int HW, int C,
+         float* partials, hipStream_t s) {
+    if (arena.dry) return PRG_OK;
+    int ns = 0;
+    int rc = launch_gn_stats<T>(h, partials, B, HW, C, lay.cfg.groups, &ns, s);
+    if (rc) return rc;
+    GnApply p{};
+    p.gamma = F(g_off); p.beta = F(b_off);
+    if (cs && cs->ss_a) {
+      p.ss_a = cs->ss_a + ss_off;
+      p.ss_a_stride = cs->ss_a_stride;
+      p.ss_b = cs->ss_b ? cs->ss_b + ss_off : nullptr;
+      p.ss_b_stride = cs->ss_b_stride;
+      p.ss_a_row = cs->row;
+      p.ss_a_row_stride = cs->row_stride;
+    }
+    return launch_gn_apply<T>(h, partials, ns, p, residual, h, B, HW, C, lay.cfg.groups, s);
+  }
+
+  // ResnetBlock (sd:700-734 / dc:726-740): out <- block2(block1(cat[s0,s1])) + res(cat[s0,s1])
+  int resblock(const ResP& r, const T* s0, int C0, const T* s1, int C1, const CondSrc* cs, T* out, int B, int H, int Wd,
+               hipStream_t s) {
+    const size_t m = arena.mark();
+    const size_t M = (size_t)B * H * Wd;
+    T* h1 = alloc<T>(M * r.cout);
+    T* res = r.has_res ? alloc<T>(M * r.cout) : nullptr;
+    float* partials = alloc<float>((size_t)B * kGnMaxSplit * 64 * 2);
+    PRG_CHECK(arena.dry || (h1 && partials && (!r.has_res || res)), "workspace exhausted (resblock)");
+    int rc;
+    if ((rc = conv(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, nullptr, h1, s))) return rc;
+    if ((rc = gn(h1, r.g1, r.b1, lay.cfg.conditional ? cs : nullptr, r.ss_off, nullptr, B, H * Wd, r.cout, partials, s)))
+      return rc;
+    if ((rc = conv(r.c2, h1, r.cout, nullptr, 0, B, H, Wd, 1, 1, 0, nullptr, out, s))) return rc;
+    const T* skip = s0;
+    if (r.has_res) {
+      if ((rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, nullptr, res, s))) return rc;
+      skip = res;
+    } else {
+      PRG_CHECK(C1 == 0 && C0 == r.cout, "resblock: identity skip needs equal widths");
+    }
+    if ((rc = gn(out, r.g2, r.b2, nullptr, 0, skip, B, H * Wd, r.cout, partials, s))) return rc;
+    arena.reset(m);
+    return PRG_OK;
+  }
+
+  // Residual(PreNorm(LinearAttention | Attention)) (sd:583-589, 631-639, 737-796)
+  int attention(const AttnP& a, const T* x, T* out, int B, int H, int Wd, hipStream_t s) {
+    const size_t m = arena.mark();
+    const int N = H * Wd;
+    const size_t M = (size_t)B * N;
+    T* xn = alloc<T>(M * a.C);
+    T* qkv = alloc<T>(M * 3 * kHidden);
+    T* o = alloc<T>(M * kHidden);
+    T* y = a.linear ? alloc<T>(M * a.C) : nullptr;
+    float* ws = a.linear ? alloc<float>(linattn_ws_floats(B, N)) : nullptr;
+    PRG_CHECK(arena.dry || (xn && qkv && o && (!a.linear || (y && ws))), "workspace exhausted (attention)");
+    int rc;
+    if (!arena.dry && (rc = launch_layernorm<T>(x, F(a.norm_g), nullptr, xn, (int64_t)M, a.C, s))) return rc;
+    if ((rc = conv(a.qkv, xn, a.C, nullptr, 0, B, H, Wd, 1, 0, 0, nullptr, qkv, s))) return rc;
+    if (a.linear) {
+      if (!arena.dry && (rc = launch_linear_attention<T>(qkv, o, ws, B, N, s))) return rc;
+      if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, nullptr, y, s))) return rc;
+      if (!arena.dry && (rc = launch_layernorm<T>(y, F(a.out_g), x, out, (int64_t)M, a.C, s))) return rc;
+    } else {
+      if (!arena.dry && (rc = launch_full_attention<T>(qkv, o, B, N, s))) return rc;
+      if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, x, out, s))) return rc;
+    }
+    arena.reset(m);
+    return PRG_OK;
+  }
+
+  void tap(const char* name, const void* p, int B, int C, int H, int Wd, bool nchw = false) {
+    if (taps_on && !arena.dry) taps[name] = Tap{p, C, H, Wd, B, nchw};
+  }
+
+  int forward(const float* x_nchw, const CondSrc& cond, float* out, int B, int S, hipStream_t s) override {
+    const Layout& L = lay;
+    const int nl = L.L;
+    PRG_CHECK(S % (1 << (nl - 1)) == 0 && (S >> (nl - 1)) >= 2, "forward: image size too small for the level count");
+    PRG_CHECK((S * S) % 4 == 0, "forward: H*W must be a multiple of 4");
+    arena.reset(0);
+    if (taps_on) taps.clear();
+    const CondSrc* cs = L.cfg.conditional ? &cond : nullptr;
+    int rc;
+    const int d0 = L.cfg.dim;
+    T* x0 = alloc<T>((size_t)B * S * S * d0);
+    PRG_CHECK(arena.dry || x0, "workspace exhausted (stem)");
+    if (!arena.dry &&
+        (rc = launch_stem_conv<T>(x_nchw, d_stem, F(L.stem_b), x0, B, L.cfg.in_channels, S, S, d0, s)))
+      return rc;
+    tap("init_conv", x0, B, d0, S, S);
+    std::vector<std::pair<const T*, int>> skips;
+    const T* x = x0;
+    int H = S;
+    for (int i = 0; i < nl; ++i) {
+      const LevelP& lv = L.downs[i];
+      const int C = L.dims[i], Co = L.dims[i + 1];
+      const size_t M = (size_t)B * H * H;
+      T* s1 = alloc<T>(M * C);
+      PRG_CHECK(arena.dry || s1, "workspace exhausted (down)");
+      if ((rc = resblock(lv.r0, x, C, nullptr, 0, cs, s1, B, H, H, s))) return rc;
+      skips.push_back({s1, C});
+      if (i == 0) tap("down0_block0", s1, B, C, H, H);
+      T* s2 = alloc<T>(M * C);
+      const size_t mk = arena.mark();
+      T* t = alloc<T>(M * C);
+      PRG_CHECK(arena.dry || (s2 && t), "workspace exhausted (down)");
+      if ((rc = resblock(lv.r1, s1, C, nullptr, 0, cs, t, B, H, H, s))) return rc;
+      if ((rc = attention(lv.at, t, s2, B, H, H, s))) return rc;
+      arena.reset(mk);
+      skips.push_back({s2, C});
+      if (i == 0) tap("down0_attn", s2, B, C, H, H);
+      const int Ho = lv.strided ? H / 2 : H;
+      T* xd = alloc<T>((size_t)B * Ho * Ho * Co);
+      PRG_CHECK(arena.dry || xd, "workspace exhausted (downsample)");
+      if ((rc = conv(lv.resample, s2, C, nullptr, 0, B, H, H, lv.strided ? 2 : 1, 1, 0, nullptr, xd, s))) return rc;
+      if (i == 0) tap("down0_out", xd, B, Co, Ho, Ho);
+      x = xd;
+      H = Ho;
+    }
+    {
+      const int C = L.dims.back();
+      const size_t M = (size_t)B * H * H;
+      T* m2 = alloc<T>(M * C);
+      T* m3 = alloc<T>(M * C);
+      const size_t mk = arena.mark();
+      T* m1 = alloc<T>(M * C);
+      PRG_CHECK(arena.dry || (m1 && m2 && m3), "workspace exhausted (mid)");
+      if ((rc = resblock(L.mid1, x, C, nullptr, 0, cs, m1, B, H, H, s))) return rc;
+      if ((rc = attention(L.mid_at, m1, m2, B, H, H, s))) return rc;
+      arena.reset(mk);
+      tap("mid_attn", m2, B, C, H, H);
+      if ((rc = resblock(L.mid2, m2, C, nullptr, 0, cs, m3, B, H, H, s))) return rc;
+      x = m3;
+    }
+    for (int i = 0; i < nl; ++i) {
+      const LevelP& lv = L.ups[i];
+      const int Ci = L.dims[nl - 1 - i], Co = L.dims[nl - i];  // block width Co, resample to Ci
+      const size_t M = (size_t)B * H * H;
+      const int Ho = lv.strided ? 2 * H : H;
+      T* xu = alloc<T>((size_t)B * Ho * Ho * Ci);
+      const size_t mk = arena.mark();
+      T* u1 = alloc<T>(M * Co);
+      T* u2 = alloc<T>(M * Co);
+      T* u3 = alloc<T>(M * Co);
+      PRG_CHECK(arena.dry || (xu && u1 && u2 && u3), "workspace exhausted (up)");
+      auto sk = skips.back(); skips.pop_back();
+      if ((rc = resblock(lv.r0, x, Co, sk.first, sk.second, cs, u1, B, H, H, s))) return rc;
+      sk = skips.back(); skips.pop_back();
+      if ((rc = resblock(lv.r1, u1, Co, sk.first, sk.second, cs, u2, B, H, H, s))) return rc;
+      if ((rc = attention(lv.at, u2, u3, B, H, H, s))) return rc;
+      if ((rc = conv(lv.resample, u3, Co, nullptr, 0, B, H, H, 1, 1, lv.strided ? 1 : 0, nullptr, xu, s))) return rc;
+      arena.reset(mk);
+      if (i == 0) tap("up0_out", xu, B, Ci, Ho, Ho);
+      x = xu;
+      H = Ho;
+    }
+    {
+      const size_t M = (size_t)B * H * H;
+      T* fr = alloc<T>(M * d0);
+      PRG_CHECK(arena.dry || fr, "workspace exhausted (final)");
+      if ((rc = resblock(L.fin, x, d0, x0, d0, cs, fr, B, H, H, s))) return rc;
+      tap("final_res", fr, B, d0, H, H);
+      if (!arena.dry && (rc = launch_head_conv<T>(fr, F(L.head_w), F(L.head_b), out, (int64_t)M, d0,
+                                                  L.cfg.sigmoid_out, s)))
+        return rc;
+    }
+    return PRG_OK;
+  }
+
+  int measure(int B, int S, size_t* bytes) override {
+    Arena saved = arena;
+    arena = Arena();
+    arena.dry = true;
+    CondSrc cs;
+    int rc = forward(nullptr, cs, nullptr, B, S, nullptr);
+    // general-path conditioning scratch lives in the same arena, after the activations
+    size_t extra = 0;
+    if (lay.cfg.conditional) extra = ((size_t)B * (lay.cfg.dim + 5 * lay.emb + lay.ss_total) * sizeof(float) + 4096);
+    if (lay.cfg.in_channels == 3) extra += (size_t)B * 3 * S * S * sizeof(float) + 4096;  // DepthAugment output
+    *bytes = arena.high + extra + (1 << 20);
+    arena = saved;
+    return rc;
+  }
+
+  // general conditioning path (per-image timesteps): cond = cat[time_mlp(t), param_mlp(K)] -> every block's Linear
+  int cond_general(const int64_t* time, const float* param_cond, int B, CondSrc* out, hipStream_t s) override {
+    const Layout& L = lay;
+    const int e = L.emb, d0 = L.cfg.dim;
+    // placed at the top of the arena so the forward's stack (which starts at 0) cannot reach it
+    size_t need = (size_t)B * (d0 + 5 * e + L.ss_total) * sizeof(float) + 4096;
+    PRG_CHECK(arena.cap >= need, "workspace too small for conditioning");
+    float* base = reinterpret_cast<float*>(arena.base + ((arena.cap - need) & ~(size_t)255));
+    float* sinu = base;                       // [B][d0]
+    float* h1 = sinu + (size_t)B * d0;        // [B][e]
+    float* cat = h1 + (size_t)B * e;          // [B][2e]  = [t_emb | p_emb]
+    float* h2 = cat + (size_t)B * 2 * e;      // [B][e]
+    float* ss = h2 + (size_t)B * e;           // [B][ss_total]
+    int rc;
+    if ((rc = launch_sinusoidal(time, sinu, B, d0, s))) return rc;
+    if ((rc = launch_linear(sinu, d0, 0, F(L.tm1_w), d0, 0, F(L.tm1_b), h1, e, B, d0, e, ACT_NONE, ACT_GELU, s))) return rc;
+    if ((rc = launch_linear(h1, e, 0, F(L.tm3_w), e, 0, F(L.tm3_b), cat, 2 * e, B, e, e, ACT_NONE, ACT_NONE, s))) return rc;
+    const int pc = L.cfg.param_cond_dim;
+    if ((rc = launch_linear(param_cond, pc, 0, F(L.pm0_w), pc, 0, F(L.pm0_b), h2, e, B, pc, e, ACT_NONE, ACT_GELU, s))) return rc;
+    if ((rc = launch_linear(h2, e, 0, F(L.pm2_w), e, 0, F(L.pm2_b), cat + e, 2 * e, B, e, e, ACT_NONE, ACT_NONE, s))) return rc;
+    auto one = [&](const ResP& r) -> int {
+      return launch_linear(cat, 2 * e, 0, F(r.mlp_w), 2 * e, 0, F(r.mlp_b), ss + r.ss_off, L.ss_total, B, 2 * e,
+                           2 * r.cout, ACT_SILU, ACT_NONE, s);
+    };
+    for (auto& lv : L.downs) { if ((rc = one(lv.r0))) return rc; if ((rc = one(lv.r1))) return rc; }
+    for (auto& lv : L.ups) { if ((rc = one(lv.r0))) return rc; if ((rc = one(lv.r1))) return rc; }
+    if ((rc = one(L.mid1))) return rc;
+    if ((rc = one(L.mid2))) return rc;
+    if ((rc = one(L.fin))) return rc;
+    out->ss_a = ss;
+    out->ss_a_stride = L.ss_total;
+    out->ss_b = nullptr;
+    out->row = nullptr;
+    return PRG_OK;
+  }
+
+  int tap_copy(const Tap& t, float* out, hipStream_t s) override {
+    if (t.nchw_f32) {
+      PRG_HIP(hipMemcpyAsync(out, t.ptr, (size_t)t.B * t.C * t.H * t.W * sizeof(float), hipMemcpyDeviceToDevice, s));
+      return PRG_OK;
+    }
+    return launch_nhwc_to_nchw_f32<T>(reinterpret_cast<const T*>(t.ptr), out, t.B, t.H * t.W, t.C, s);
+  }
+};
+
+// ---- weight preparation (host) ---------------------------------------------------------------
+static void standardize(const float* w, int Cout, int K, std::vector<float>& out) {
+  out.resize((size_t)Cout * K);
+  for (int o = 0; o < Cout; ++o) {
+    double m = 0;
+    for (int k = 0; k < K; ++k) m += w[(size_t)o * K + k];
+    m /= K;
+    double v = 0;
+    for (int k = 0; k < K; ++k) { double d = w[(size_t)o * K + k] - m; v += d * d; }
+    v /= K;
+    const double rs = 1.0 / std::sqrt(v + 1e-5);
+    for (int k = 0; k < K; ++k) out[(size_t)o * K + k] = (float)((w[(size_t)o * K + k] - m) * rs);
+  }
+}
+
+template <typename T>
+static void pack_all(Layout& L, const float* flat, std::vector<T>& packed) {
+  std::vector<ConvP*> convs;
+  auto add_res = [&](ResP& r) { convs.push_back(&r.c1); convs.push_back(&r.c2); if (r.has_res) convs.push_back(&r.res); };
+  auto add_at = [&](AttnP& a) { convs.push_back(&a.qkv); convs.push_back(&a.out); };
+  for (auto& lv : L.downs) { add_res(lv.r0); add_res(lv.r1); add_at(lv.at); convs.push_back(&lv.resample); }
+  for (auto& lv : L.ups) { add_res(lv.r0); add_res(lv.r1); add_at(lv.at); convs.push_back(&lv.resample); }
+  add_res(L.mid1); add_at(L.mid_at); add_res(L.mid2); add_res(L.fin);
+  std::vector<float> tmp;
+  std::vector<T> one;
+  for (ConvP* p : convs) {
+    const float* w = flat + p->w_flat;
+    if (p->ws) { standardize(w, p->Cout, p->Cin * p->KH * p->KW, tmp); w = tmp.data(); }
+    pack_conv_weight<T>(w, p->Cout, p->Cin, p->KH, p->KW, one, &p->CoutPad, &p->kchunks);
+    size_t off = (packed.size() + 127) / 128 * 128;  // 256-byte aligned tiles
+    packed.resize(off + one.size());
+    std::memcpy(packed.data() + off, one.data(), one.size() * sizeof(T));
+    p->w_off = off;
+  }
+}
+
+template <typename T>
+static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t n, prg_unet** out) {
+  std::unique_ptr<UnetImpl<T>> u(new UnetImpl<T>());
+  int rc = build_layout(*cfg, u->lay);
+  if (rc) return rc;
+  if (u->lay.total != n)
+    return fail(PRG_E_INVALID, "prg_unet_create: expected " + std::to_string(u->lay.total) + " floats, got " +
+                                   std::to_string(n));
+  std::vector<T> packed;
+  pack_all<T>(u->lay, weights, packed);
+  const Layout& L = u->lay;
+  std::vector<float> stem((size_t)49 * L.cfg.in_channels * L.cfg.dim);
+  for (int o = 0; o < L.cfg.dim; ++o)
+    for (int c = 0; c < L.cfg.in_channels; ++c)
+      for (int t = 0; t < 49; ++t)
+        stem[((size_t)t * L.cfg.in_channels + c) * L.cfg.dim + o] = weights[L.stem_w + ((size_t)o * L.cfg.in_channels + c) * 49 + t];
+  if (hipMalloc(&u->d_flat, (size_t)n * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(flat weights)");
+  if (hipMalloc(&u->d_packed, packed.size() * sizeof(T)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(packed weights)");
+  if (hipMalloc(&u->d_stem, stem.size() * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(stem weights)");
+  PRG_HIP(hipMemcpy(u->d_flat, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  PRG_HIP(hipMemcpy(u->d_packed, packed.data(), packed.size() * sizeof(T), hipMemcpyHostToDevice));
+  PRG_HIP(hipMemcpy(u->d_stem, stem.data(), stem.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = u.release();
+  return PRG_OK;
+}
+
+static int reserve(prg_unet* h, int B, int S) {
+  if (B <= h->resB && S <= h->resS && h->arena.base) return PRG_OK;
+  size_t bytes = 0;
+  const int nb = B > h->resB ? B : h->resB, ns = S > h->resS ? S : h->resS;
+  int rc = h->measure(nb, ns, &bytes);
+  if (rc) return rc;
+  PRG_HIP(hipDeviceSynchronize());
+  if (h->arena.base) PRG_HIP(hipFree(h->arena.base));
+  h->arena = Arena();
+  if (hipMalloc(reinterpret_cast<void**>(&h->arena.base), bytes) != hipSuccess) {
+    h->arena.base = nullptr;
+    h->resB = h->resS = 0;
+    return fail(PRG_E_NOMEM, "hipMalloc(workspace " + std::to_string(bytes >> 20) + " MiB)");
+  }
+  h->arena.cap = bytes;
+  h->resB = nb;
+  h->resS = ns;
+  return PRG_OK;
+}
+
+}  // namespace prg
+
+// =============================================================================================
+// sampler handle
+// =============================================================================================
+struct prg_sampler {
+  prg_unet* unet = nullptr;
+  int B = 0, S = 0, n_steps = 0;
+  std::vector<prg_step> steps;
+  prg_step* d_steps = nullptr;
+  float* d_tpart = nullptr;   // [n_steps][ss_total]  time half of every block's conditioning (+ bias)
+  float* d_ppart = nullptr;   // [B][ss_total]        camera-parameter half
+  float* d_scratch = nullptr; // embedding scratch
+  float* d_x = nullptr;       // state (B, S*S)
+  float* d_u = nullptr;       // network output
+  int* d_step = nullptr;
+  uint64_t* d_seeds = nullptr;
+  hipStream_t own_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const float* g_cond = nullptr;   // pointers baked into the captured graph
+  const float* g_noise = nullptr;
+  float* g_out = nullptr;
+  hipStream_t g_stream = nullptr;
+  bool use_graph = true;
+  ProfileSink prof;
+  double last_total_ms = 0;
+};
+
+namespace prg {
+
+static void sampler_free(prg_sampler* h) {
+  if (h->exec) hipGraphExecDestroy(h->exec);
+  if (h->graph) hipGraphDestroy(h->graph);
+  h->exec = nullptr;
+  h->graph = nullptr;
+}
+
+static int sampler_one_step(prg_sampler* h, const float* cond, const float* noise, float* out, hipStream_t s) {
+  CondSrc cs;
+  cs.ss_a = h->d_tpart;
+  cs.ss_a_stride = 0;
+  cs.row = h->d_step;
+  cs.row_stride = h->unet->lay.ss_total;
+  cs.ss_b = h->d_ppart;
+  cs.ss_b_stride = h->unet->lay.ss_total;
+  int rc = h->unet->forward(h->d_x, cs, h->d_u, h->B, h->S, s);
+  if (rc) return rc;
+  SamplerStepArgs a;
+  a.x = h->d_x; a.u = h->d_u; a.cond = cond; a.noise = noise; a.steps = h->d_steps; a.step_idx = h->d_step;
+  a.seeds = h->d_seeds; a.final_out = out; a.B = h->B; a.HW = h->S * h->S; a.n_steps = h->n_steps;
+  if ((rc = launch_sampler_step(a, s))) return rc;
+  return launch_advance_step(h->d_step, s);
+}
+
+}  // namespace prg
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int prg_abi_version(void) { return PRG_ABI_VERSION; }
+const char* prg_last_error(void) { return prg::last_error(); }
+
+int prg_device_info(char* name, size_t name_len, int* compute_units) {
+  int dev = 0;
+  PRG_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  PRG_HIP(hipGetDeviceProperties(&p, dev));
+  if (name && name_len) {
+    std::strncpy(name, p.gcnArchName, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  return PRG_OK;
+}
+
+int64_t prg_unet_param_count(const prg_unet_config* cfg) {
+  if (!cfg) return PRG_E_INVALID;
+  Layout L;
+  if (build_layout(*cfg, L)) return PRG_E_INVALID;
+  return L.total;
+}
+
+int prg_unet_create(const prg_unet_config* cfg, const float* weights, int64_t n_floats, int dtype, prg_unet** out) {
+  PRG_CHECK(cfg && weights && out, "prg_unet_create: null pointer");
+  PRG_CHECK(dtype == PRG_F32 || dtype == PRG_BF16, "prg_unet_create: dtype must be PRG_F32 or PRG_BF16");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PRG_E_HIP, "prg_unet_create: no HIP device");
+  *out = nullptr;
+  int rc = dtype == PRG_F32 ? create_impl<float>(cfg, weights, n_floats, out)
+                            : create_impl<bf16_t>(cfg, weights, n_floats, out);
+  if (rc == PRG_OK) (*out)->dtype = dtype;
+  return rc;
+}
+
+int prg_unet_destroy(prg_unet* h) {
+  if (!h) return PRG_OK;
+  hipDeviceSynchronize();
+  if (h->d_flat) hipFree(h->d_flat);
+  if (h->d_packed) hipFree(h->d_packed);
+  if (h->d_stem) hipFree(h->d_stem);
+  if (h->arena.base) hipFree(h->arena.base);
+  delete h;
+  return PRG_OK;
+}
+
+int prg_unet_reserve(prg_unet* h, int B, int S) {
+  PRG_CHECK(h && B > 0 && S > 0, "prg_unet_reserve: bad arguments");
+  return reserve(h, B, S);
+}
+
+int prg_unet_set_taps(prg_unet* h, int enable) {
+  PRG_CHECK(h, "prg_unet_set_taps: null handle");
+  h->taps_on = enable != 0;
+  return PRG_OK;
+}
+
+int prg_unet_get_tap(prg_unet* h, const char* name, float* out, int64_t cap, int* C, int* H, int* W, void* stream) {
+  PRG_CHECK(h && name && out, "prg_unet_get_tap: null pointer");
+  auto it = h->taps.find(name);
+  if (it == h->taps.end()) return fail(PRG_E_STATE, std::string("no such tap recorded: ") + name);
+  const Tap& t = it->second;
+  PRG_CHECK((int64_t)t.B * t.C * t.H * t.W <= cap, "prg_unet_get_tap: output buffer too small");
+  if (C) *C = t.C;
+  if (H) *H = t.H;
+  if (W) *W = t.W;
+  return h->tap_copy(t, out, (hipStream_t)stream);
+}
+
+int prg_unet_forward(prg_unet* h, const float* x, const int64_t* time, const float* param_cond, float* out, int B,
+                     int S, void* stream) {
+  PRG_CHECK(h && x && out, "prg_unet_forward: null pointer");
+  PRG_CHECK(h->lay.cfg.conditional && time && param_cond, "prg_unet_forward: handle is not a conditional U-Net");
+  PRG_CHECK(h->lay.cfg.in_channels == 1, "prg_unet_forward: in_channels must be 1");
+  PRG_CHECK(B > 0 && S > 0, "prg_unet_forward: bad shape");
+  int rc = reserve(h, B, S);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  CondSrc cs;
+  if ((rc = h->cond_general(time, param_cond, B, &cs, s))) return rc;
+  return h->forward(x, cs, out, B, S, s);
+}
+
+int prg_maskunet_forward(prg_unet* h, const float* depth, float* prob, int B, int S, void* stream) {
+  PRG_CHECK(h && depth && prob, "prg_maskunet_forward: null pointer");
+  PRG_CHECK(!h->lay.cfg.conditional && h->lay.cfg.in_channels == 3, "prg_maskunet_forward: handle is not a MaskUnet");
+  PRG_CHECK(B > 0 && S > 0, "prg_maskunet_forward: bad shape");
+  int rc = reserve(h, B, S);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // DepthAugment output (B,3,S,S) float32 sits at the top of the arena, out of the forward stack's reach
+  const size_t aug_bytes = (size_t)B * 3 * S * S * sizeof(float);
+  PRG_CHECK(h->arena.cap > aug_bytes + 4096, "workspace too small");
+  float* aug = reinterpret_cast<float*>(h->arena.base + ((h->arena.cap - aug_bytes - 256) & ~(size_t)255));
+  if ((rc = prg_depth_augment(depth, aug, B, S, S, stream))) return rc;
+  CondSrc cs;
+  rc = h->forward(aug, cs, prob, B, S, s);
+  if (h->taps_on) h->taps["augment"] = Tap{aug, 3, S, S, B, true};
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+int prg_sampler_create(prg_unet* unet, const prg_step* steps, int n_steps, int B, int S, prg_sampler** out) {
+  PRG_CHECK(unet && steps && out, "prg_sampler_create: null pointer");
+  PRG_CHECK(unet->lay.cfg.conditional && unet->lay.cfg.in_channels == 1, "prg_sampler_create: needs the conditional U-Net");
+  PRG_CHECK(n_steps > 0 && B > 0 && S > 0, "prg_sampler_create: bad sizes");
+  int rc = reserve(unet, B, S);
+  if (rc) return rc;
+  std::unique_ptr<prg_sampler> h(new prg_sampler());
+  h->unet = unet; h->B = B; h->S = S; h->n_steps = n_steps;
+  h->steps.assign(steps, steps + n_steps);
+  const Layout& L = unet->lay;
+  const int e = L.emb, d0 = L.cfg.dim, W = L.ss_total;
+  const size_t HW = (size_t)S * S;
+  const int R = n_steps > B ? n_steps : B;
+  if (hipMalloc(&h->d_steps, sizeof(prg_step) * n_steps) != hipSuccess ||
+      hipMalloc(&h->d_tpart, sizeof(float) * (size_t)n_steps * W) != hipSuccess ||
+      hipMalloc(&h->d_ppart, sizeof(float) * (size_t)B * W) != hipSuccess ||
+      hipMalloc(&h->d_scratch, sizeof(float) * (size_t)R * (d0 + 2 * e) + sizeof(int32_t) * n_steps) != hipSuccess ||
+      hipMalloc(&h->d_x, sizeof(float) * B * HW) != hipSuccess || hipMalloc(&h->d_u, sizeof(float) * B * HW) != hipSuccess ||
+      hipMalloc(&h->d_step, sizeof(int)) != hipSuccess || hipMalloc(&h->d_seeds, sizeof(uint64_t) * B) != hipSuccess)
+    return fail(PRG_E_NOMEM, "prg_sampler_create: hipMalloc failed");
+  PRG_HIP(hipMemcpy(h->d_steps, steps, sizeof(prg_step) * n_steps, hipMemcpyHostToDevice));
+  PRG_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault));
+  // time half of the conditioning for every transition: Tpart[k] = W_t . SiLU(time_mlp(t_k)) + bias
+  {
+    hipStream_t s = h->own_stream;
+    float* sinu = h->d_scratch;
+    float* h1 = sinu + (size_t)R * d0;
+    float* temb = h1 + (size_t)R * e;
+    int32_t* tdev = reinterpret_cast<int32_t*>(temb + (size_t)R * e);
+    std::vector<int32_t> tt(n_steps);
+    for (int k = 0; k < n_steps; ++k) tt[k] = steps[k].t;
+    PRG_HIP(hipMemcpyAsync(tdev, tt.data(), sizeof(int32_t) * n_steps, hipMemcpyHostToDevice, s));
+    const float* F = unet->d_flat;
+    if ((rc = launch_sinusoidal_i32(tdev, sinu, n_steps, d0, s))) return rc;
+    if ((rc = launch_linear(sinu, d0, 0, F + L.tm1_w, d0, 0, F + L.tm1_b, h1, e, n_steps, d0, e, ACT_NONE, ACT_GELU, s))) return rc;
+    if ((rc = launch_linear(h1, e, 0, F + L.tm3_w, e, 0, F + L.tm3_b, temb, e, n_steps, e, e, ACT_NONE, ACT_NONE, s))) return rc;
+    auto one = [&](const ResP& r) -> int {
+      return launch_linear(temb, e, 0, F + r.mlp_w, 2 * e, 0, F + r.mlp_b, h->d_tpart + r.ss_off, W, n_steps, e,
+                           2 * r.cout, ACT_SILU, ACT_NONE, s);
+    };
+    for (auto& lv : L.downs) { if ((rc = one(lv.r0))) return rc; if ((rc = one(lv.r1))) return rc; }
+    for (auto& lv : L.ups) { if ((rc = one(lv.r0))) return rc; if ((rc = one(lv.r1))) return rc; }
+    if ((rc = one(L.mid1))) return rc;
+    if ((rc = one(L.mid2))) return rc;
+    if ((rc = one(L.fin))) return rc;
+    PRG_HIP(hipStreamSynchronize(s));
+  }
+  *out = h.release();
+  return PRG_OK;
+}
+
+int prg_sampler_destroy(prg_sampler* h) {
+  if (!h) return PRG_OK;
+  hipDeviceSynchronize();
+  sampler_free(h);
+  for (auto& ev : h->prof.pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  void* ptrs[] = {h->d_steps, h->d_tpart, h->d_ppart, h->d_scratch, h->d_x, h->d_u, h->d_step, h->d_seeds};
+  for (void* p : ptrs) if (p) hipFree(p);
+  delete h;
+  return PRG_OK;
+}
+
+int prg_sampler_set_graph(prg_sampler* h, int enable) {
+  PRG_CHECK(h, "prg_sampler_set_graph: null handle");
+  h->use_graph = enable != 0;
+  return PRG_OK;
+}
+
+int prg_sampler_set_profile(prg_sampler* h, int enable) {
+  PRG_CHECK(h, "prg_sampler_set_profile: null handle");
+  h->prof.on = enable != 0;
+  return PRG_OK;
+}
+
+int prg_sampler_get_profile(prg_sampler* h, double* conv_ms, int64_t* conv_launches, double* conv_flops,
+                            double* total_ms) {
+  PRG_CHECK(h, "prg_sampler_get_profile: null handle");
+  if (conv_ms) *conv_ms = h->prof.conv_ms;
+  if (conv_launches) *conv_launches = h->prof.launches;
+  if (conv_flops) *conv_flops = h->prof.conv_flops;
+  if (total_ms) *total_ms = h->last_total_ms;
+  return PRG_OK;
+}
+
+int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_cond, const float* noise,
+                    const uint64_t* seeds, float* out, void* stream) {
+  PRG_CHECK(h && param_cond && out, "prg_sampler_run: null pointer");
+  PRG_CHECK(noise || seeds, "prg_sampler_run: need stored noise or per-scene seeds");
+  prg_unet* u = h->unet;
+  PRG_CHECK(u->resB >= h->B && u->resS >= h->S, "prg_sampler_run: U-Net workspace was shrunk");
+  hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+  const Layout& L = u->lay;
+  const int e = L.emb, W = L.ss_total, B = h->B;
+  int rc;
+  if (seeds) PRG_HIP(hipMemcpyAsync(h->d_seeds, seeds, sizeof(uint64_t) * B, hipMemcpyHostToDevice, s));
+  PRG_HIP(hipMemsetAsync(h->d_step, 0, sizeof(int), s));
+  // camera half of the conditioning: Ppart[b] = W_p . SiLU(param_mlp(K_b))
+  {
+    float* h2 = h->d_scratch;
+    float* pemb = h2 + (size_t)B * e;
+    const float* F = u->d_flat;
+    const int pc = L.cfg.param_cond_dim;
+    if ((rc = launch_linear(param_cond, pc, 0, F + L.pm0_w, pc, 0, F + L.pm0_b, h2, e, B, pc, e, ACT_NONE, ACT_GELU, s))) return rc;
+    if ((rc = launch_linear(h2, e, 0, F + L.pm2_w, e, 0, F + L.pm2_b, pemb, e, B, e, e, ACT_NONE, ACT_NONE, s))) return rc;
+    auto one = [&](const ResP& r) -> int {
+      return launch_linear(pemb, e, 0, F + r.mlp_w, 2 * e, e, nullptr, h->d_ppart + r.ss_off, W, B, e, 2 * r.cout,
+                           ACT_SILU, ACT_NONE, s);
+    };
+    for (auto& lv : L.downs) { if ((rc = one(lv.r0))) return rc; if ((rc = one(lv.r1))) return rc; }
+    for (auto& lv : L.ups) { if ((rc = one(lv.r0))) return rc; if ((rc = one(lv.r1))) return rc; }
+    if ((rc = one(L.mid1))) return rc;
+    if ((rc = one(L.mid2))) return rc;
+    if ((rc = one(L.fin))) return rc;
+  }
+  if ((rc = launch_sampler_init(h->d_x, noise, h->d_seeds, B, h->S * h->S, s))) return rc;
+
+  const bool profiling = h->prof.on;
+  u->prof = profiling ? &h->prof : nullptr;
+  h->prof.conv_ms = 0; h->prof.conv_flops = 0; h->prof.launches = 0; h->prof.used = 0;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (profiling) {
+    PRG_HIP(hipEventCreate(&t0));
+    PRG_HIP(hipEventCreate(&t1));
+    PRG_HIP(hipEventRecord(t0, s));
+  }
+  if (h->use_graph && !profiling && !u->taps_on) {
+    const bool stale = !h->exec || h->g_cond != img_cond || h->g_noise != noise || h->g_out != out || h->g_stream != s;
+    if (stale) {
+      sampler_free(h);
+      PRG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      rc = sampler_one_step(h, img_cond, noise, out, s);
+      hipGraph_t g = nullptr;
+      hipError_t ce = hipStreamEndCapture(s, &g);
+      if (rc) { if (g) hipGraphDestroy(g); return rc; }
+      if (ce != hipSuccess) return fail(PRG_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+      h->graph = g;
+      PRG_HIP(hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0));
+      h->g_cond = img_cond; h->g_noise = noise; h->g_out = out; h->g_stream = s;
+    }
+    for (int k = 0; k < h->n_steps; ++k) PRG_HIP(hipGraphLaunch(h->exec, s));
+  } else {
+    for (int k = 0; k < h->n_steps; ++k) {
+      if ((rc = sampler_one_step(h, img_cond, noise, out, s))) { u->prof = nullptr; return rc; }
+      if (profiling) {  // harvest this step's conv events (keeps the pool small)
+        PRG_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < h->prof.used; ++i) {
+          float ms = 0;
+          PRG_HIP(hipEventElapsedTime(&ms, h->prof.pool[i].first, h->prof.pool[i].second));
+          h->prof.conv_ms += ms;
+        }
+        h->prof.used = 0;
+      }
+    }
+  }
+  u->prof = nullptr;
+  if (profiling) {
+    PRG_HIP(hipEventRecord(t1, s));
+    PRG_HIP(hipEventSynchronize(t1));
+    float ms = 0;
+    PRG_HIP(hipEventElapsedTime(&ms, t0, t1));
+    h->last_total_ms = ms;
+    hipEventDestroy(t0);
+    hipEventDestroy(t1);
+  }
+  return PRG_OK;
+}
+
+}  // extern "C"

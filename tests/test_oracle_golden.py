@@ -1,0 +1,189 @@
+"""The CPU oracle (oracle/) against golden vectors produced by the real reference (tools/make_goldens.py).
+
+This is what pins the oracle: every function on the hot path is compared with the reference's own output on
+the same inputs.  torch-CPU arithmetic is shared with the reference, so most comparisons are bit-exact; where
+the oracle's expression order legitimately differs (functional vs module code paths never do here) a tolerance
+is written next to the assert."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import diffusion as OD
+from oracle import geometry as OG
+from oracle import unet as OU
+from pointreggpt_amd import weights as W
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+T = torch.tensor
+
+
+def test_state_dict_spec_matches_reference():
+    spec = json.load(open(os.path.join(GOLDEN, "state_dict_spec.json")))
+    for key, cfg in (("unet64", W.unet_config(64)), ("mask64", W.maskunet_config(64)), ("unet8", W.unet_config(8))):
+        mine = [[k, list(v)] for k, v in W.param_spec(cfg).items()]
+        assert mine == spec[key]
+    assert W.num_params(W.unet_config(64)) == 38376833       # SURVEY §2 [probe]
+    assert W.num_params(W.maskunet_config(64)) == 34096769
+
+
+def test_G1_schedule(golden):
+    g = golden("G1_schedule")
+    for T_, pre in ((1000, ""), (8, "T8_")):
+        s = OD.schedule(T_)
+        for k, v in s.items():
+            assert np.array_equal(v.numpy(), g[pre + k]), k
+    s = OD.schedule(1000)   # known-answer values quoted in SURVEY §8a
+    assert abs(float(s["betas"][0]) - 3.0027920729e-04) < 1e-12
+    assert float(s["betas"][999]) == np.float32(0.999)
+    assert float(s["posterior_mean_coef1"][0]) == 1.0 and float(s["posterior_mean_coef2"][0]) == 0.0
+    for steps in (5, 50, 250):
+        pairs = OD.ddim_time_pairs(1000, steps)
+        times = [p[0] for p in pairs] + [pairs[-1][1]]
+        assert times == g[f"ddim_times_{steps}"].tolist()
+
+
+def test_G2_intrinsic_transform(golden):
+    g = golden("G2_intrinsic_transform")
+    for S in (32, 64, 128, 256):
+        for i, k in enumerate(g["K"]):
+            assert np.array_equal(OG.intrinsic_transform(k, S, S), g[f"S{S}"][i])
+        assert np.array_equal(OG.intrinsic_transform(g["K"], S, S), g[f"S{S}_batched"])
+    assert np.allclose(OG.intrinsic_transform(g["K"][4], 64, 64)[[0, 1, 0, 1], [0, 1, 2, 2]],
+                       [75.7486, 76.0456, 32.5, 32.0], atol=1e-4)   # SURVEY §8a a21 KAT
+    assert np.array_equal(OG.candidate_intrinsics(), g["K"])
+
+
+def test_G3_random_sample_pose(golden):
+    g = golden("G3_random_sample_pose")
+    for s in (0, 1, 12345):
+        np.random.seed(s)
+        assert np.array_equal(OG.random_sample_pose(4), g[f"pose_seed{s}"])
+        assert np.array_equal(np.random.rand(2), g[f"after_seed{s}"])   # same amount of stream consumed
+
+
+def test_G4_pc2depth(golden):
+    g = golden("G4_pc2depth")
+    d, m = OG.pc2depth_tensor(T(g["pc"]), T(g["valid"]), T(g["K"]), (64, 64))
+    assert np.array_equal(d.numpy(), g["depth"]) and np.array_equal(m.numpy(), g["mask"])
+    d, m = OG.pc2depth_tensor(T(g["pc"][:, :5000]), T(g["valid"][:, :5000]), T(g["K"]), (48, 80))
+    assert np.array_equal(d.numpy(), g["depth_48x80"]) and np.array_equal(m.numpy(), g["mask_48x80"])
+
+
+def test_G5_G6_reproject_unproject(golden):
+    g = golden("G5_G6_reproject_unproject")
+    depth, K, pose = T(g["depth"]), T(g["K"]), T(g["pose"])
+    d, m = OG.reproject_tensor(depth * 10, K, pose, (0, 10))
+    assert np.array_equal(d.numpy(), g["rpj_depth"]) and np.array_equal(m.numpy(), g["rpj_mask"])
+    d, m = OG.reproject_tensor(depth * 10, K, pose, (0.5, 10))
+    assert np.array_equal(d.numpy(), g["rpj05_depth"]) and np.array_equal(m.numpy(), g["rpj05_mask"])
+    # identity pose: the round trip returns the clipped source depth bit-exactly (SURVEY §8c [probe])
+    src = (depth[2] * 10)
+    assert np.array_equal(g["rpj_depth"][2], torch.where((src > 0) & (src < 10), src, torch.zeros(())).numpy())
+    pc, ok = OG.depth2pc_tensor(depth * 10, K, (0.5, 10))
+    assert np.array_equal(pc.numpy(), g["pc"], equal_nan=True) and np.array_equal(ok.numpy(), g["pc_valid"])
+    for b in range(3):
+        p = OG.point_cloud(g["depth"][b, 0] * 10, g["K"][b], (0.5, 10))
+        assert p.dtype == np.float64 and np.array_equal(p, g[f"cloud{b}"])
+        assert np.array_equal(OG.inverse_pose_apply(p, g["pose"][b]), g[f"cloud{b}_common"])
+        dd, mm = OG.project_cloud(g[f"cloud{b}"].astype(np.float32), g["pose"][b], g["K"][b], 64)
+        assert np.array_equal(dd[0].numpy(), g[f"gen_depth{b}"]) and np.array_equal(mm[0].numpy(), g[f"gen_mask{b}"])
+
+
+def test_G7_unet_small_with_taps(golden):
+    g = golden("G7_unet_small_taps")
+    for dim in (8, 16):
+        p = W.synth_state_dict(W.unet_config(dim), 7)
+        taps = {}
+        y = OU.unet_forward(p, T(g[f"d{dim}_x"]), T(g[f"d{dim}_t"]), T(g[f"d{dim}_pc"]), taps=taps)
+        assert np.array_equal(y.numpy(), g[f"d{dim}_y"])
+        for k in ("init_conv", "down0_block0", "down0_attn", "down0_out", "mid_attn", "up0_out", "final_res"):
+            assert np.array_equal(taps[k].numpy(), g[f"d{dim}_tap_{k}"]), k
+
+
+def test_G8_unet_dim64(golden):
+    g = golden("G8_unet_dim64")
+    p = W.synth_state_dict(W.unet_config(64), 8)
+    y = OU.unet_forward(p, T(g["x"]), T(g["t"]), T(g["pc"]))
+    assert np.array_equal(y.numpy(), g["y"])
+
+
+def _denoiser(dim, seed):
+    p = W.synth_state_dict(W.unet_config(dim), seed)
+    return lambda x, t, c: OU.unet_forward(p, x, t, c)
+
+
+def test_G9_single_transitions(golden):
+    g = golden("G9_G10_sampler")
+    sch = OD.schedule(1000)
+    den = _denoiser(16, 9)
+    x, pc, cond = T(g["x"]), T(g["pc"]), T(g["cond"])
+    for t in (999, 500, 1, 0):
+        img, x0 = OD.p_sample(sch, den, x, t, pc, cond, T(g[f"ps{t}_noise"]))
+        assert np.array_equal(img.numpy(), g[f"ps{t}_img"]), t
+        assert np.array_equal(x0.numpy(), g[f"ps{t}_x0"]), t
+    img, _ = OD.p_sample(sch, den, x, 500, pc, None, T(g["ps500_nocond_noise"]))
+    assert np.array_equal(img.numpy(), g["ps500_nocond_img"])
+
+
+def test_G10_short_chains(golden):
+    g = golden("G9_G10_sampler")
+    den = _denoiser(16, 9)
+    pc, cond = T(g["pc"]), T(g["cond"])
+    out = OD.p_sample_loop(OD.schedule(8), den, pc, cond, (2, 1, 32, 32), OD.stored_noise(T(g["chain8_noise"])))
+    assert np.array_equal(out.numpy(), g["chain8_out"])
+    sch = OD.schedule(1000)
+    out = OD.sample(sch, den, pc, cond, 32, OD.stored_noise(T(g["ddim5_noise"])), sampling_steps=5)
+    assert np.array_equal(out.numpy(), g["ddim5_out"])
+    out = OD.sample(sch, den, pc, None, 32, OD.stored_noise(T(g["ddim5_nocond_noise"])), sampling_steps=5)
+    assert np.array_equal(out.numpy(), g["ddim5_nocond_out"])
+    # the reference's own draw order reproduced from a seeded torch generator
+    gen = torch.Generator().manual_seed(4321)
+    torch.manual_seed(4321)
+    out = OD.sample(sch, den, pc, cond, 32, lambda k: torch.randn((2, 1, 32, 32)), sampling_steps=5)
+    assert np.array_equal(out.numpy(), g["ddim5_out"])
+
+
+def test_G11_maskunet(golden):
+    g = golden("G11_maskunet")
+    x = T(g["depth"])
+    assert np.array_equal(OU.depth_augment(x).numpy(), g["augment"])
+    for dim in (8, 16):
+        p = W.synth_state_dict(W.maskunet_config(dim), 11, final_bias=4.0)
+        assert np.array_equal(OU.maskunet_forward(p, x).numpy(), g[f"d{dim}_prob"])
+    old = OD.MASK_THRESHOLD
+    try:
+        OD.MASK_THRESHOLD = float(g["thr"])
+        cond, d, m = OD.correct_and_condition(T(g["d16_prob"]), x, T(g["hit"]))
+    finally:
+        OD.MASK_THRESHOLD = old
+    assert np.array_equal(cond.numpy(), g["img_cond"]) and np.array_equal(d.numpy(), g["corrected"])
+    assert np.array_equal(m.numpy(), g["mask_out"])
+
+
+def test_G12_end_to_end_pair(golden):
+    """Config 1 of BASELINE.json: 64x64, 50-step DDIM, dim-64 networks (CPU plumbing case)."""
+    g = golden("G12_end_to_end_64")
+    unet_p = W.synth_state_dict(W.unet_config(64), 12)
+    mask_p = W.synth_state_dict(W.maskunet_config(64), 13, final_bias=6.0)
+    d_rpj, hit = OG.reproject_tensor(T(g["depth"]) * 10, T(g["K"]), T(g["pose"]), (0, 10))
+    assert np.array_equal((d_rpj * 0.1).numpy(), g["rpj_depth"]) and np.array_equal(hit.numpy(), g["rpj_mask"])
+    prob1 = OU.maskunet_forward(mask_p, d_rpj * 0.1)
+    assert np.array_equal(prob1.numpy(), g["prob1"])
+    old = OD.MASK_THRESHOLD
+    try:
+        OD.MASK_THRESHOLD = float(g["thr1"])
+        cond, _, _ = OD.correct_and_condition(prob1, d_rpj * 0.1, hit)
+    finally:
+        OD.MASK_THRESHOLD = old
+    assert np.array_equal(cond.numpy(), g["img_cond"])
+    den = lambda x, t, c: OU.unet_forward(unet_p, x, t, c)
+    img = OD.sample(OD.schedule(1000), den, OG.param_vector(T(g["K"])), cond, 64, OD.stored_noise(T(g["noise"])),
+                    sampling_steps=50)
+    assert np.array_equal(img.numpy(), g["sampled"])
+    prob2 = OU.maskunet_forward(mask_p, img)
+    assert np.array_equal(prob2.numpy(), g["prob2"])
+    out = torch.where(prob2 > float(g["thr2"]), img, torch.zeros_like(img))
+    cloud = OG.inverse_pose_apply(OG.point_cloud(out[0, 0].numpy() * 10, g["K"][0], (0.5, 10)), g["pose"][0])
+    assert np.array_equal(cloud, g["cloud"])

@@ -1,0 +1,326 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference, read-only) in this container.
+
+Run:  python tools/make_goldens.py            (needs /root/reference; takes ~1-2 minutes on 8 cores)
+
+Every fixture stores the inputs and the reference's outputs.  Network weights are NOT stored: they come from
+the build's deterministic initialiser (pointreggpt_amd.weights.synth_state_dict(cfg, seed)), loaded into the
+reference modules with load_state_dict, and are regenerated bit-identically by the tests.
+Fixture ids follow SURVEY.md §8c (G1..G12).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from _refimport import import_reference  # noqa: E402
+from pointreggpt_amd import synthetic, weights  # noqa: E402
+
+sd, dc = import_reference()
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_grad_enabled(False)
+
+
+def save(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  [{', '.join(conv)}]")
+
+
+def ref_unet(dim, seed):
+    m = sd.Unet(dim=dim, param_cond_dim=4, dim_mults=(1, 2, 4, 8), channels=1)
+    m.load_state_dict(weights.synth_state_dict(weights.unet_config(dim), seed))
+    return m.eval()
+
+
+def ref_maskunet(dim, seed, final_bias=None):
+    m = dc.MaskUnet(dim=dim, dim_mults=(1, 2, 4, 8))
+    m.load_state_dict(weights.synth_state_dict(weights.maskunet_config(dim), seed, final_bias=final_bias))
+    return m.eval()
+
+
+def ref_diffusion(model, S, T=1000, steps=None):
+    return sd.GaussianDiffusion(model, image_size=S, timesteps=T, sampling_timesteps=steps, loss_type="l1",
+                                objective="pred_x0", beta_schedule="sigmoid", ddim_sampling_eta=1.0,
+                                is_ddnm_sampling=True)
+
+
+def hook_taps(model, names):
+    """Forward hooks on reference sub-modules -> dict of outputs."""
+    taps = {}
+    for key, mod in names.items():
+        mod.register_forward_hook(lambda _m, _i, o, key=key: taps.__setitem__(key, o.detach().clone()))
+    return taps
+
+
+def recorded_noise(fn, seed):
+    """Run fn() under torch.manual_seed(seed) while recording every randn / randn_like draw, in order."""
+    draws = []
+    o_randn, o_like = torch.randn, torch.randn_like
+
+    def randn(*a, **k):
+        t = o_randn(*a, **k)
+        draws.append(t.clone())
+        return t
+
+    def randn_like(x, **k):
+        t = o_like(x, **k)
+        draws.append(t.clone())
+        return t
+
+    torch.manual_seed(seed)
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        out = fn()
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+    return out, (torch.stack(draws) if draws else torch.zeros(0))
+
+
+def mixed_cond(B, S, seed):
+    """A DDNM condition with a mixed known/unknown mask: (B,2,S,S) in [-1,1]."""
+    g = torch.Generator().manual_seed(seed)
+    depth = torch.rand((B, 1, S, S), generator=g) * 0.3 + 0.05
+    mask = (torch.rand((B, 1, S, S), generator=g) > 0.45).float()
+    depth = depth * mask
+    return torch.cat([depth, mask], 1) * 2 - 1
+
+
+# ------------------------------------------------------------------------------------------------
+def g1_schedule():
+    m = ref_unet(8, 7)
+    d = ref_diffusion(m, 32)
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2", "loss_weight"]
+    out = {n: getattr(d, n) for n in names}
+    for steps in (5, 50, 250):
+        t = torch.linspace(-1, 999, steps=steps + 1)
+        out[f"ddim_times_{steps}"] = np.array(list(reversed(t.int().tolist())), dtype=np.int64)
+    d8 = ref_diffusion(m, 32, T=8)
+    for n in names:
+        out["T8_" + n] = getattr(d8, n)
+    save("G1_schedule", **out)
+
+
+def g2_intrinsics():
+    K = np.array([[[f, 0.0, 320.0], [0.0, f, 240.0], [0.0, 0.0, 1.0]] for f in
+                  (585.0, 572.0, 583.0, 540.021232, 570.342205, 533.069214)], dtype=np.float32)
+    out = {"K": K}
+    for S in (32, 64, 128, 256):
+        out[f"S{S}"] = np.stack([sd.intrinsic_transform(k, resize=S, centercrop=S) for k in K])
+        out[f"S{S}_batched"] = sd.intrinsic_transform(K, resize=S, centercrop=S)
+    out["none"] = sd.intrinsic_transform(K[4])
+    save("G2_intrinsic_transform", **out)
+
+
+def g3_pose():
+    out = {}
+    for s in (0, 1, 12345):
+        np.random.seed(s)
+        out[f"pose_seed{s}"] = sd.random_sample_pose(4)
+        out[f"after_seed{s}"] = np.random.rand(2)       # pins how much of the stream was consumed
+        np.random.seed(s)
+        out[f"intr_seed{s}"] = sd.random_sample_intrinsic(16)
+    save("G3_random_sample_pose", **out)
+
+
+def g4_pc2depth():
+    rng = np.random.default_rng(4)
+    B, N, S = 2, 20000, 64
+    K = np.stack([sd.intrinsic_transform(np.array([[570.342205, 0, 320], [0, 570.342205, 240], [0, 0, 1]],
+                                                  dtype=np.float32), resize=S, centercrop=S)] * B).astype(np.float32)
+    K[1, 0, 0] *= 1.03
+    pc = np.empty((B, N, 3), dtype=np.float32)
+    pc[..., 2] = rng.uniform(0.5, 4.0, (B, N))
+    pc[..., 0] = rng.uniform(-1.6, 1.6, (B, N)) * pc[..., 2]      # spills outside the frame on both sides
+    pc[..., 1] = rng.uniform(-1.6, 1.6, (B, N)) * pc[..., 2]
+    # exact half-pixel ties: x*fx/z + cx == k + 0.5  (fx=cx-free construction: choose z=fx, x = k+0.5-cx)
+    for b in range(B):
+        fx, fy, cx, cy = K[b, 0, 0], K[b, 1, 1], K[b, 0, 2], K[b, 1, 2]
+        for i, k in enumerate(range(0, 40)):
+            pc[b, i] = [np.float32(k + 0.5) - cx, np.float32(k % 7 + 0.5) - cy, 1.0]
+            pc[b, i, 0] /= fx
+            pc[b, i, 1] /= fy
+    pc[:, 100:160, 2] *= -1                                        # behind the camera
+    pc[:, 160:170, 2] = 0.0                                        # z == 0
+    pc[:, 170:180, 0] = np.nan                                     # NaN coordinates
+    pc[:, 200:1200] = pc[:, 1200:2200]                             # exact duplicates -> collisions
+    pc[:, 200:1200, 2] *= np.float32(1.25)
+    pc[:, 200:1200, :2] *= np.float32(1.25)                        # same pixel, farther: must lose
+    valid = rng.random((B, N)) > 0.1
+    d, m = sd.pc2depth_tensor(torch.tensor(pc), torch.tensor(valid), torch.tensor(K), image_size=[S, S])
+    # non-square + empty cloud
+    d2, m2 = sd.pc2depth_tensor(torch.tensor(pc[:, :5000]), torch.tensor(valid[:, :5000]), torch.tensor(K),
+                                image_size=[48, 80])
+    save("G4_pc2depth", pc=pc, valid=valid, K=K, depth=d, mask=m, depth_48x80=d2, mask_48x80=m2)
+
+
+def g5_g6_reproject():
+    S, B = 64, 3
+    depth, K, pose = synthetic.synth_batch(5, range(B), S)
+    pose[2] = np.eye(4, dtype=np.float32)                          # identity: bit-exact round trip
+    dm = torch.tensor(depth) * 10
+    d, m = sd.reproject_tensor(dm, torch.tensor(K), torch.tensor(pose), clip=[0, 10])
+    d05, m05 = sd.reproject_tensor(dm, torch.tensor(K), torch.tensor(pose), clip=[0.5, 10])
+    pc, valid = sd.depth2pc_tensor(dm, torch.tensor(K), clip=[0.5, 10])
+    pc0, valid0 = sd.depth2pc_tensor(dm, torch.tensor(K), clip=[0, 10], invalid_num=0.0)
+    clouds = {}
+    for b in range(B):
+        p = sd.point_cloud(depth[b, 0] * 10, K[b], clip=[0.5, 10])
+        clouds[f"cloud{b}"] = p
+        clouds[f"cloud{b}_common"] = (p - pose[b, :3, 3]) @ pose[b, :3, :3]
+    # the generator's per-scene form: float32 numpy cloud, numpy rigid move, batch-of-one z-buffer (sd:2531-2547)
+    gen = {}
+    for b in range(B):
+        cloud = clouds[f"cloud{b}"].astype(np.float32)
+        moved = cloud @ pose[b, :3, :3].T + pose[b, :3, 3]
+        dd, mm = sd.pc2depth_tensor(torch.tensor(moved[None]), torch.ones((1, len(moved)), dtype=torch.bool),
+                                    torch.tensor(K[b][None]), image_size=[S, S])
+        gen[f"gen_depth{b}"], gen[f"gen_mask{b}"] = dd[0], mm[0]
+    save("G5_G6_reproject_unproject", depth=depth, K=K, pose=pose, rpj_depth=d, rpj_mask=m, rpj05_depth=d05,
+         rpj05_mask=m05, pc=pc, pc_valid=valid, pc0=pc0, pc0_valid=valid0, **clouds, **gen)
+
+
+def g7_unet_taps():
+    out = {}
+    for dim, S in ((8, 32), (16, 32)):
+        m = ref_unet(dim, 7)
+        taps = hook_taps(m, {"init_conv": m.init_conv, "down0_block0": m.downs[0][0], "down0_attn": m.downs[0][2],
+                             "down0_out": m.downs[0][3], "mid_attn": m.mid_attn, "up0_out": m.ups[0][3],
+                             "final_res": m.final_res_block})
+        g = torch.Generator().manual_seed(70 + dim)
+        x = torch.randn((2, 1, S, S), generator=g)
+        t = torch.tensor([3, 871])
+        pc = torch.tensor([[75.7486, 76.0456, 32.5, 32.0], [80.0, 79.5, 31.5, 32.5]]) * (S / 64)
+        y = m(x, t, pc)
+        out.update({f"d{dim}_x": x, f"d{dim}_t": t, f"d{dim}_pc": pc, f"d{dim}_y": y})
+        out.update({f"d{dim}_tap_{k}": v for k, v in taps.items()})
+    save("G7_unet_small_taps", **out)
+
+
+def g8_unet_full():
+    m = ref_unet(64, 8)
+    g = torch.Generator().manual_seed(8)
+    S = 64
+    x = torch.randn((2, 1, S, S), generator=g)
+    t = torch.tensor([0, 999])
+    pc = torch.tensor([[75.7486, 76.0456, 32.5, 32.0], [73.1, 73.4, 32.5, 32.0]])
+    save("G8_unet_dim64", x=x, t=t, pc=pc, y=m(x, t, pc))
+
+
+def g9_g10_sampler():
+    S, B, dim = 32, 2, 16
+    m = ref_unet(dim, 9)
+    pc = torch.tensor([[37.87, 38.02, 16.25, 16.0], [36.5, 36.7, 16.25, 16.0]])
+    cond = mixed_cond(B, S, 9)
+    out = {"pc": pc, "cond": cond}
+    d = ref_diffusion(m, S)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn((B, 1, S, S), generator=g)
+    out["x"] = x
+    # G9a: single ancestral steps
+    for t in (999, 500, 1, 0):
+        (img, x0), nz = recorded_noise(lambda t=t: d.p_sample(x, t, pc, cond), 100 + t)
+        out[f"ps{t}_img"], out[f"ps{t}_x0"] = img, x0
+        out[f"ps{t}_noise"] = nz[0] if len(nz) else torch.zeros_like(x)
+    # G9b: unconditional (img_cond=None) single step
+    (img, x0), nz = recorded_noise(lambda: d.p_sample(x, 500, pc, None), 77)
+    out["ps500_nocond_img"], out["ps500_nocond_noise"] = img, nz[0]
+    # G10a: full short ancestral chain T=8
+    d8 = ref_diffusion(m, S, T=8)
+    img, nz = recorded_noise(lambda: d8.sample(param_cond=pc, img_cond=cond, disable_tqdm=True), 1234)
+    out["chain8_out"], out["chain8_noise"] = img, nz
+    # G10b: 1000 -> 5 DDIM
+    d5 = ref_diffusion(m, S, T=1000, steps=5)
+    img, nz = recorded_noise(lambda: d5.sample(param_cond=pc, img_cond=cond, disable_tqdm=True), 4321)
+    out["ddim5_out"], out["ddim5_noise"] = img, nz
+    # G10c: DDIM without a condition
+    img, nz = recorded_noise(lambda: d5.sample(param_cond=pc, img_cond=None, disable_tqdm=True), 555)
+    out["ddim5_nocond_out"], out["ddim5_nocond_noise"] = img, nz
+    save("G9_G10_sampler", **out)
+
+
+def g11_maskunet():
+    S, B = 32, 2
+    depth, _, _ = synthetic.synth_batch(11, range(B), S)
+    depth[1, 0, :6, :6] = 0.0                                      # an all-zero 3x3 window
+    x = torch.tensor(depth)
+    aug = dc.DepthAugment()(x)
+    out = {"depth": x, "augment": aug}
+    for dim in (8, 16):
+        m = ref_maskunet(dim, 11, final_bias=4.0)                 # logit shift: probabilities straddle 0.99
+        prob = m(x)
+        out[f"d{dim}_prob"] = prob
+    # threshold + condition assembly exactly as Generator.generate does (sd:2564-2570)
+    prob = out["d16_prob"]
+    g = torch.Generator().manual_seed(11)
+    hit = torch.rand((B, 1, S, S), generator=g) > 0.3
+    thr = float(np.quantile(prob.numpy(), 0.4))                    # mixed mask whatever the weights give
+    images = x.clone()
+    mask_crt = prob > thr
+    images[~mask_crt] = 0
+    mask_rpj = hit & mask_crt
+    cond = sd.normalize_to_neg_one_to_one(torch.cat([images, mask_rpj], dim=1))
+    out.update(hit=hit, thr=np.float32(thr), corrected=images, mask_out=mask_rpj, img_cond=cond)
+    save("G11_maskunet", **out)
+
+
+def g12_end_to_end():
+    """Config 1: one synthetic pair at 64x64, 50-step DDIM, dim=64 networks, depth-map form of the pipeline."""
+    S, B = 64, 1
+    depth, K, pose = synthetic.synth_batch(12, range(B), S)
+    unet, mask = ref_unet(64, 12), ref_maskunet(64, 13, final_bias=6.0)
+    d = ref_diffusion(unet, S, T=1000, steps=50)
+    Kt, Pt = torch.tensor(K), torch.tensor(pose)
+    d_rpj, hit = sd.reproject_tensor(torch.tensor(depth) * 10, Kt, Pt, clip=[0, 10])
+    images_rpj = d_rpj * 0.1
+    prob1 = mask(images_rpj)
+    thr1 = float(np.quantile(prob1.numpy(), 0.25))
+    mask_crt = prob1 > thr1
+    images_rpj[~mask_crt] = 0
+    mask_rpj = hit & mask_crt
+    img_cond = sd.normalize_to_neg_one_to_one(torch.cat([images_rpj, mask_rpj], dim=1))
+    pc = sd.param_vector(Kt)
+    images, nz = recorded_noise(lambda: d.sample(param_cond=pc, img_cond=img_cond, disable_tqdm=True), 2024)
+    prob2 = mask(images)
+    thr2 = float(np.quantile(prob2.numpy(), 0.25))
+    out_img = images.clone()
+    out_img[~(prob2 > thr2)] = 0
+    cloud = sd.point_cloud(out_img[0, 0].numpy() * 10, K[0], clip=[0.5, 10])
+    cloud = (cloud - pose[0, :3, 3]) @ pose[0, :3, :3]
+    save("G12_end_to_end_64", depth=depth, K=K, pose=pose, rpj_depth=d_rpj * 0.1, rpj_mask=hit, prob1=prob1,
+         thr1=np.float32(thr1), img_cond=img_cond, noise=nz, sampled=images, prob2=prob2, thr2=np.float32(thr2),
+         depth_out=out_img, cloud=cloud)
+
+
+def spec_fixture():
+    import json
+    spec = {"unet64": [[k, list(v.shape)] for k, v in sd.Unet(dim=64, param_cond_dim=4).state_dict().items()],
+            "mask64": [[k, list(v.shape)] for k, v in dc.MaskUnet(dim=64).state_dict().items()],
+            "unet8": [[k, list(v.shape)] for k, v in sd.Unet(dim=8, param_cond_dim=4).state_dict().items()]}
+    with open(os.path.join(OUT, "state_dict_spec.json"), "w") as f:
+        json.dump(spec, f)
+    print("state_dict_spec.json written")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    only = set(sys.argv[1:])
+    jobs = [("g1", g1_schedule), ("g2", g2_intrinsics), ("g3", g3_pose), ("g4", g4_pc2depth), ("g5", g5_g6_reproject),
+            ("g7", g7_unet_taps), ("g8", g8_unet_full), ("g9", g9_g10_sampler), ("g11", g11_maskunet),
+            ("g12", g12_end_to_end), ("spec", spec_fixture)]
+    for name, fn in jobs:
+        if not only or name in only:
+            fn()
