@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Benchmark of the generative data path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+One *step* = one batch of B synthetic scene pairs through the hot path (BASELINE.json configs[1]/[2]):
+z-buffer SE(3) reprojection -> MaskUnet -> DDNM condition -> T-step sampler over the conditional U-Net ->
+MaskUnet -> float64 unprojection, everything resident in HBM when the clock starts.  Scene pairs are
+independent, so ranks take disjoint scene indices and never communicate on the data path (weak scaling);
+`value` = pairs produced by all ranks / max-over-ranks wall time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+UNET_GFLOP = {64: 14.744, 128: 58.976, 256: 236.282}      # per image, SURVEY.md §8d / BASELINE.md §2
+MASK_GFLOP = {64: 14.787, 128: 59.173, 256: 237.096}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}        # dense, MI355X_MICROARCH.md chip table
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=1, help="timed batches per rank")
+    p.add_argument("--warmup", type=int, default=1, help="untimed batches per rank")
+    p.add_argument("--batch", type=int, default=64)
+    p.add_argument("--size", type=int, default=128)
+    p.add_argument("--timesteps", type=int, default=1000)
+    p.add_argument("--sampling-steps", type=int, default=None, help="< timesteps selects DDIM (default: ancestral DDNM)")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--dim", type=int, default=64)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--sampler-only", action="store_true", help="configs[1]: p_sample_loop only (no geometry / MaskUnet)")
+    p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--profile-transitions", type=int, default=40)
+    return p.parse_args()
+
+
+def cpu_baseline(size, dim):
+    """The reference's arithmetic on the host cores: the oracle's p_sample (torch-CPU / oneDNN, fp32) on a bounded
+    sample — 1 warm-up + 3 timed transitions at batch 4 — extrapolated to pairs/s for the full chain."""
+    from oracle import diffusion as OD
+    from oracle import unet as OU
+    from pointreggpt_amd import weights as W
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, T = 4, 1000
+    p = W.synth_state_dict(W.unet_config(dim), 0)
+    sch = OD.schedule(T)
+    den = lambda x, t, c: OU.unet_forward(p, x, t, c)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((B, 1, size, size), generator=g)
+    pc = torch.tensor([[151.5, 152.1, size / 2 + 0.5, size / 2]] * B)
+    cond = torch.cat([torch.rand((B, 1, size, size), generator=g) * 2 - 1,
+                      (torch.rand((B, 1, size, size), generator=g) > 0.5).float() * 2 - 1], 1)
+    nz = torch.randn((B, 1, size, size), generator=g)
+    OD.p_sample(sch, den, x, 999, pc, cond, nz)
+    t0 = time.perf_counter()
+    n = 3
+    for i in range(n):
+        x, _ = OD.p_sample(sch, den, x, 998 - i, pc, cond, nz)
+    dt = (time.perf_counter() - t0) / n
+    pairs_per_s = B / (dt * T)
+    return {"value": pairs_per_s, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle p_sample (torch-CPU fp32), batch {B}, {size}x{size}, 1 warm-up + {n} timed transitions "
+                      f"= {dt:.3f} s/transition, extrapolated x{T} transitions; MaskUnet/geometry (0.2% of the work) omitted"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a HIP device (the product has no CPU path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from pointreggpt_amd import geometry as G
+    from pointreggpt_amd import synthetic
+    from pointreggpt_amd.diffusion import GaussianDiffusion
+    from pointreggpt_amd.unet import MaskUnet, Unet
+
+    B, S = a.batch, a.size
+    dev = torch.device("cuda", local)
+    unet = Unet(a.dim, dtype=a.dtype).init_synthetic(seed=1)
+    mask = None if a.sampler_only else MaskUnet(a.dim, dtype=a.dtype).init_synthetic(seed=2, final_bias=6.0)
+    diff = GaussianDiffusion(unet, image_size=S, timesteps=a.timesteps, sampling_timesteps=a.sampling_steps)
+    n_trans = len(diff.step_table())
+
+    total_batches = a.warmup + a.steps
+    # rank r owns scene indices r*total*B ... ; inputs are synthesised and uploaded BEFORE the clock starts
+    batches = []
+    for i in range(total_batches):
+        first = (rank * total_batches + i) * B
+        idx = list(range(first, first + B))
+        depth, K, pose = synthetic.synth_batch(a.seed, idx, S)
+        batches.append(dict(idx=idx, depth=torch.from_numpy(depth).to(dev), K=torch.from_numpy(K).to(dev),
+                            pose=torch.from_numpy(pose).to(dev),
+                            seeds=[synthetic.noise_seed(a.seed, j) for j in idx]))
+
+    def one_batch(bt):
+        pc = G.param_vector(bt["K"])
+        if a.sampler_only:
+            rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+            _, _, cond = G.apply_mask(torch.ones_like(rpj), rpj, hit, 0.5)
+            return diff.sample(param_cond=pc, img_cond=cond, seeds=bt["seeds"])
+        rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+        _, _, cond = G.apply_mask(mask(rpj), rpj, hit, 0.99)
+        img = diff.sample(param_cond=pc, img_cond=cond, seeds=bt["seeds"])
+        out, _, _ = G.apply_mask(mask(img), img, None, 0.99, want_cond=False)
+        xyz, valid = G.unproject_f64(out, bt["K"], bt["pose"])
+        return xyz
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_batch(batches[i])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total_batches):
+        one_batch(batches[i])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    pairs = world * a.steps * B
+    value = pairs / dt
+    tflop_pair = (n_trans * UNET_GFLOP.get(S, 58.976 * (S / 128) ** 2) +
+                  (0 if a.sampler_only else 2 * MASK_GFLOP.get(S, 59.173 * (S / 128) ** 2))) / 1e3
+
+    res = {
+        "metric": "generated point-cloud pairs/sec (node), 128x128 depth, 1000-step DDNM",
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": ("configs[1]: DDNM p_sample_loop only" if a.sampler_only else
+                                "configs[2]: full pipeline (SE(3) z-buffer reproject + MaskUnet + DDNM sampler + MaskUnet + f64 unproject)"),
+                   "batch_per_gpu": B, "image_size": S, "transitions": n_trans,
+                   "sampler": "ddim" if diff.is_ddim_sampling else "ancestral-ddnm", "unet_dim": a.dim,
+                   "noise": "on-device Philox4x32-10 keyed per scene", "weights": "synthetic (deterministic initialiser)",
+                   "parallelism": f"scene-sharded x{world}, no collectives", "hipgraph": True,
+                   "tflop_per_pair": tflop_pair},
+        "end_to_end_mfma_frac": value / world * tflop_pair / MFMA_PEAK_TFLOPS[a.dtype],
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # dominant kernel = conv_igemm_kernel (implicit-GEMM convolution).  Its launches are timed live with HIP events
+        # on the sampler's own stream over `profile_transitions` transitions of the same workload (eager launches).
+        nprof = min(a.profile_transitions, n_trans)
+        pdiff = GaussianDiffusion(unet, image_size=S, timesteps=a.timesteps, sampling_timesteps=a.sampling_steps)
+        rows = pdiff.step_table()[:nprof]
+        pdiff.step_table = lambda: rows
+        bt = batches[-1]
+        pc = G.param_vector(bt["K"])
+        rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+        _, _, cond = G.apply_mask(torch.ones_like(rpj), rpj, hit, 0.5)
+        pdiff.sample(param_cond=pc, img_cond=cond, seeds=bt["seeds"], profile=True)
+        torch.cuda.synchronize()
+        pr = pdiff.last_profile(B)
+        ach = pr["conv_flops"] / (pr["conv_ms"] * 1e-3) / 1e12
+        res["roofline"] = {
+            "kernel": "conv_igemm_kernel (implicit-GEMM conv, MFMA)", "bound": "mfma", "achieved": ach,
+            "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype],
+            "traffic": None,
+            "launches": pr["conv_launches"], "avg_launch_us": pr["conv_ms"] * 1e3 / max(1, pr["conv_launches"]),
+            "flop_per_launch": pr["conv_flops"] / max(1, pr["conv_launches"]),
+            "share_of_step_time": pr["conv_ms"] / pr["total_ms"],
+            "measured": f"HIP events around every conv launch, {nprof} transitions, batch {B}",
+        }
+        pdiff.close()
+    if rank == 0 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(S, a.dim)
+
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

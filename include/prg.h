@@ -163,11 +163,13 @@ int prg_sampler_set_graph(prg_sampler* h, int enable);
 
 /* param_cond (B,4); img_cond (B,2,S,S) in [-1,1] or NULL (unconditional: no DDNM replacement);
  * noise: NULL -> on-device Philox4x32-10 keyed per scene by seeds[b] (HOST array of B uint64; results do
- * not depend on batch composition or rank) ; else DEVICE float32 (n_steps+1, B, S, S): slab 0 is the start
- * image, slab k feeds transition k-1 (unused where sigma == 0) — the reference's draw order (sd:1293,1279).
+ * not depend on batch composition or rank) ; else DEVICE float32 (noise_slabs, B, S, S) in the reference's
+ * draw order (sd:1293,1279 / sd:1339,1369): slab 0 is the start image, slab k+1 feeds transition k and is
+ * read only where sigma != 0 — both samplers draw nothing on their last transition, so noise_slabs = n_steps
+ * suffices; the call fails with PRG_E_INVALID if a transition with sigma != 0 would read past noise_slabs.
  * out (B,1,S,S) = (x_final + 1) * 0.5  (sd:1316).                                                          */
 int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_cond, const float* noise,
-                    const uint64_t* seeds, float* out, void* stream);
+                    int64_t noise_slabs, const uint64_t* seeds, float* out, void* stream);
 
 /* Wall-clock free timing hook for bench.py: average duration in milliseconds of the dominant kernel class
  * (implicit-GEMM convolution launches) measured with HIP events on the run's own stream during the last

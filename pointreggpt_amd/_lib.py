@@ -53,7 +53,7 @@ PROTOTYPES = {
     "prg_sampler_create": (C.c_int, [_P, C.POINTER(StepC), _I, _I, _I, C.POINTER(_P)]),
     "prg_sampler_destroy": (C.c_int, [_P]),
     "prg_sampler_set_graph": (C.c_int, [_P, _I]),
-    "prg_sampler_run": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "prg_sampler_run": (C.c_int, [_P, _P, _P, _P, _L, _P, _P, _P]),
     "prg_sampler_set_profile": (C.c_int, [_P, _I]),
     "prg_sampler_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]),

@@ -834,9 +834,15 @@ int prg_sampler_get_profile(prg_sampler* h, double* conv_ms, int64_t* conv_launc
 }
 
 int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_cond, const float* noise,
-                    const uint64_t* seeds, float* out, void* stream) {
+                    int64_t noise_slabs, const uint64_t* seeds, float* out, void* stream) {
   PRG_CHECK(h && param_cond && out, "prg_sampler_run: null pointer");
   PRG_CHECK(noise || seeds, "prg_sampler_run: need stored noise or per-scene seeds");
+  if (noise) {
+    int64_t need = 1;
+    for (int k = 0; k < h->n_steps; ++k)
+      if (h->steps[k].sigma != 0.0f) need = k + 2;
+    PRG_CHECK(noise_slabs >= need, "prg_sampler_run: stored noise has too few slabs for this transition table");
+  }
   prg_unet* u = h->unet;
   PRG_CHECK(u->resB >= h->B && u->resS >= h->S, "prg_sampler_run: U-Net workspace was shrunk");
   hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;

@@ -110,8 +110,10 @@ class GaussianDiffusion:
 
     @property
     def n_draws(self) -> int:
-        """Noise slabs a stored-noise run consumes: start image + one per transition."""
-        return len(self.step_table()) + 1
+        """Noise slabs a stored-noise run consumes: the start image + one per transition that adds noise
+        (every transition but the last, for both samplers) = the reference's number of randn draws."""
+        rows = self.step_table()
+        return 1 + max([k + 1 for k, r in enumerate(rows) if r["sigma"] != 0.0], default=0)
 
     def _sampler(self, batch: int):
         key = (batch, self.image_size)
@@ -161,11 +163,13 @@ class GaussianDiffusion:
         seed_arr = None
         if noise is not None:
             nz = noise.to(device="cuda", dtype=torch.float32).contiguous()
-            assert nz.numel() == self.n_draws * B * S * S, "stored noise has the wrong number of draws"
+            assert nz.numel() % (B * S * S) == 0 and nz.numel() // (B * S * S) >= self.n_draws, \
+                f"stored noise needs {self.n_draws} draws of shape ({B},1,{S},{S})"
         else:
             seed_arr = (C.c_uint64 * B)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in (seeds if seeds is not None else range(B))])
         out = torch.empty((B, 1, S, S), dtype=torch.float32, device="cuda")
         _lib.check(lib.prg_sampler_run(h, _lib.ptr(pc), _lib.ptr(cond), _lib.ptr(nz),
+                                       0 if nz is None else nz.numel() // (B * S * S),
                                        C.cast(seed_arr, C.c_void_p) if seed_arr is not None else None,
                                        _lib.ptr(out), _lib.stream_ptr()), "prg_sampler_run")
         self._keepalive = (pc, cond, nz)   # the run is asynchronous: keep inputs alive until the next call

@@ -1,0 +1,177 @@
+"""CPU tests (-m "not gpu"): host-side logic of the product, the C-ABI library's exports, multi-rank sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from pointreggpt_amd import _lib, geometry as G, sharding, synthetic, weights as W
+from pointreggpt_amd.diffusion import GaussianDiffusion, ddim_times, make_schedule
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    """The built .so loads (no GPU needed) and exports exactly the entry points include/prg.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "prg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(prg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().prg_abi_version() == 1
+
+
+def test_param_count_matches_library():
+    lib = _lib.load()
+    from pointreggpt_amd.unet import _cfg_c
+    for cfg in (W.unet_config(64), W.maskunet_config(64), W.unet_config(8), W.maskunet_config(16)):
+        assert lib.prg_unet_param_count(ctypes.byref(_cfg_c(cfg))) == W.num_params(cfg)
+    bad = _cfg_c(W.unet_config(64))
+    bad.dim = 7
+    assert lib.prg_unet_param_count(ctypes.byref(bad)) < 0
+    assert b"dim" in lib.prg_last_error()
+
+
+def test_product_has_no_cpu_path():
+    from pointreggpt_amd.unet import Unet
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.PrgError):
+        Unet(16).init_synthetic(0)
+    with pytest.raises(_lib.PrgError):
+        G.pc2depth_tensor(torch.zeros((1, 4, 3)), None, torch.eye(3)[None], image_size=(8, 8))
+    # and nothing under the package imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "pointreggpt_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_host_geometry_against_reference_goldens(golden):
+    g = golden("G2_intrinsic_transform")
+    for S in (32, 64, 128, 256):
+        assert np.array_equal(G.intrinsic_transform(g["K"], S, S), g[f"S{S}_batched"])
+        assert np.array_equal(G.intrinsic_transform(g["K"][0], S, S), g[f"S{S}"][0])
+    assert np.array_equal(G.intrinsic_transform(g["K"][4]), g["none"])
+    assert np.array_equal(G.candidate_intrinsics(), g["K"])
+    g = golden("G3_random_sample_pose")
+    for s in (0, 1, 12345):
+        np.random.seed(s)
+        assert np.array_equal(G.random_sample_pose(4), g[f"pose_seed{s}"])
+        assert np.array_equal(np.random.rand(2), g[f"after_seed{s}"])
+        np.random.seed(s)
+        assert np.array_equal(G.random_sample_intrinsic(16), g[f"intr_seed{s}"])
+    K = torch.tensor(g["pose_seed0"][:, :3, :3])
+    assert torch.equal(G.param_vector(K), torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1))
+
+
+class _FakeNet:
+    channels = out_dim = 1
+    random_or_learned_sinusoidal_cond = False
+
+
+def test_schedule_and_step_table_against_reference_goldens(golden):
+    g = golden("G1_schedule")
+    for T, pre in ((1000, ""), (8, "T8_")):
+        for k, v in make_schedule(T).items():
+            assert np.array_equal(v.numpy(), g[pre + k]), k
+    for n in (5, 50, 250):
+        assert ddim_times(1000, n) == g[f"ddim_times_{n}"].tolist()
+    d = GaussianDiffusion(_FakeNet(), image_size=32, timesteps=1000)
+    rows = d.step_table()
+    assert len(rows) == 1000 and [r["t"] for r in rows] == list(range(999, -1, -1)) and d.n_draws == 1000
+    assert rows[-1]["sigma"] == 0.0 and rows[-1]["c_x0"] == 1.0 and rows[-1]["c_x"] == 0.0     # t = 0
+    assert rows[0]["c_x0"] == float(g["posterior_mean_coef1"][999]) and rows[0]["c_eps"] == 0.0
+    assert rows[3]["sigma"] == float(np.exp(np.float32(0.5) * g["posterior_log_variance_clipped"][996]))
+    d = GaussianDiffusion(_FakeNet(), image_size=32, timesteps=1000, sampling_timesteps=250)
+    rows = d.step_table()
+    assert len(rows) == 250 and rows[0]["t"] == 999 and rows[1]["t"] == 995 and d.n_draws == 250
+    assert rows[-1] == dict(rows[-1], c_x0=1.0, c_x=0.0, c_eps=0.0, sigma=0.0) and all(r["clip_pred"] == 1 for r in rows)
+    a, an = g["alphas_cumprod"][999], g["alphas_cumprod"][995]
+    sigma = np.sqrt((1 - a / an) * (1 - an) / (1 - a), dtype=np.float32)
+    assert abs(rows[0]["sigma"] - float(sigma)) <= 1e-7 and abs(rows[0]["c_x0"] - float(np.sqrt(an))) <= 1e-7
+    with pytest.raises(ValueError):
+        GaussianDiffusion(_FakeNet(), image_size=32, objective="pred_noise")
+
+
+def test_synthetic_scenes_are_index_keyed():
+    d1, K1, P1 = synthetic.synth_batch(0, [5, 9], 64)
+    d2, K2, P2 = synthetic.synth_batch(0, [9, 5, 7], 64)
+    assert np.array_equal(d1[0], d2[1]) and np.array_equal(K1[1], K2[0]) and np.array_equal(P1[0], P2[1])
+    assert d1.dtype == np.float32 and d1.shape == (2, 1, 64, 64) and 0.0 <= d1.min() and d1.max() <= 0.35
+    assert 0.02 < (d1 == 0).mean() < 0.1
+    assert synthetic.noise_seed(0, 5) != synthetic.noise_seed(0, 6) and synthetic.noise_seed(0, 5) == synthetic.noise_seed(0, 5)
+
+
+def test_flatten_state_dict_and_checkpoint_layouts():
+    from pointreggpt_amd.unet import flatten_state_dict
+    cfg = W.unet_config(8)
+    sd = W.synth_state_dict(cfg, 3)
+    flat = flatten_state_dict(cfg, sd)
+    assert flat.dtype == np.float32 and flat.size == W.num_params(cfg)
+    assert np.array_equal(flat[:8 * 49], sd["init_conv.weight"].reshape(-1).numpy())
+    # EMA-style checkpoint (ema_model. + model. prefixes) and plain 'model' fallback both resolve
+    ema = {"initted": torch.tensor(True), **{"ema_model.model." + k: v for k, v in sd.items()}}
+    got = W.unet_state_from_checkpoint({"ema": ema, "model": {}}, cfg)
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    got = W.unet_state_from_checkpoint({"model": {"model." + k: v for k, v in sd.items()}}, cfg)
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    with pytest.raises(KeyError):
+        W.unet_state_from_checkpoint({"model": {}}, cfg)
+    bad = dict(sd)
+    bad["init_conv.bias"] = torch.zeros(3)
+    with pytest.raises(ValueError):
+        flatten_state_dict(cfg, bad)
+
+
+def test_shard_range_partitions_exactly():
+    for start, stop, batch in ((0, 10000, 64), (7, 8, 4), (0, 0, 4), (3, 1003, 1), (0, 130, 64)):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                a, b = sharding.shard_range(start, stop, r, world, batch)
+                assert start <= a <= b <= stop and ((a - start) % batch == 0 or a == stop)
+                got += list(range(a, b))
+            assert got == list(range(start, stop))
+    assert sharding.num_to_groups(10, 4) == [4, 4, 2] and sharding.num_to_groups(8, 4) == [4, 4]
+
+
+_WORKER = r"""
+import os, sys, json
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pointreggpt_amd import sharding, synthetic
+rank, world, _ = sharding.rank_world()
+dist.init_process_group("gloo", rank=rank, world_size=world)
+a, b = sharding.shard_range(0, 37, rank, world, batch=4)
+mine = torch.zeros(37, dtype=torch.int64); mine[a:b] = 1
+# per-scene noise keys and inputs must not depend on the rank that owns the scene
+keys = torch.tensor([synthetic.noise_seed(0, i) % (2**62) for i in range(a, b)] + [0] * (37 - (b - a)), dtype=torch.int64)
+dist.all_reduce(mine)
+t = torch.tensor([float(b - a)], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0:
+    print(json.dumps({"cover": mine.tolist(), "max_load": t.item()}))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharding_over_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): the ranks' scene ranges tile the request exactly, MAX-reduction works."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29731", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["cover"] == [1] * 37 and res["max_load"] == 20.0
