@@ -54,7 +54,6 @@ def cpu_baseline(size, dim):
     from oracle import unet as OU
     from pointreggpt_amd import weights as W
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     B, T = 4, 1000
     p = W.synth_state_dict(W.unet_config(dim), 0)
     sch = OD.schedule(T)
@@ -65,16 +64,31 @@ def cpu_baseline(size, dim):
     cond = torch.cat([torch.rand((B, 1, size, size), generator=g) * 2 - 1,
                       (torch.rand((B, 1, size, size), generator=g) > 0.5).float() * 2 - 1], 1)
     nz = torch.randn((B, 1, size, size), generator=g)
-    OD.p_sample(sch, den, x, 999, pc, cond, nz)
-    t0 = time.perf_counter()
+
+    def transition(i):
+        t0 = time.perf_counter()
+        OD.p_sample(sch, den, x, 999 - i, pc, cond, nz)
+        return time.perf_counter() - t0
+
+    # oneDNN does not scale to every core of a big host at this batch: pick the fastest thread count first
+    best, used = None, 1
+    for th in [c for c in (8, 16, 32, 64, 128) if c <= cores] or [cores]:
+        torch.set_num_threads(th)
+        transition(0)
+        d = transition(1)
+        if best is None or d < best:
+            best, used = d, th
+        if d > 2.5 * best:
+            break
+    torch.set_num_threads(used)
     n = 3
-    for i in range(n):
-        x, _ = OD.p_sample(sch, den, x, 998 - i, pc, cond, nz)
-    dt = (time.perf_counter() - t0) / n
+    dt = sum(transition(2 + i) for i in range(n)) / n
+    cores = used
     pairs_per_s = B / (dt * T)
     return {"value": pairs_per_s, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle p_sample (torch-CPU fp32), batch {B}, {size}x{size}, 1 warm-up + {n} timed transitions "
-                      f"= {dt:.3f} s/transition, extrapolated x{T} transitions; MaskUnet/geometry (0.2% of the work) omitted"}
+            "sample": f"oracle p_sample (torch-CPU fp32, {used} threads = fastest of a sweep on a {os.cpu_count()}-core host), "
+                      f"batch {B}, {size}x{size}, {n} timed transitions = {dt:.3f} s/transition, extrapolated x{T} "
+                      f"transitions; MaskUnet/geometry (0.2% of the work) omitted"}
 
 
 def main():

@@ -237,7 +237,7 @@ int prg_depth2pc(const float* depth, const float* K, float* pc, uint8_t* valid, 
 
 int prg_pc2depth(const float* pc, const uint8_t* valid, const float* K, float* depth, uint8_t* mask, int B, int N,
                  int H, int W, void* stream) {
-  PRG_CHECK(pc && K && depth, "prg_pc2depth: null pointer");
+  PRG_CHECK((pc || N == 0) && K && depth, "prg_pc2depth: null pointer");
   PRG_CHECK(B > 0 && N >= 0 && H > 0 && W > 0, "prg_pc2depth: bad shape");
   hipStream_t s = (hipStream_t)stream;
   size_t n = (size_t)B * H * W;
