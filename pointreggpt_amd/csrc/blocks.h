@@ -6,7 +6,6 @@
 namespace prg {
 
 constexpr int kHeads = 4, kDimHead = 32, kHidden = 128;   // sd:738, sd:773
-constexpr int kGnMaxSplit = 64;
 
 // GroupNorm (sd:685, eps 1e-5) over NHWC x (B, HW, C).  Pass 1 writes per-slab (sum, sumsq) partials
 // [B][nsplit][G][2]; pass 2 reduces them in a fixed order (deterministic), normalises, applies the optional
@@ -25,6 +24,11 @@ struct GnApply {
   const int* ss_a_row;    // optional device int: row index into ss_a added on top (sampler: current step), or null
   int64_t ss_a_row_stride;
 };
+// Fold GroupNorm (+ conditioning) into per-(image, channel) affine coefficients y = x * A + B (the SiLU that follows
+// is applied by the consumer): the fused prologue of the next conv reads these.  A, Bc: [B][C] float32.
+int launch_gn_coeff(const float* partials, int nsplit, const GnApply& p, float* A, float* Bc, int B, int HW, int C,
+                    int G, hipStream_t s);
+
 template <typename T>
 int launch_gn_apply(const T* x, const float* partials, int nsplit, const GnApply& p, const T* residual, T* out, int B,
                     int HW, int C, int G, hipStream_t s);

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
   const int p0 = blockIdx.x * slab, p1 = min(HW, p0 + slab);
   const size_t base = (size_t)b * HW * C;
+#pragma unroll 4
   for (int px = p0 + ps; px < p1; px += psub) {
     const size_t o = base + (size_t)px * C + vc * VEC;
     Vec16<T> v = vec_load(x + o), r, w;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int u = 0; u < VEC; ++u) {
       float y = fmaf(Elem<T>::load(v.e[u]), a[u], bb[u]);
       if (ssa) y = fmaf(y, sc[u], sh[u]);
-      y = silu_f(y);
+      y = Elem<T>::silu(y);
       if (residual) y += Elem<T>::load(r.e[u]);
       w.e[u] = Elem<T>::store(y);
     }
@@ -187,6 +188,58 @@ template int launch_gn_apply<float>(const float*, const float*, int, const GnApp
                                     int, hipStream_t);
 template int launch_gn_apply<bf16_t>(const bf16_t*, const float*, int, const GnApply&, const bf16_t*, bf16_t*, int, int,
                                      int, int, hipStream_t);
+
+// grid (B): GroupNorm (+ conditioning) folded to y = x * A[b][c] + Bc[b][c]
+__global__ __launch_bounds__(256) void gn_coeff_kernel(const float* __restrict__ partials, int nsplit, GnApply p,
+                                                       float* __restrict__ A, float* __restrict__ Bc, int HW, int C,
+                                                       int G) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x;
+  if (threadIdx.x < G) {
+    double ss = 0, qq = 0;
+    const float* pp = partials + ((size_t)b * nsplit * G + threadIdx.x) * 2;
+    for (int k = 0; k < nsplit; ++k) {
+      ss += (double)pp[(size_t)k * G * 2 + 0];
+      qq += (double)pp[(size_t)k * G * 2 + 1];
+    }
+    const double n = (double)HW * (C / G);
+    const double mean = ss / n;
+    double var = qq / n - mean * mean;
+    if (var < 0) var = 0;
+    s_mean[threadIdx.x] = (float)mean;
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  const float* ssa = nullptr;
+  const float* ssb = nullptr;
+  if (p.ss_a) {
+    ssa = p.ss_a + (size_t)b * p.ss_a_stride;
+    if (p.ss_a_row) ssa += (size_t)(*p.ss_a_row) * p.ss_a_row_stride;
+    if (p.ss_b) ssb = p.ss_b + (size_t)b * p.ss_b_stride;
+  }
+  const int cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    float a = s_rstd[g] * p.gamma[c];
+    float bb = p.beta[c] - s_mean[g] * a;
+    if (ssa) {
+      float s0 = ssa[c], s1 = ssa[C + c];
+      if (ssb) { s0 += ssb[c]; s1 += ssb[C + c]; }
+      a = a * (s0 + 1.0f);
+      bb = fmaf(bb, s0 + 1.0f, s1);
+    }
+    A[(size_t)b * C + c] = a;
+    Bc[(size_t)b * C + c] = bb;
+  }
+}
+
+int launch_gn_coeff(const float* partials, int nsplit, const GnApply& p, float* A, float* Bc, int B, int HW, int C,
+                    int G, hipStream_t s) {
+  PRG_CHECK(partials && A && Bc && G <= 64 && C % G == 0, "gn_coeff: bad arguments");
+  gn_coeff_kernel<<<B, 256, 0, s>>>(partials, nsplit, p, A, Bc, HW, C, G);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
 
 // =============================================================================================
 // channel LayerNorm (per pixel over C, biased variance, eps 1e-5, gain only) + optional residual

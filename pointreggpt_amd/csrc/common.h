@@ -72,12 +72,18 @@ struct Elem<float> {
   static constexpr int kVec = 4;  // elements per 16-byte vector
   __host__ __device__ static inline float load(float v) { return v; }
   __host__ __device__ static inline float store(float v) { return v; }
+  // parity mode: IEEE exp / divide, the reference's x * sigmoid(x)
+  __device__ static inline float silu(float x) { return x / (1.0f + expf(-x)); }
 };
 template <>
 struct Elem<bf16_t> {
   static constexpr int kVec = 8;
   __host__ __device__ static inline float load(bf16_t v) { return bf16_to_f32(v); }
   __host__ __device__ static inline bf16_t store(float v) { return f32_to_bf16(v); }
+  // throughput mode: v_exp_f32 + v_rcp_f32 (1 ulp-class, far below bf16 resolution)
+  __device__ static inline float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+  }
 };
 
 // 16-byte vector of T with element access as float
@@ -124,6 +130,8 @@ __device__ inline double wave_sum_d(double v) {
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+constexpr int kGnMaxSplit = 256;   // max GroupNorm (sum, sumsq) partial slabs per image
 
 // ---------------------------------------------------------------------------------------------
 // activations

@@ -1,4 +1,4 @@
-// conv.h — launch interface of the implicit-GEMM convolution and its weight packing.
+// conv.h — launch interface of the MFMA convolutions and their weight packing.
 #pragma once
 #include <vector>
 
@@ -6,17 +6,15 @@
 
 namespace prg {
 
-// K-chunk (elements of one tap's channel range staged per main-loop iteration): 64 bytes per tile row.
+// K-chunk of the generic kernel (elements of one tap's channel range staged per main-loop iteration): 64 bytes
+// per tile row.  The halo kernel consumes two of these per step (128-byte pixel rows).
 template <typename T>
 struct ConvTile {
   static constexpr int BK = 64 / (int)sizeof(T);  // bf16: 32, f32: 16
 };
 
-// Optional prologue applied to the INPUT of a convolution while it is staged into LDS — this is how
-// GroupNorm + (scale+1, shift) + SiLU of the previous Block is fused into the consuming conv.
 struct ConvDesc {
-  // geometry
-  int B, Hin, Win;          // source tensors' spatial size (before optional x2 nearest upsample)
+  int B, Hin, Win;          // source tensors' spatial size (before the optional x2 nearest upsample)
   int C0, C1;               // channels of src0 / src1 (virtual concat [src0, src1]); C1 = 0 when unused
   int ups;                  // 1: conv runs on the 2x nearest-upsampled image (Upsample, sd:592-594)
   int KH, KW, stride, pad;
@@ -39,10 +37,27 @@ struct ConvLaunch {
   const float* bias;     // [Cout] or null
   const T* residual;     // NHWC (M, Cout) added in the epilogue, or null
   T* out;                // NHWC (M, Cout)
+  // fused GroupNorm statistics of the OUTPUT (before any activation): per (image, M-tile, group) (sum, sumsq)
+  // written to gn_partials [B][gn_nsplit][gn_groups][2]; null = off.  launch_conv decides whether the shape
+  // allows it and reports the slab count through *gn_nsplit_out (0 = caller must run the stats kernel).
+  float* gn_partials;
+  int gn_groups;
+  // fused prologue on the INPUT (halo kernel, single source): x <- silu(x * pro_a[b][c] + pro_b[b][c]);
+  // this is GroupNorm + (scale+1, shift) + SiLU of the previous Block folded into per-(image, channel) affine
+  // coefficients (sd:690-696).  null = off.
+  const float* pro_a;
+  const float* pro_b;
 };
 
+// Returns PRG_OK; *gn_nsplit_out (may be null) receives the number of statistic slabs per image written, or 0
+// when statistics were requested but this shape cannot fuse them.  `allow_prologue` must be checked by the
+// caller with conv_supports_prologue() before setting pro_a / pro_b.
 template <typename T>
-int launch_conv(const ConvLaunch<T>& L, hipStream_t s);
+int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out);
+
+// true when the 3x3 halo kernel will run this conv (so a fused input prologue is available)
+template <typename T>
+bool conv_supports_prologue(const ConvDesc& d);
 
 inline double conv_flops(const ConvDesc& d) {
   return 2.0 * (double)d.B * d.Hout * d.Wout * d.Cout * (double)(d.C0 + d.C1) * d.KH * d.KW;

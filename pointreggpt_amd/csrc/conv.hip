@@ -2,16 +2,23 @@
 //
 //   out[m][n] = bias[n] + sum_{tap,c} in[pixel(m) + tap][c] * w[n][tap][c]        m = (b, oy, ox), NHWC
 //
-// One kernel covers every MFMA-shaped conv on the path (sd:592-616, 681-796, 864-918): 3x3 (Block proj, the last
-// down/up convs), 4x4 stride 2 (Downsample), 1x1 (res_conv, to_qkv, to_out), the x2 nearest Upsample folded into
-// the gather, and the skip concat as two source pointers.  T = bf16_t uses v_mfma_f32_32x32x16_bf16 (fp32
-// accumulate); T = float uses v_mfma_f32_32x32x2_f32, which is an exact k-ordered fmaf chain — the parity mode.
+// T = bf16_t uses v_mfma_f32_32x32x16_bf16 (fp32 accumulate); T = float uses v_mfma_f32_32x32x2_f32, an exact
+// k-ordered fmaf chain — the parity mode.  Two kernels share one epilogue:
 //
-// Tiling: a 256-thread workgroup (4 waves) owns a BM x BN output tile; the main loop walks (tap, 64-byte channel
-// chunk).  Both operands are staged global -> registers -> LDS (register staging lets the gather zero-fill the
-// padding halo and select the concat source per 16-byte vector), with the next chunk's global loads issued
-// before the MFMAs of the current one and a double-buffered LDS image, so there is one barrier per chunk.
-// LDS rows are padded by 16 B: the 32 rows a wave reads with one ds_read_b128 fall on distinct bank slots.
+//  * conv3x3_halo_kernel — every 3x3 / stride 1 / pad 1 conv whose widths are multiples of 128 bytes (all of them
+//    at dim = 64: Block.proj, the last down/up convs, Upsample's conv with the x2 nearest gather folded in, the
+//    skip concat as two sources).  A workgroup owns a TH x TW pixel tile of ONE image: its (TH+2) x (TW+2) input
+//    halo is staged into LDS once per 128-byte channel chunk and reused by all nine taps (9x less global->LDS
+//    traffic than an im2col gather), weights stream through a double-buffered LDS tile one tap at a time, and
+//    the next chunk's halo is prefetched into registers underneath the MFMAs.  LDS images are XOR-swizzled at
+//    16-byte granularity (unit ^= (row >> 1) & 7) so the 32 rows of a ds_read_b128 fragment load hit distinct
+//    bank quads.  Optional fused prologue: GroupNorm + (scale+1, shift) + SiLU of the previous Block applied
+//    while the halo is written (each halo pixel transformed once, never the 9x im2col copies).
+//  * conv_igemm_kernel — the general gather form (1x1, 4x4 stride 2, ragged widths, tiny images).
+//
+// Shared epilogue: accumulators are transposed through LDS so every lane stores 16 contiguous bytes (full 128-byte
+// lines per 8 lanes) instead of 2-byte pieces, bias / residual are added on the way, and the per-(image, tile,
+// group) GroupNorm partial sums of the output are emitted in a fixed order (deterministic) for the consumer.
 #include "conv.h"
 
 namespace prg {
@@ -19,58 +26,344 @@ namespace prg {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// One "unit" = 16 bytes = Elem<T>::kVec channels.  A fragment step consumes one unit per lane.
 template <typename T>
 struct Mma;
 
 template <>
 struct Mma<bf16_t> {
-  static constexpr int KSTEP = 16;
+  // per 2 units (hi = lane>>5 picks the unit): one K=16 MFMA
+  static constexpr int UNITS_PER_CALL = 2;
   using Frag = bf16x8;
-  __device__ static inline Frag load(const bf16_t* row_base, int kk, int hi) {
-    return *reinterpret_cast<const Frag*>(row_base + kk * 16 + hi * 8);
-  }
-  __device__ static inline f32x16 mma(Frag a, Frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  __device__ static inline int unit_of(int call, int hi) { return call * 2 + hi; }
+  __device__ static inline Frag load(const void* p) { return *reinterpret_cast<const Frag*>(p); }
+  __device__ static inline void mma(const Frag& a, const Frag& b, f32x16& c, int /*hi*/) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
 
 template <>
 struct Mma<float> {
-  static constexpr int KSTEP = 2;
-  using Frag = float;
-  __device__ static inline Frag load(const float* row_base, int kk, int hi) { return row_base[kk * 2 + hi]; }
-  __device__ static inline f32x16 mma(Frag a, Frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  // per unit (both lane halves read the SAME 4 floats): two K=2 MFMAs, k = {0,1} then {2,3}
+  static constexpr int UNITS_PER_CALL = 1;
+  struct Frag {
+    float4 v;
+  };
+  __device__ static inline int unit_of(int call, int /*hi*/) { return call; }
+  __device__ static inline Frag load(const void* p) {
+    Frag f;
+    f.v = *reinterpret_cast<const float4*>(p);
+    return f;
+  }
+  __device__ static inline void mma(const Frag& a, const Frag& b, f32x16& c, int hi) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a.v.y : a.v.x, hi ? b.v.y : b.v.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a.v.w : a.v.z, hi ? b.v.w : b.v.z, c, 0, 0, 0);
   }
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch<T> L, const int M, const int tiles_m,
-                                                         const int tiles_n) {
-  constexpr int BK = ConvTile<T>::BK;
+// ---------------------------------------------------------------------------------------------
+// shared epilogue
+// ---------------------------------------------------------------------------------------------
+// Wave tile = (TM*32) rows x 64 columns.  `stage` = this wave's private LDS scratch of 32 x 68 floats.
+// row_to_m(local_row) -> global output row (pixel index) or -1.  Returns through (gs, gq) this lane's partial
+// (sum, sumsq) over the 8 consecutive channels it stored (cols (lane & 7) * 8 .. + 7 of the wave tile).
+template <typename T, int TM, typename RowMap>
+__device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][2], float* stage, int lane,
+                                      int col0, RowMap row_to_m, float& gs, float& gq) {
+  constexpr int P = 68;  // stage pitch (floats): 64 + 4 keeps rows 16-byte aligned and off one bank
   constexpr int VEC = Elem<T>::kVec;
-  constexpr int VPR = BK / VEC;              // 16-byte vectors per tile row (4)
-  constexpr int BKP = BK + VEC;              // row pitch: +16 B
-  constexpr int RPP = 256 / VPR;             // rows staged per pass (64)
-  constexpr int AP = BM / RPP, BP = BN / RPP;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int cc = lane & 7, rr = lane >> 3;  // read-back role: 8 lanes per row, 8 rows per pass
+  const int col = col0 + cc * 8;
+  const bool col_ok = col < L.d.Cout;       // Cout is a multiple of 8 on this path
+  float bias[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) bias[u] = (L.bias && col_ok) ? L.bias[col + u] : 0.0f;
+  gs = 0.0f;
+  gq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();  // previous pass fully read (and, first time, the main loop's LDS reads are done)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * hi) * P + j * 32 + l31] = acc[i][j][e];
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = pass * 8 + rr;
+      const int64_t m = row_to_m(i * 32 + r);
+      const float4 v0 = *reinterpret_cast<const float4*>(stage + r * P + cc * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(stage + r * P + cc * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (m >= 0 && col_ok) {
+        const size_t o = (size_t)m * L.d.Cout + col;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] += bias[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { gs += v[u]; gq = fmaf(v[u], v[u], gq); }
+        if (L.residual) {
+#pragma unroll
+          for (int h = 0; h < 8 / VEC; ++h) {
+            Vec16<T> rv = vec_load(L.residual + o + h * VEC);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) v[h * VEC + u] += Elem<T>::load(rv.e[u]);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 8 / VEC; ++h) {
+          Vec16<T> w;
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) w.e[u] = Elem<T>::store(v[h * VEC + u]);
+          vec_store(L.out + o + h * VEC, w);
+        }
+      }
+    }
+  }
+}
+
+// Block-level, fixed-order reduction of the lanes' (gs, gq) into per-group partials and one global store per group.
+// red = LDS scratch of 4 waves x 8 column chunks x 2 floats.  Wave layout WAVES_M x WAVES_N, wave tile 64 columns.
+template <int WAVES_M, int WAVES_N>
+__device__ inline void epilogue_stats(float* red, float gs, float gq, int wave, int lane, int tn_col0, int Cout,
+                                      int groups, float* dst /* partials + (image*nsplit + slab) * groups * 2 */) {
+  // lanes with equal (lane & 7) stored the same 8-channel column chunk: fold the 8 row-lanes together
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    gs += __shfl_xor(gs, o, 64);
+    gq += __shfl_xor(gq, o, 64);
+  }
+  __syncthreads();
+  if (lane < 8) {
+    red[(wave * 8 + lane) * 2 + 0] = gs;
+    red[(wave * 8 + lane) * 2 + 1] = gq;
+  }
+  __syncthreads();
+  const int cpg = Cout / groups;                 // multiple of 8 on this path
+  const int ngrp_blk = (WAVES_N * 64) / cpg;     // groups covered by this workgroup's columns
+  const int t = wave * 64 + lane;
+  if (t < ngrp_blk) {
+    const int g = tn_col0 / cpg + t;
+    if (g < groups) {
+      float ss = 0.0f, qq = 0.0f;
+      for (int ch = 0; ch < cpg / 8; ++ch) {
+        const int cblk = t * (cpg / 8) + ch;     // 8-channel chunk index within the workgroup's columns
+        const int wn = cblk / 8, c8 = cblk % 8;
+        for (int wm = 0; wm < WAVES_M; ++wm) {
+          ss += red[((wm * WAVES_N + wn) * 8 + c8) * 2 + 0];
+          qq += red[((wm * WAVES_N + wn) * 8 + c8) * 2 + 1];
+        }
+      }
+      dst[g * 2 + 0] = ss;
+      dst[g * 2 + 1] = qq;
+    }
+  }
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed); give each XCD a contiguous run of tiles so the
+// tiles that share input halos / weight tiles meet in one L2.  Bijective for any grid size.
+__device__ inline int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 halo kernel
+// ---------------------------------------------------------------------------------------------
+template <typename T, int TH, int TW, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvLaunch<T> L, const int tiles_x,
+                                                           const int tiles_y, const int tiles_n, const int fuse_stats) {
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int CH = 8 * VEC;                 // channels per 128-byte pixel row (bf16 64, f32 32)
+  constexpr int BKG = ConvTile<T>::BK;        // packed-weight chunk (half a pixel row)
+  constexpr int BM = TH * TW;
+  constexpr int HP = TW + 2, HALO = (TH + 2) * HP;
+  constexpr int NH = (HALO * 8 + 255) / 256;  // halo units per thread
+  constexpr int NB = BN * 8 / 256;            // weight units per thread
+  constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M, TM = WM / 32;
+  constexpr int CALLS = 8 / Mma<T>::UNITS_PER_CALL;
+  static_assert(WM % 32 == 0 && TM >= 1, "wave tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* As = reinterpret_cast<T*>(smem);        // [2][BM][BKP]
-  T* Bs = As + 2 * BM * BKP;                 // [2][BN][BKP]
+  uint4* Ah = reinterpret_cast<uint4*>(smem);            // [HALO][8] swizzled 16-byte units
+  uint4* Bs = Ah + HALO * 8;                             // [2][BN][8]
+  float* stage = reinterpret_cast<float*>(smem);         // epilogue scratch aliases the main-loop images
 
   const ConvDesc& d = L.d;
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed); give each XCD a contiguous run of tiles so
-  // the tiles that share input halos / the same A tile meet in one L2.  Bijective for any grid size.
-  const int nblk = tiles_m * tiles_n;
-  const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int nblk = tiles_x * tiles_y * tiles_n * d.B;
+  int lin = xcd_remap(blockIdx.x, nblk);
+  const int tn = lin % tiles_n; lin /= tiles_n;
+  const int tx = lin % tiles_x; lin /= tiles_x;
+  const int ty = lin % tiles_y;
+  const int b = lin / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int Cin = d.C0 + d.C1;
+  const int nchunks = Cin / CH;
+  const int Hl = d.Hout, Wl = d.Wout;         // 3x3 s1 p1: conv input extent == output extent (after upsample)
+  const int slot = tid & 7;                    // this thread always stages unit `slot` of a row (256 % 8 == 0)
+
+  // per-thread halo bookkeeping: source pixel offset (or -1) of each of its halo units
+  int64_t hsrc[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int hp = (tid >> 3) + k * 32;
+    hsrc[k] = -1;
+    if (hp < HALO) {
+      const int hy = hp / HP, hx = hp - hy * HP;
+      int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      if ((unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl) {
+        if (d.ups) { y >>= 1; x >>= 1; }
+        hsrc[k] = ((int64_t)b * d.Hin + y) * d.Win + x;
+      }
+    }
+  }
+  // per-lane fragment rows: tile pixel p -> halo position of tap (0,0)
+  int ahp[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = wm * WM + i * 32 + l31;
+    ahp[i] = (p / TW) * HP + (p % TW);
+  }
+
+  Vec16<T> hreg[NH], breg[NB];
+  auto gload_halo = [&](int chunk) {
+    const int c = chunk * CH + slot * VEC;
+    const bool first = c < d.C0;
+    const T* base = first ? L.src0 : L.src1;
+    const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) hreg[k] = hsrc[k] >= 0 ? vec_load(base + hsrc[k] * Cs + cc) : vec_zero<T>();
+  };
+  auto gload_b = [&](int chunk, int tap) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int n = (tid >> 3) + j * 32;
+      const T* p = L.w + ((size_t)(tap * d.kchunks + 2 * chunk + (slot >> 2)) * d.CoutPad + tn * BN + n) * BKG +
+                   (slot & 3) * VEC;
+      breg[j] = vec_load(p);
+    }
+  };
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int niter = nchunks * 9;
+  gload_halo(0);
+  gload_b(0, 0);
+  int tap = 0, chunk = 0;
+  for (int it = 0; it < niter; ++it) {
+    if (tap == 0) {
+      if (it > 0) __syncthreads();            // every wave is done reading the previous chunk's halo
+      // prologue coefficients of this thread's 8 channels (only when fused)
+      float pa[VEC], pb[VEC];
+      if (L.pro_a) {
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+          pa[u] = L.pro_a[(size_t)b * d.C0 + chunk * CH + slot * VEC + u];
+          pb[u] = L.pro_b[(size_t)b * d.C0 + chunk * CH + slot * VEC + u];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int hp = (tid >> 3) + k * 32;
+        if (hp < HALO) {
+          Vec16<T> v = hreg[k];
+          if (L.pro_a && hsrc[k] >= 0) {
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) v.e[u] = Elem<T>::store(Elem<T>::silu(fmaf(Elem<T>::load(v.e[u]), pa[u], pb[u])));
+          }
+          Ah[hp * 8 + (slot ^ ((hp >> 1) & 7))] = *reinterpret_cast<const uint4*>(&v);
+        }
+      }
+    }
+    uint4* Bb = Bs + (it & 1) * BN * 8;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int n = (tid >> 3) + j * 32;
+      Bb[n * 8 + (slot ^ ((n >> 1) & 7))] = *reinterpret_cast<const uint4*>(&breg[j]);
+    }
+    __syncthreads();
+    // next iteration's operands: in flight underneath the MFMAs
+    const int ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
+    if (it + 1 < niter) gload_b(nchunk, ntap);
+    if (tap == 0 && chunk + 1 < nchunks) gload_halo(chunk + 1);
+
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int toff = kh * HP + kw;
+#pragma unroll
+    for (int call = 0; call < CALLS; ++call) {
+      const int unit = Mma<T>::unit_of(call, hi);
+      typename Mma<T>::Frag fa[TM], fb[2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int hp = ahp[i] + toff;
+        fa[i] = Mma<T>::load(Ah + hp * 8 + (unit ^ ((hp >> 1) & 7)));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + j * 32 + l31;
+        fb[j] = Mma<T>::load(Bb + n * 8 + (unit ^ ((n >> 1) & 7)));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j], hi);
+    }
+    tap = ntap;
+    chunk = nchunk;
+  }
+
+  float gs, gq;
+  auto row_to_m = [&](int r) -> int64_t {
+    const int p = wm * WM + r;
+    return ((int64_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+  };
+  epilogue_store<T, TM>(L, acc, stage + wave * 32 * 68, lane, tn * BN + wn * 64, row_to_m, gs, gq);
+  if (fuse_stats) {
+    const int nsplit = tiles_x * tiles_y;
+    float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
+    epilogue_stats<WAVES_M, WAVES_N>(stage + 4 * 32 * 68, gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic gather kernel (1x1, 4x4 s2, ragged shapes)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvLaunch<T> L, const int M, const int tiles_m,
+                                                         const int tiles_n, const int fuse_stats, const int wide) {
+  constexpr int BK = ConvTile<T>::BK;
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int UPR = BK / VEC;              // 16-byte units per tile row (4)
+  constexpr int RPP = 256 / UPR;             // rows staged per pass (64)
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M, TM = WM / 32;
+  constexpr int CALLS = UPR / Mma<T>::UNITS_PER_CALL;
+  static_assert(TM >= 1, "wave tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* As = reinterpret_cast<uint4*>(smem);   // [2][BM][UPR+1]  (row pitch 5 units = 80 B: conflict-free b128 reads)
+  uint4* Bs = As + 2 * BM * (UPR + 1);          // [2][BN][UPR+1]
+  float* stage = reinterpret_cast<float*>(smem);
+  constexpr int PITCH = UPR + 1;
+
+  const ConvDesc& d = L.d;
+  const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tn = lin % tiles_n, tm = lin / tiles_n;
 
   const int tid = threadIdx.x;
-  const int lrow = tid / VPR, kvec = tid % VPR;
+  const int lrow = tid / UPR, ku = tid % UPR;
   const int Cin = d.C0 + d.C1;
   const int Hl = d.ups ? 2 * d.Hin : d.Hin, Wl = d.ups ? 2 * d.Win : d.Win;
   const int HWo = d.Hout * d.Wout;
@@ -80,30 +373,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch<T> L, 
   bool a_ok[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    int m = tm * BM + lrow + i * RPP;
+    const int m = tm * BM + lrow + i * RPP;
     a_ok[i] = m < M;
-    int mm = a_ok[i] ? m : 0;
-    int b = mm / HWo, rem = mm - b * HWo;
-    int oy = rem / d.Wout, ox = rem - oy * d.Wout;
+    const int mm = a_ok[i] ? m : 0;
+    const int bb = mm / HWo, rem = mm - bb * HWo;
+    const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
     a_iy0[i] = oy * d.stride - d.pad;
     a_ix0[i] = ox * d.stride - d.pad;
-    a_base[i] = (int64_t)b * d.Hin * d.Win;
+    a_base[i] = (int64_t)bb * d.Hin * d.Win;
   }
 
   Vec16<T> ra[AP], rb[BP];
-  const int ntaps = d.KH * d.KW;
-  const int niter = ntaps * d.kchunks;
-
+  const int niter = d.KH * d.KW * d.kchunks;
   auto gload = [&](int tap, int kc) {
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
-    const int c = kc * BK + kvec * VEC;
+    const int c = kc * BK + ku * VEC;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-      bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl && c < Cin;
+      const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl && c < Cin;
       if (d.ups) { iy >>= 1; ix >>= 1; }
       if (ok) {
-        int64_t pix = a_base[i] + (int64_t)iy * d.Win + ix;
+        const int64_t pix = a_base[i] + (int64_t)iy * d.Win + ix;
         const T* p = (c < d.C0) ? L.src0 + pix * d.C0 + c : L.src1 + pix * d.C1 + (c - d.C0);
         ra[i] = vec_load(p);
       } else {
@@ -119,76 +410,143 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch<T> L, 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, hi = lane >> 5;
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[TM][2];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   int tap = 0, kc = 0;
   gload(0, 0);
   for (int it = 0; it < niter; ++it) {
-    const int buf = it & 1;
-    T* Ab = As + buf * BM * BKP;
-    T* Bb = Bs + buf * BN * BKP;
+    uint4* Ab = As + (it & 1) * BM * PITCH;
+    uint4* Bb = Bs + (it & 1) * BN * PITCH;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) vec_store(Ab + (lrow + i * RPP) * BKP + kvec * VEC, ra[i]);
+    for (int i = 0; i < AP; ++i) Ab[(lrow + i * RPP) * PITCH + ku] = *reinterpret_cast<const uint4*>(&ra[i]);
 #pragma unroll
-    for (int j = 0; j < BP; ++j) vec_store(Bb + (lrow + j * RPP) * BKP + kvec * VEC, rb[j]);
+    for (int j = 0; j < BP; ++j) Bb[(lrow + j * RPP) * PITCH + ku] = *reinterpret_cast<const uint4*>(&rb[j]);
     __syncthreads();
     if (++kc == d.kchunks) { kc = 0; ++tap; }
-    if (it + 1 < niter) gload(tap, kc);   // in flight while the MFMAs below run
+    if (it + 1 < niter) gload(tap, kc);
 #pragma unroll
-    for (int kk = 0; kk < BK / Mma<T>::KSTEP; ++kk) {
-      typename Mma<T>::Frag fa[TM], fb[TN];
+    for (int call = 0; call < CALLS; ++call) {
+      const int unit = Mma<T>::unit_of(call, hi);
+      typename Mma<T>::Frag fa[TM], fb[2];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = Mma<T>::load(Ab + (wm * WM + i * 32 + l31) * BKP, kk, hi);
+      for (int i = 0; i < TM; ++i) fa[i] = Mma<T>::load(Ab + (wm * WM + i * 32 + l31) * PITCH + unit);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = Mma<T>::load(Bb + (wn * WN + j * 32 + l31) * BKP, kk, hi);
+      for (int j = 0; j < 2; ++j) fb[j] = Mma<T>::load(Bb + (wn * 64 + j * 32 + l31) * PITCH + unit);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j], hi);
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if (wide) {
+    float gs, gq;
+    auto row_to_m = [&](int r) -> int64_t {
+      const int m = tm * BM + wm * WM + r;
+      return m < M ? (int64_t)m : (int64_t)-1;
+    };
+    epilogue_store<T, TM>(L, acc, stage + wave * 32 * 68, lane, tn * BN + wn * 64, row_to_m, gs, gq);
+    if (fuse_stats) {
+      const int nsplit = HWo / BM;
+      const int bimg = (tm * BM) / HWo, slab = tm - bimg * nsplit;
+      float* dst = L.gn_partials + ((size_t)bimg * nsplit + slab) * L.gn_groups * 2;
+      epilogue_stats<WAVES_M, WAVES_N>(stage + 4 * 32 * 68, gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
+    }
+  } else {
+    // narrow fallback (Cout not a multiple of 8): C/D layout col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = tn * BN + wn * WN + j * 32 + l31;
-    if (col >= d.Cout) continue;
-    const float bv = L.bias ? L.bias[col] : 0.0f;
+    for (int j = 0; j < 2; ++j) {
+      const int col = tn * BN + wn * 64 + j * 32 + l31;
+      if (col >= d.Cout) continue;
+      const float bv = L.bias ? L.bias[col] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = tm * BM + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        if (row < M) {
-          float v = acc[i][j][e] + bv;
-          const size_t o = (size_t)row * d.Cout + col;
-          if (L.residual) v += Elem<T>::load(L.residual[o]);
-          L.out[o] = Elem<T>::store(v);
+        for (int e = 0; e < 16; ++e) {
+          const int row = tm * BM + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          if (row < M) {
+            float v = acc[i][j][e] + bv;
+            const size_t o = (size_t)row * d.Cout + col;
+            if (L.residual) v += Elem<T>::load(L.residual[o]);
+            L.out[o] = Elem<T>::store(v);
+          }
         }
-      }
     }
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-static int launch_cfg(const ConvLaunch<T>& L, int M, hipStream_t s) {
-  constexpr int BK = ConvTile<T>::BK;
-  constexpr int BKP = BK + Elem<T>::kVec;
-  const int tiles_m = ceil_div(M, BM), tiles_n = L.d.CoutPad / BN;
-  const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(T);
-  conv_igemm_kernel<T, BM, BN, WM, WN><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n);
+// ---------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kEpilogueLds = (size_t)4 * 32 * 68 * sizeof(float) + 4 * 8 * 2 * sizeof(float);  // 35,072 B
+
+template <typename T>
+struct HaloPick {
+  int TH, TW, BN;
+};
+template <typename T>
+static bool pick_halo(const ConvDesc& d, HaloPick<T>* p) {
+  constexpr int CH = 8 * Elem<T>::kVec;
+  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return false;
+  if (d.C0 % CH || d.C1 % CH || d.Cout % 64) return false;
+  const int H = d.Hout, W = d.Wout;
+  if (d.Cout % 128 == 0) {
+    if (W % 32 == 0 && H % 4 == 0) { *p = {4, 32, 128}; return true; }
+    if (W % 16 == 0 && H % 8 == 0) { *p = {8, 16, 128}; return true; }
+    return false;
+  }
+  if (W % 32 == 0 && H % 8 == 0) { *p = {8, 32, 64}; return true; }
+  if (W % 16 == 0 && H % 8 == 0) { *p = {8, 16, 64}; return true; }
+  return false;
+}
+
+template <typename T>
+bool conv_supports_prologue(const ConvDesc& d) {
+  HaloPick<T> p;
+  return d.C1 == 0 && pick_halo<T>(d, &p);
+}
+template bool conv_supports_prologue<float>(const ConvDesc&);
+template bool conv_supports_prologue<bf16_t>(const ConvDesc&);
+
+template <typename T, int TH, int TW, int BN>
+static int launch_halo(const ConvLaunch<T>& L, hipStream_t s, int fuse_stats, int* nsplit) {
+  const ConvDesc& d = L.d;
+  const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH, tiles_n = d.Cout / BN;
+  constexpr int HALO = (TH + 2) * (TW + 2);
+  size_t lds = (size_t)(HALO * 8 + 2 * BN * 8) * 16;
+  if (lds < kEpilogueLds) lds = kEpilogueLds;
+  if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
+  conv3x3_halo_kernel<T, TH, TW, BN><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 256, lds, s>>>(L, tiles_x, tiles_y,
+                                                                                            tiles_n, fuse_stats);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+template <typename T, int BM, int BN>
+static int launch_igemm(const ConvLaunch<T>& L, int M, hipStream_t s, int want_stats, int* nsplit) {
+  constexpr int UPR = ConvTile<T>::BK / Elem<T>::kVec;
+  const ConvDesc& d = L.d;
+  const int tiles_m = ceil_div(M, BM), tiles_n = d.CoutPad / BN;
+  const int HWo = d.Hout * d.Wout;
+  const int wide = d.Cout % 8 == 0;
+  const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
+  const int fuse = want_stats && wide && cpg % 8 == 0 && cpg <= BN && HWo % BM == 0 && HWo / BM <= kGnMaxSplit;
+  if (nsplit) *nsplit = fuse ? HWo / BM : 0;
+  size_t lds = (size_t)2 * (BM + BN) * (UPR + 1) * 16;
+  if (lds < kEpilogueLds) lds = kEpilogueLds;
+  conv_igemm_kernel<T, BM, BN><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse, wide);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
 
 template <typename T>
-int launch_conv(const ConvLaunch<T>& L, hipStream_t s) {
+int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out) {
   const ConvDesc& d = L.d;
   constexpr int VEC = Elem<T>::kVec;
   PRG_CHECK(L.src0 && L.w && L.out, "conv: null pointer");
@@ -198,13 +556,26 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s) {
   const int64_t M64 = (int64_t)d.B * d.Hout * d.Wout;
   PRG_CHECK(M64 > 0 && M64 < (int64_t)1 << 31, "conv: M out of range");
   const int M = (int)M64;
-  if (d.CoutPad % 128 == 0) return launch_cfg<T, 128, 128, 64, 64>(L, M, s);
-  if (M >= 256 * 64) return launch_cfg<T, 256, 64, 64, 64>(L, M, s);
-  return launch_cfg<T, 128, 64, 32, 64>(L, M, s);
+  const int want_stats = L.gn_partials != nullptr;
+  if (gn_nsplit_out) *gn_nsplit_out = 0;
+  HaloPick<T> hp;
+  if (pick_halo<T>(d, &hp)) {
+    const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
+    const int tiles = (d.Wout / hp.TW) * (d.Hout / hp.TH);
+    const int fuse = want_stats && cpg % 8 == 0 && cpg <= hp.BN && tiles <= kGnMaxSplit;
+    if (hp.TH == 8 && hp.TW == 32 && hp.BN == 64) return launch_halo<T, 8, 32, 64>(L, s, fuse, gn_nsplit_out);
+    if (hp.TH == 4 && hp.TW == 32 && hp.BN == 128) return launch_halo<T, 4, 32, 128>(L, s, fuse, gn_nsplit_out);
+    if (hp.TH == 8 && hp.TW == 16 && hp.BN == 128) return launch_halo<T, 8, 16, 128>(L, s, fuse, gn_nsplit_out);
+    if (hp.TH == 8 && hp.TW == 16 && hp.BN == 64) return launch_halo<T, 8, 16, 64>(L, s, fuse, gn_nsplit_out);
+  }
+  PRG_CHECK(!L.pro_a, "conv: fused prologue requested on a shape the halo kernel does not cover");
+  if (d.CoutPad % 128 == 0) return launch_igemm<T, 128, 128>(L, M, s, want_stats, gn_nsplit_out);
+  if (M >= 256 * 64) return launch_igemm<T, 256, 64>(L, M, s, want_stats, gn_nsplit_out);
+  return launch_igemm<T, 128, 64>(L, M, s, want_stats, gn_nsplit_out);
 }
 
-template int launch_conv<float>(const ConvLaunch<float>&, hipStream_t);
-template int launch_conv<bf16_t>(const ConvLaunch<bf16_t>&, hipStream_t);
+template int launch_conv<float>(const ConvLaunch<float>&, hipStream_t, int*);
+template int launch_conv<bf16_t>(const ConvLaunch<bf16_t>&, hipStream_t, int*);
 
 // ---------------------------------------------------------------------------------------------
 // weight packing (host)
@@ -240,9 +611,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, T* __restrict__ out, int H,
                                                         int W, int Cout) {
   constexpr int TS = 16, HALO = 3, TW = TS + 2 * HALO;  // 22
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tile = reinterpret_cast<float*>(smem);          // [CIN][TW][TW]
-  float* wl = tile + CIN * TW * TW;                      // [49*CIN][Cout]
+  __shared__ float tile[CIN * TW * TW];
   const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
   const int tid = threadIdx.x;
   for (int i = tid; i < CIN * TW * TW; i += 256) {
@@ -250,12 +619,13 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     int yy = ty0 + rem / TW - HALO, xx = tx0 + rem % TW - HALO;
     tile[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[((size_t)b * CIN + c) * H * W + (size_t)yy * W + xx] : 0.0f;
   }
-  for (int i = tid; i < 49 * CIN * Cout; i += 256) wl[i] = wk[i];
   __syncthreads();
   const int ly = tid / TS, lx = tid % TS;
   const int oy = ty0 + ly, ox = tx0 + lx;
-  if (oy >= H || ox >= W) return;
-  T* o = out + (((size_t)b * H + oy) * W + ox) * Cout;
+  const bool ok = oy < H && ox < W;
+  T* o = out + (((size_t)b * H + (ok ? oy : 0)) * W + (ok ? ox : 0)) * Cout;
+  // the weight index is wave-uniform: the compiler reads it with scalar loads, so the inner loop is 1 LDS read per
+  // 8 FMAs.  Accumulation order = (cin, kh, kw) ascending fmaf chain.
 #pragma unroll 1
   for (int co = 0; co < Cout; co += 8) {
     float acc[8];
@@ -263,18 +633,19 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
 #pragma unroll 1
     for (int c = 0; c < CIN; ++c)
-#pragma unroll 1
+#pragma unroll
       for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 7; ++kw) {
-          float v = tile[c * TW * TW + (ly + kh) * TW + lx + kw];
-          const float* wp = wl + ((kh * 7 + kw) * CIN + c) * Cout + co;
+          const float v = tile[c * TW * TW + (ly + kh) * TW + lx + kw];
+          const float* wp = wk + ((kh * 7 + kw) * CIN + c) * Cout + co;
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc[u] = fmaf(v, wp[u], acc[u]);
         }
+    if (ok) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (co + u < Cout) o[co + u] = Elem<T>::store(acc[u] + bias[co + u]);
+      for (int u = 0; u < 8; ++u) o[co + u] = Elem<T>::store(acc[u] + bias[co + u]);
+    }
   }
 }
 
@@ -284,12 +655,10 @@ int launch_stem_conv(const float* x, const float* wk, const float* bias, T* out,
   PRG_CHECK(Cin == 1 || Cin == 3, "stem conv: Cin must be 1 or 3");
   PRG_CHECK(Cout % 8 == 0, "stem conv: Cout must be a multiple of 8");
   dim3 grid(ceil_div(W, 16), ceil_div(H, 16), B);
-  size_t lds = ((size_t)Cin * 22 * 22 + (size_t)49 * Cin * Cout) * sizeof(float);
-  PRG_CHECK(lds <= 64 * 1024, "stem conv: weights do not fit LDS");
   if (Cin == 1)
-    stem_conv_kernel<T, 1><<<grid, 256, lds, s>>>(x, wk, bias, out, H, W, Cout);
+    stem_conv_kernel<T, 1><<<grid, 256, 0, s>>>(x, wk, bias, out, H, W, Cout);
   else
-    stem_conv_kernel<T, 3><<<grid, 256, lds, s>>>(x, wk, bias, out, H, W, Cout);
+    stem_conv_kernel<T, 3><<<grid, 256, 0, s>>>(x, wk, bias, out, H, W, Cout);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }

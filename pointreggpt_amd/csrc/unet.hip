@@ -241,17 +241,33 @@ struct UnetImpl : prg_unet {
   template <typename U>
   U* alloc(size_t n) { return reinterpret_cast<U*>(arena.alloc(n * sizeof(U))); }
 
-  int conv(const ConvP& p, const T* s0, int C0, const T* s1, int C1, int B, int Hin, int Win, int stride, int pad,
-           int ups, const T* residual, T* out, hipStream_t s) {
-    ConvLaunch<T> L;
-    L.d.B = B; L.d.Hin = Hin; L.d.Win = Win; L.d.C0 = C0; L.d.C1 = C1; L.d.ups = ups;
-    L.d.KH = p.KH; L.d.KW = p.KW; L.d.stride = stride; L.d.pad = pad;
+  struct ConvOpt {           // optional fusions of one conv launch
+    const T* residual = nullptr;
+    float* gn_partials = nullptr;   // fused GroupNorm statistics of the output
+    int* gn_nsplit = nullptr;       // out: slabs written (0 = not fused for this shape)
+    const float* pro_a = nullptr;   // fused GroupNorm+cond+SiLU on the input (halo kernel)
+    const float* pro_b = nullptr;
+  };
+
+  ConvDesc make_desc(const ConvP& p, int C0, int C1, int B, int Hin, int Win, int stride, int pad, int ups) const {
+    ConvDesc d;
+    d.B = B; d.Hin = Hin; d.Win = Win; d.C0 = C0; d.C1 = C1; d.ups = ups;
+    d.KH = p.KH; d.KW = p.KW; d.stride = stride; d.pad = pad;
     const int Hl = ups ? 2 * Hin : Hin, Wl = ups ? 2 * Win : Win;
-    L.d.Hout = (Hl + 2 * pad - p.KH) / stride + 1;
-    L.d.Wout = (Wl + 2 * pad - p.KW) / stride + 1;
-    L.d.Cout = p.Cout; L.d.CoutPad = p.CoutPad; L.d.kchunks = p.kchunks;
-    L.src0 = s0; L.src1 = s1; L.w = W(p); L.bias = F(p.b_off); L.residual = residual; L.out = out;
+    d.Hout = (Hl + 2 * pad - p.KH) / stride + 1;
+    d.Wout = (Wl + 2 * pad - p.KW) / stride + 1;
+    d.Cout = p.Cout; d.CoutPad = p.CoutPad; d.kchunks = p.kchunks;
+    return d;
+  }
+
+  int conv(const ConvP& p, const T* s0, int C0, const T* s1, int C1, int B, int Hin, int Win, int stride, int pad,
+           int ups, const ConvOpt& o, T* out, hipStream_t s) {
+    ConvLaunch<T> L;
+    L.d = make_desc(p, C0, C1, B, Hin, Win, stride, pad, ups);
+    L.src0 = s0; L.src1 = s1; L.w = W(p); L.bias = F(p.b_off); L.residual = o.residual; L.out = out;
+    L.gn_partials = o.gn_partials; L.gn_groups = lay.cfg.groups; L.pro_a = o.pro_a; L.pro_b = o.pro_b;
     PRG_CHECK(C0 + C1 == p.Cin, "conv: channel mismatch");
+    if (o.gn_nsplit) *o.gn_nsplit = 0;
     if (arena.dry) return PRG_OK;
     if (prof && prof->on) {
       if (prof->used == prof->pool.size()) {
@@ -262,22 +278,16 @@ struct UnetImpl : prg_unet {
       }
       auto& ev = prof->pool[prof->used++];
       PRG_HIP(hipEventRecord(ev.first, s));
-      int rc = launch_conv<T>(L, s);
+      int rc = launch_conv<T>(L, s, o.gn_nsplit);
       PRG_HIP(hipEventRecord(ev.second, s));
       prof->conv_flops += conv_flops(L.d);
       prof->launches += 1;
       return rc;
     }
-    return launch_conv<T>(L, s);
+    return launch_conv<T>(L, s, o.gn_nsplit);
   }
 
-  // GroupNorm + cond + SiLU (+ residual), in place on h
-  int gn(T* h, int64_t g_off, int64_t b_off, const CondSrc* cs, int ss_off, const T* residual, int B, int HW, int C,
-         float* partials, hipStream_t s) {
-    if (arena.dry) return PRG_OK;
-    int ns = 0;
-    int rc = launch_gn_stats<T>(h, partials, B, HW, C, lay.cfg.groups, &ns, s);
-    if (rc) return rc;
+  GnApply gn_params(int64_t g_off, int64_t b_off, const CondSrc* cs, int ss_off) const {
     GnApply p{};
     p.gamma = F(g_off); p.beta = F(b_off);
     if (cs && cs->ss_a) {
@@ -288,31 +298,54 @@ struct UnetImpl : prg_unet {
       p.ss_a_row = cs->row;
       p.ss_a_row_stride = cs->row_stride;
     }
-    return launch_gn_apply<T>(h, partials, ns, p, residual, h, B, HW, C, lay.cfg.groups, s);
+    return p;
   }
 
-  // ResnetBlock (sd:700-734 / dc:726-740): out <- block2(block1(cat[s0,s1])) + res(cat[s0,s1])
+  // ResnetBlock (sd:700-734 / dc:726-740): out <- block2(block1(cat[s0,s1])) + res(cat[s0,s1]).
+  //   conv1 (+ fused GN statistics) -> [GN + cond + SiLU folded into conv2's halo load] -> conv2 (+ statistics)
+  //   -> GN + SiLU + skip in one elementwise pass.
   int resblock(const ResP& r, const T* s0, int C0, const T* s1, int C1, const CondSrc* cs, T* out, int B, int H, int Wd,
                hipStream_t s) {
     const size_t m = arena.mark();
     const size_t M = (size_t)B * H * Wd;
+    const int G = lay.cfg.groups, HW = H * Wd;
     T* h1 = alloc<T>(M * r.cout);
     T* res = r.has_res ? alloc<T>(M * r.cout) : nullptr;
-    float* partials = alloc<float>((size_t)B * kGnMaxSplit * 64 * 2);
-    PRG_CHECK(arena.dry || (h1 && partials && (!r.has_res || res)), "workspace exhausted (resblock)");
-    int rc;
-    if ((rc = conv(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, nullptr, h1, s))) return rc;
-    if ((rc = gn(h1, r.g1, r.b1, lay.cfg.conditional ? cs : nullptr, r.ss_off, nullptr, B, H * Wd, r.cout, partials, s)))
-      return rc;
-    if ((rc = conv(r.c2, h1, r.cout, nullptr, 0, B, H, Wd, 1, 1, 0, nullptr, out, s))) return rc;
+    float* part1 = alloc<float>((size_t)B * kGnMaxSplit * G * 2);
+    float* part2 = alloc<float>((size_t)B * kGnMaxSplit * G * 2);
+    float* coefA = alloc<float>((size_t)B * r.cout);
+    float* coefB = alloc<float>((size_t)B * r.cout);
+    PRG_CHECK(arena.dry || (h1 && part1 && part2 && coefA && coefB && (!r.has_res || res)), "workspace exhausted (resblock)");
+    const CondSrc* c1 = lay.cfg.conditional ? cs : nullptr;
+    int rc, ns1 = 0, ns2 = 0;
+    ConvOpt o1;
+    o1.gn_partials = part1; o1.gn_nsplit = &ns1;
+    if ((rc = conv(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, o1, h1, s))) return rc;
+    if (!arena.dry && ns1 == 0 && (rc = launch_gn_stats<T>(h1, part1, B, HW, r.cout, G, &ns1, s))) return rc;
+    const GnApply g1 = gn_params(r.g1, r.b1, c1, r.ss_off);
+    ConvOpt o2;
+    o2.gn_partials = part2; o2.gn_nsplit = &ns2;
+    const bool fuse_pro = conv_supports_prologue<T>(make_desc(r.c2, r.cout, 0, B, H, Wd, 1, 1, 0));
+    if (!arena.dry) {
+      if (fuse_pro) {
+        if ((rc = launch_gn_coeff(part1, ns1, g1, coefA, coefB, B, HW, r.cout, G, s))) return rc;
+        o2.pro_a = coefA; o2.pro_b = coefB;
+      } else if ((rc = launch_gn_apply<T>(h1, part1, ns1, g1, nullptr, h1, B, HW, r.cout, G, s))) {
+        return rc;
+      }
+    }
+    if ((rc = conv(r.c2, h1, r.cout, nullptr, 0, B, H, Wd, 1, 1, 0, o2, out, s))) return rc;
+    if (!arena.dry && ns2 == 0 && (rc = launch_gn_stats<T>(out, part2, B, HW, r.cout, G, &ns2, s))) return rc;
     const T* skip = s0;
     if (r.has_res) {
-      if ((rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, nullptr, res, s))) return rc;
+      if ((rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, ConvOpt(), res, s))) return rc;
       skip = res;
     } else {
       PRG_CHECK(C1 == 0 && C0 == r.cout, "resblock: identity skip needs equal widths");
     }
-    if ((rc = gn(out, r.g2, r.b2, nullptr, 0, skip, B, H * Wd, r.cout, partials, s))) return rc;
+    if (!arena.dry &&
+        (rc = launch_gn_apply<T>(out, part2, ns2, gn_params(r.g2, r.b2, nullptr, 0), skip, out, B, HW, r.cout, G, s)))
+      return rc;
     arena.reset(m);
     return PRG_OK;
   }
@@ -330,14 +363,15 @@ struct UnetImpl : prg_unet {
     PRG_CHECK(arena.dry || (xn && qkv && o && (!a.linear || (y && ws))), "workspace exhausted (attention)");
     int rc;
     if (!arena.dry && (rc = launch_layernorm<T>(x, F(a.norm_g), nullptr, xn, (int64_t)M, a.C, s))) return rc;
-    if ((rc = conv(a.qkv, xn, a.C, nullptr, 0, B, H, Wd, 1, 0, 0, nullptr, qkv, s))) return rc;
+    if ((rc = conv(a.qkv, xn, a.C, nullptr, 0, B, H, Wd, 1, 0, 0, ConvOpt(), qkv, s))) return rc;
     if (a.linear) {
       if (!arena.dry && (rc = launch_linear_attention<T>(qkv, o, ws, B, N, s))) return rc;
-      if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, nullptr, y, s))) return rc;
+      if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, ConvOpt(), y, s))) return rc;
       if (!arena.dry && (rc = launch_layernorm<T>(y, F(a.out_g), x, out, (int64_t)M, a.C, s))) return rc;
     } else {
       if (!arena.dry && (rc = launch_full_attention<T>(qkv, o, B, N, s))) return rc;
-      if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, x, out, s))) return rc;
+      { ConvOpt ro; ro.residual = x;
+        if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, ro, out, s))) return rc; }
     }
     arena.reset(m);
     return PRG_OK;
@@ -387,7 +421,7 @@ struct UnetImpl : prg_unet {
       const int Ho = lv.strided ? H / 2 : H;
       T* xd = alloc<T>((size_t)B * Ho * Ho * Co);
       PRG_CHECK(arena.dry || xd, "workspace exhausted (downsample)");
-      if ((rc = conv(lv.resample, s2, C, nullptr, 0, B, H, H, lv.strided ? 2 : 1, 1, 0, nullptr, xd, s))) return rc;
+      if ((rc = conv(lv.resample, s2, C, nullptr, 0, B, H, H, lv.strided ? 2 : 1, 1, 0, ConvOpt(), xd, s))) return rc;
       if (i == 0) tap("down0_out", xd, B, Co, Ho, Ho);
       x = xd;
       H = Ho;
@@ -423,7 +457,7 @@ struct UnetImpl : prg_unet {
       sk = skips.back(); skips.pop_back();
       if ((rc = resblock(lv.r1, u1, Co, sk.first, sk.second, cs, u2, B, H, H, s))) return rc;
       if ((rc = attention(lv.at, u2, u3, B, H, H, s))) return rc;
-      if ((rc = conv(lv.resample, u3, Co, nullptr, 0, B, H, H, 1, 1, lv.strided ? 1 : 0, nullptr, xu, s))) return rc;
+      if ((rc = conv(lv.resample, u3, Co, nullptr, 0, B, H, H, 1, 1, lv.strided ? 1 : 0, ConvOpt(), xu, s))) return rc;
       arena.reset(mk);
       if (i == 0) tap("up0_out", xu, B, Ci, Ho, Ho);
       x = xu;
