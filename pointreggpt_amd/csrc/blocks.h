@@ -29,6 +29,11 @@ struct GnApply {
 int launch_gn_coeff(const float* partials, int nsplit, const GnApply& p, float* A, float* Bc, int B, int HW, int C,
                     int G, hipStream_t s);
 
+// y = silu(x * A[b][c] + Bc[b][c]) + residual over NHWC x (B, HW, C): the apply half of GroupNorm once gn_coeff ran.
+template <typename T>
+int launch_affine_silu(const T* x, const float* A, const float* Bc, const T* residual, T* out, int B, int HW, int C,
+                       hipStream_t s);
+
 template <typename T>
 int launch_gn_apply(const T* x, const float* partials, int nsplit, const GnApply& p, const T* residual, T* out, int B,
                     int HW, int C, int G, hipStream_t s);

@@ -189,6 +189,67 @@ template int launch_gn_apply<float>(const float*, const float*, int, const GnApp
 template int launch_gn_apply<bf16_t>(const bf16_t*, const float*, int, const GnApply&, const bf16_t*, bf16_t*, int, int,
                                      int, int, hipStream_t);
 
+// Flat elementwise pass: y = silu(x * A[b][c] + Bc[b][c]) + residual, with the coefficients precomputed by
+// gn_coeff_kernel (no per-workgroup statistics prologue: every workgroup streams from its first instruction).
+template <typename T>
+__global__ __launch_bounds__(256) void affine_silu_kernel(const T* __restrict__ x, const float* __restrict__ A,
+                                                          const float* __restrict__ Bc, const T* __restrict__ residual,
+                                                          T* __restrict__ out, int64_t nvec_per_img, int nvc, int C,
+                                                          int64_t total) {
+  constexpr int VEC = Elem<T>::kVec;
+  // consecutive threads -> consecutive 16-byte vectors; a thread's channel vector index is fixed when the grid stride
+  // is a multiple of nvc (it is: 256 * gridDim.x with nvc a power of two <= 256)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += stride * 4) {
+    Vec16<T> v[4], r[4];
+    int64_t idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      idx[k] = i0 + k * stride;
+      if (idx[k] < total) {
+        v[k] = vec_load(x + idx[k] * VEC);
+        if (residual) r[k] = vec_load(residual + idx[k] * VEC);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (idx[k] < total) {
+        const int b = (int)(idx[k] / nvec_per_img);
+        const int vc = (int)(idx[k] % nvc);
+        const float* a = A + (size_t)b * C + vc * VEC;
+        const float* bb = Bc + (size_t)b * C + vc * VEC;
+        Vec16<T> w;
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) {
+          float y = Elem<T>::silu(fmaf(Elem<T>::load(v[k].e[u]), a[u], bb[u]));
+          if (residual) y += Elem<T>::load(r[k].e[u]);
+          w.e[u] = Elem<T>::store(y);
+        }
+        vec_store(out + idx[k] * VEC, w);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_affine_silu(const T* x, const float* A, const float* Bc, const T* residual, T* out, int B, int HW, int C,
+                       hipStream_t s) {
+  constexpr int VEC = Elem<T>::kVec;
+  PRG_CHECK(C % VEC == 0, "affine_silu: C must be a multiple of the vector width");
+  const int nvc = C / VEC;
+  const int64_t per_img = (int64_t)HW * nvc, total = per_img * B;
+  int64_t blocks = (total + 1023) / 1024;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  affine_silu_kernel<T><<<(int)blocks, 256, 0, s>>>(x, A, Bc, residual, out, per_img, nvc, C, total);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_affine_silu<float>(const float*, const float*, const float*, const float*, float*, int, int, int,
+                                       hipStream_t);
+template int launch_affine_silu<bf16_t>(const bf16_t*, const float*, const float*, const bf16_t*, bf16_t*, int, int, int,
+                                        hipStream_t);
+
 // grid (B): GroupNorm (+ conditioning) folded to y = x * A[b][c] + Bc[b][c]
 __global__ __launch_bounds__(256) void gn_coeff_kernel(const float* __restrict__ partials, int nsplit, GnApply p,
                                                        float* __restrict__ A, float* __restrict__ Bc, int HW, int C,
@@ -329,7 +390,7 @@ template int launch_layernorm<bf16_t>(const bf16_t*, const float*, const bf16_t*
 // =============================================================================================
 constexpr int kLaMaxSplit = 128;
 static inline int la_nsplit(int N) {
-  int ns = ceil_div(N, 256);
+  int ns = ceil_div(N, 512);    // >= 512 pixels per slab: the fixed-order reduce of the slabs stays cheap
   if (ns > kLaMaxSplit) ns = kLaMaxSplit;
   return ns < 1 ? 1 : ns;
 }
@@ -349,50 +410,70 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// grid (ns, B): column max of k over a slab of pixels, merged with an order-independent atomic max
+// grid (slabs, B): column max of k.  16-byte loads: thread = (pixel lane 0..15, 8-channel vector 0..15), running max
+// over the slab in registers, LDS fold over the 16 pixel lanes, then ONE order-independent atomic max per channel.
 template <typename T>
 __global__ __launch_bounds__(256) void la_kmax_kernel(const T* __restrict__ qkv, float* __restrict__ kmax, int N,
                                                       int slab) {
-  __shared__ float sm[256];
-  const int b = blockIdx.y, c = threadIdx.x & 127, sub = threadIdx.x >> 7;
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int NV = 128 / VEC;              // vectors per pixel (bf16 16, f32 32)
+  constexpr int PL = 256 / NV;               // pixel lanes (16 / 8)
+  __shared__ float sm[PL][128];
+  const int b = blockIdx.y, vc = threadIdx.x % NV, pl = threadIdx.x / NV;
   const int p0 = blockIdx.x * slab, p1 = min(N, p0 + slab);
-  float m = -INFINITY;
-  const T* base = qkv + (size_t)b * N * 384 + 128 + c;
-  for (int n = p0 + sub; n < p1; n += 2) m = fmaxf(m, Elem<T>::load(base[(size_t)n * 384]));
-  sm[threadIdx.x] = m;
+  float m[VEC];
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) m[u] = -INFINITY;
+  const T* base = qkv + (size_t)b * N * 384 + 128 + vc * VEC;
+#pragma unroll 4
+  for (int n = p0 + pl; n < p1; n += PL) {
+    Vec16<T> v = vec_load(base + (size_t)n * 384);
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) m[u] = fmaxf(m[u], Elem<T>::load(v.e[u]));
+  }
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) sm[pl][vc * VEC + u] = m[u];
   __syncthreads();
-  if (sub == 0) {
-    m = fmaxf(m, sm[threadIdx.x + 128]);
-    if (m > -INFINITY) atomic_max_f32(kmax + (size_t)b * 128 + c, m);
+  if (threadIdx.x < 128) {
+    float r = sm[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < PL; ++k) r = fmaxf(r, sm[k][threadIdx.x]);
+    if (r > -INFINITY) atomic_max_f32(kmax + (size_t)b * 128 + threadIdx.x, r);
   }
 }
 
-// grid (ns, 4, B): partial context of one head over a slab: thread (d = tid/8, e0 = (tid%8)*4)
+// grid (ns, 4, B): partial context of one head over a slab: thread (d = tid/8, e0 = (tid%8)*4).
+// Staging with 16-byte loads: thread = (pixel 0..P-1, vector of the head's 32 channels).
 template <typename T>
 __global__ __launch_bounds__(256) void la_ctx_kernel(const T* __restrict__ qkv, const float* __restrict__ kmax,
                                                      float* __restrict__ ctxp, float* __restrict__ sump, int N,
                                                      int slab) {
-  constexpr int P = 64;
-  __shared__ __attribute__((aligned(16))) float ek[P][32];
-  __shared__ __attribute__((aligned(16))) float vv[P][32];
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int NV = 32 / VEC;               // vectors per (pixel, head): bf16 4, f32 8
+  constexpr int P = 256 / NV;                // pixels staged per iteration: 64 / 32
+  __shared__ __attribute__((aligned(16))) float ek[64][32];
+  __shared__ __attribute__((aligned(16))) float vv[64][32];
   const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z, ns = gridDim.x;
   const int tid = threadIdx.x, d = tid >> 3, e0 = (tid & 7) * 4;
   const int p0 = sp * slab, p1 = min(N, p0 + slab);
-  const float km = kmax[(size_t)b * 128 + h * 32 + (tid & 31)];  // for the staging role below: channel = tid % 32
-  float acc[4] = {0, 0, 0, 0}, ssum = 0.0f;
-  const T* base = qkv + (size_t)b * N * 384;
-  for (int t0 = p0; t0 < p1; t0 += P) {
-    // stage P pixels: thread loads channel (tid % 32) of pixels (tid / 32) + 8 i
+  const int sv = tid % NV, spx = tid / NV;   // staging role
+  float km[VEC];
 #pragma unroll
-    for (int i = 0; i < P / 8; ++i) {
-      const int pp = (tid >> 5) + i * 8, n = t0 + pp, ch = tid & 31;
-      float kvv = 0.0f, vvv = 0.0f;
-      if (n < p1) {
-        kvv = expf(Elem<T>::load(base[(size_t)n * 384 + 128 + h * 32 + ch]) - km);
-        vvv = Elem<T>::load(base[(size_t)n * 384 + 256 + h * 32 + ch]);
-      }
-      ek[pp][ch] = kvv;
-      vv[pp][ch] = vvv;
+  for (int u = 0; u < VEC; ++u) km[u] = kmax[(size_t)b * 128 + h * 32 + sv * VEC + u];
+  float acc[4] = {0, 0, 0, 0}, ssum = 0.0f;
+  const T* base = qkv + (size_t)b * N * 384 + h * 32 + sv * VEC;
+  for (int t0 = p0; t0 < p1; t0 += P) {
+    const int n = t0 + spx;
+    Vec16<T> kvec = vec_zero<T>(), vvec = vec_zero<T>();
+    const bool ok = n < p1;
+    if (ok) {
+      kvec = vec_load(base + (size_t)n * 384 + 128);
+      vvec = vec_load(base + (size_t)n * 384 + 256);
+    }
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      ek[spx][sv * VEC + u] = ok ? expf(Elem<T>::load(kvec.e[u]) - km[u]) : 0.0f;
+      vv[spx][sv * VEC + u] = Elem<T>::load(vvec.e[u]);
     }
     __syncthreads();
 #pragma unroll 8
@@ -498,7 +579,10 @@ int launch_linear_attention(const T* qkv, T* out, float* ws, int B, int N, hipSt
   fill_u32_kernel<<<ceil_div(B * 128, 256), 256, 0, s>>>(reinterpret_cast<uint32_t*>(kmax), 0xFF800000u,
                                                         (size_t)B * 128);
   PRG_LAUNCH_CHECK();
-  la_kmax_kernel<T><<<dim3(ns, B), 256, 0, s>>>(qkv, kmax, N, slab);
+  {
+    const int kslab = 128, kns = ceil_div(N, kslab);   // fine slabs: the merge is an atomic max, no reduce pass
+    la_kmax_kernel<T><<<dim3(kns, B), 256, 0, s>>>(qkv, kmax, N, kslab);
+  }
   PRG_LAUNCH_CHECK();
   la_ctx_kernel<T><<<dim3(ns, 4, B), 256, 0, s>>>(qkv, kmax, ctxp, sump, N, slab);
   PRG_LAUNCH_CHECK();

@@ -49,6 +49,12 @@ __host__ __device__ inline float bf16_to_f32(bf16_t b) {
 }
 
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // gfx950 has a native round-to-nearest-even conversion (v_cvt_pk_bf16_f32)
+  bf16_t r;
+  r.v = __builtin_bit_cast(uint16_t, (__bf16)f);
+  return r;
+#else
   union {
     uint32_t u;
     float f;
@@ -63,6 +69,7 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   x.u += 0x7fffu + lsb;
   r.v = (uint16_t)(x.u >> 16);
   return r;
+#endif
 }
 
 template <typename T>

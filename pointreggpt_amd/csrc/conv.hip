@@ -545,6 +545,10 @@ static int launch_igemm(const ConvLaunch<T>& L, int M, hipStream_t s, int want_s
   return PRG_OK;
 }
 
+int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_ws.hip
+static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n) { return try_launch_conv3x3_ws(L, s, n); }
+static inline int try_ws(const ConvLaunch<float>&, hipStream_t, int*) { return 0; }
+
 template <typename T>
 int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out) {
   const ConvDesc& d = L.d;
@@ -558,6 +562,11 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out) {
   const int M = (int)M64;
   const int want_stats = L.gn_partials != nullptr;
   if (gn_nsplit_out) *gn_nsplit_out = 0;
+  {
+    const int r = try_ws(L, s, gn_nsplit_out);   // wave-specialised persistent kernel (bf16 throughput path)
+    if (r < 0) return r;
+    if (r == 1) return PRG_OK;
+  }
   HaloPick<T> hp;
   if (pick_halo<T>(d, &hp)) {
     const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;

@@ -343,9 +343,11 @@ struct UnetImpl : prg_unet {
     } else {
       PRG_CHECK(C1 == 0 && C0 == r.cout, "resblock: identity skip needs equal widths");
     }
-    if (!arena.dry &&
-        (rc = launch_gn_apply<T>(out, part2, ns2, gn_params(r.g2, r.b2, nullptr, 0), skip, out, B, HW, r.cout, G, s)))
-      return rc;
+    if (!arena.dry) {
+      // GroupNorm + SiLU + skip: fold the statistics into per-(image, channel) coefficients, then one flat pass
+      if ((rc = launch_gn_coeff(part2, ns2, gn_params(r.g2, r.b2, nullptr, 0), coefA, coefB, B, HW, r.cout, G, s))) return rc;
+      if ((rc = launch_affine_silu<T>(out, coefA, coefB, skip, out, B, HW, r.cout, s))) return rc;
+    }
     arena.reset(m);
     return PRG_OK;
   }

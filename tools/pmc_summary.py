@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in rows:
-    n = r["Kernel_Name"].replace("void prg::", "").replace("prg::", "").split("(")[0][:52]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void prg::", "").replace("prg::", "").split("(")[0][:52]
     key = (n, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) if "Grid_Size" in r else 0)
     agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
     cnt[(key, r["Counter_Name"])] += 1

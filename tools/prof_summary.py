@@ -8,7 +8,7 @@ nfw = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 per = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    short = n.replace("void prg::", "").replace("prg::", "")
+    short = n.replace("(anonymous namespace)::", "").replace("void prg::", "").replace("prg::", "")
     short = short.split("(")[0][:60]
     key = (short, int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
     per[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
