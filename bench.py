@@ -196,10 +196,18 @@ def main():
         torch.cuda.synchronize()
         pr = pdiff.last_profile(B)
         ach = pr["conv_flops"] / (pr["conv_ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
+        if os.path.exists(tpath) and B == 64 and S == 128 and a.dtype == "bf16":
+            # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same workload (bench.py cannot
+            # run the profiler on itself); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_conv_hbm_traffic.json"
         res["roofline"] = {
-            "kernel": "conv_igemm_kernel (implicit-GEMM conv, MFMA)", "bound": "mfma", "achieved": ach,
+            "kernel": "MFMA convolutions: conv3x3_ws_kernel (3x3, wave-specialised persistent) + conv_igemm_kernel (1x1 / 4x4s2)",
+            "bound": "mfma", "achieved": ach,
             "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype],
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE*2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "launches": pr["conv_launches"], "avg_launch_us": pr["conv_ms"] * 1e3 / max(1, pr["conv_launches"]),
             "flop_per_launch": pr["conv_flops"] / max(1, pr["conv_launches"]),
             "share_of_step_time": pr["conv_ms"] / pr["total_ms"],

@@ -5,6 +5,7 @@
 // the skip `torch.cat` never materialises (two source pointers into the conv), `nn.Upsample` is folded into the
 // following conv's gather, weight standardisation is folded into the packed weights at load time.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -325,12 +326,15 @@ struct UnetImpl : prg_unet {
     const GnApply g1 = gn_params(r.g1, r.b1, c1, r.ss_off);
     ConvOpt o2;
     o2.gn_partials = part2; o2.gn_nsplit = &ns2;
-    const bool fuse_pro = conv_supports_prologue<T>(make_desc(r.c2, r.cout, 0, B, H, Wd, 1, 1, 0));
+    // PRG_FUSE_PRO: -1 (default) fuse wherever the conv supports it; 0 never; N > 0 only for widths >= N
+    static const int fuse_min = [] { const char* e = std::getenv("PRG_FUSE_PRO"); return e ? std::atoi(e) : -1; }();
+    const bool fuse_pro = conv_supports_prologue<T>(make_desc(r.c2, r.cout, 0, B, H, Wd, 1, 1, 0)) &&
+                          (fuse_min < 0 || (fuse_min > 0 && r.cout >= fuse_min));
     if (!arena.dry) {
+      if ((rc = launch_gn_coeff(part1, ns1, g1, coefA, coefB, B, HW, r.cout, G, s))) return rc;
       if (fuse_pro) {
-        if ((rc = launch_gn_coeff(part1, ns1, g1, coefA, coefB, B, HW, r.cout, G, s))) return rc;
         o2.pro_a = coefA; o2.pro_b = coefB;
-      } else if ((rc = launch_gn_apply<T>(h1, part1, ns1, g1, nullptr, h1, B, HW, r.cout, G, s))) {
+      } else if ((rc = launch_affine_silu<T>(h1, coefA, coefB, nullptr, h1, B, HW, r.cout, s))) {
         return rc;
       }
     }
