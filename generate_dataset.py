@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""generate_dataset.py — same command line and output layout as the reference script (generate_dataset.py:1-62):
+
+    python generate_dataset.py --resume=official [--dataset_name generated_dataset] [-start 0] [-stop 1] [--num_samples 1]
+
+writes ./<dataset_name>/data/scene-XXXXXX/{sample-000000.cloud.ply, sample-000001.cloud.ply, camera-intrinsics.txt,
+sample-*.pose.txt, *.png}.  The hot path runs on the MI355X HIP library.  Additive flags (defaults = the reference's
+hard-coded literals, generate_dataset.py:32-55):
+  --image_size 256  --timesteps 1000  --sampling_timesteps 250  --batch_size 4  --dim 64  --dtype bf16
+  --data_root /path/to/3DMatch-RGBD/train
+  --synthetic SEED    synthetic scenes instead of 3DMatch frames (no dataset needed)
+  --resume synthetic[:SEED]   deterministic synthetic weights instead of ./successive_ddnm_diffusion_results/model-<resume>.pt
+Under `torchrun --nproc-per-node N` every rank takes a contiguous block of [-start, -stop) (no collectives).
+"""
+import argparse
+import os
+
+import torch
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--resume", default=None, type=str, help="checkpoint to load", required=True)
+    p.add_argument("--dataset_name", default="generated_dataset", type=str, help="")
+    p.add_argument("--start_scene_index", "-start", default=0, type=int, help="scenes index to start")
+    p.add_argument("--stop_scene_index", "-stop", default=1, type=int, help="scenes index to stop")
+    p.add_argument("--num_samples", default=1, type=int, help="sample numbers for each scene")
+    p.add_argument("--image_size", default=256, type=int)
+    p.add_argument("--timesteps", default=1000, type=int)
+    p.add_argument("--sampling_timesteps", default=250, type=int)
+    p.add_argument("--batch_size", default=4, type=int)
+    p.add_argument("--dim", default=64, type=int)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--data_root", default="/path/to/3DMatch-RGBD/train", type=str)
+    p.add_argument("--synthetic", default=None, type=int, help="seed of the synthetic scene generator")
+    p.add_argument("--mask_threshold", default=0.99, type=float)
+    args = p.parse_args()
+
+    from pointreggpt_amd import sharding
+    from pointreggpt_amd.diffusion import GaussianDiffusion
+    from pointreggpt_amd.generator import Generator
+    from pointreggpt_amd.unet import MaskUnet, Unet
+    from pointreggpt_amd.weights import maskunet_state_from_checkpoint
+
+    rank, world, local = sharding.rank_world()
+    torch.cuda.set_device(local)
+    start, stop = sharding.shard_range(args.start_scene_index, args.stop_scene_index, rank, world, args.batch_size)
+
+    model = Unet(dim=args.dim, param_cond_dim=4, dim_mults=(1, 2, 4, 8), channels=1, dtype=args.dtype)
+    depth_correction = MaskUnet(dim=args.dim, dim_mults=(1, 2, 4, 8), dtype=args.dtype)
+    diffusion = GaussianDiffusion(model, image_size=args.image_size, timesteps=args.timesteps,
+                                  sampling_timesteps=args.sampling_timesteps, loss_type="l1", objective="pred_x0",
+                                  beta_schedule="sigmoid", ddim_sampling_eta=1.0, is_ddnm_sampling=True)
+    generator = Generator(diffusion, args.data_root, batch_size=args.batch_size,
+                          results_folder="./successive_ddnm_diffusion_results",
+                          samples_folder="./{}/data".format(args.dataset_name), synthetic_seed=args.synthetic)
+    if args.resume.startswith("synthetic"):
+        seed = int(args.resume.split(":")[1]) if ":" in args.resume else 0
+        model.init_synthetic(seed)
+        depth_correction.init_synthetic(seed + 1, final_bias=8.0)
+    else:
+        generator.load(args.resume)
+        ckpt = torch.load("./depth_correction_results/model-best.pt", map_location="cpu")
+        depth_correction.load_state_dict(maskunet_state_from_checkpoint(ckpt, depth_correction.cfg))
+    if stop > start:
+        generator.generate(start_scene_index=start, stop_scene_index=stop, num_samples=args.num_samples,
+                           has_refine_step=False, depth_correction=depth_correction,
+                           mask_threshold=args.mask_threshold)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

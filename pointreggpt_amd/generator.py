@@ -1,0 +1,214 @@
+"""`Generator.generate` (sd:2250-2694) on the HIP hot path: same sequence, same on-disk layout, batched geometry.
+
+Per batch of scenes: source depth frame -> scene "memory" cloud (crop box) -> sample-000000.cloud.ply; for each sample:
+random pose -> z-buffer reprojection of the memory clouds (ONE launch for the ragged batch) -> depth correction ->
+DDNM condition -> diffusion sampler -> depth correction -> float64 unprojection into the common frame -> fragment
+-> crop / voxel / sample-000001.cloud.ply, plus the pose / intrinsic / png side files the reference writes.
+
+Input side: `--synthetic` scenes (pointreggpt_amd.synthetic; what tests and benchmarks use — neither box has 3DMatch)
+or the reference's real-data layout (train_info.pkl + `<cloud>.info.txt` + 3DMatch RGB-D frames, sd:2352-2459).
+The real-data decode path mirrors torchvision Resize(NEAREST)/CenterCrop/ToTensor with PIL and is parity-unpinned.
+
+Sharding: scenes are independent; under torchrun every rank takes a contiguous block of the requested range
+(pointreggpt_amd.sharding) — the reference leaves this to manual -start/-stop.
+sd = /root/reference/denoising_diffusion_pytorch/successive_ddnm_diffusion.py
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import shutil
+from pathlib import Path
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import geometry as G
+from . import postprocess as PP
+from . import synthetic
+from .sharding import num_to_groups
+
+PAIRS_PER_LAP = 20642   # real pairs per lap of the scene index; src/tgt swap on odd laps (sd:2397-2410)
+
+
+class Generator:
+    def __init__(self, diffusion_model, folder: Optional[str], *, batch_size=16, samples_folder="./samples",
+                 results_folder="./results", synthetic_seed: Optional[int] = None, device="cuda", **_ignored):
+        self.model = diffusion_model                  # pointreggpt_amd.diffusion.GaussianDiffusion
+        self.folder = folder
+        self.batch_size = int(batch_size)
+        self.image_size = diffusion_model.image_size
+        self.samples_folder = Path(samples_folder)
+        self.samples_folder.mkdir(parents=True, exist_ok=True)
+        self.results_folder = Path(results_folder)
+        self.synthetic_seed = synthetic_seed
+        self.device = torch.device(device)
+
+    # -- weights (sd:2307-2324): the generator samples from the EMA copy ------------------------------------------
+    def load(self, milestone, unet=None):
+        from .weights import unet_state_from_checkpoint
+        data = torch.load(str(self.results_folder / f"model-{milestone}.pt"), map_location="cpu")
+        net = unet if unet is not None else self.model.model
+        net.load_state_dict(unet_state_from_checkpoint(data, net.cfg))
+
+    # -- input side ------------------------------------------------------------------------------------------------
+    def _real_scene(self, abs_idx: int, info_train, scene_dir: Path):
+        """Source frame of scene `abs_idx` from the 3DMatch layout (sd:2397-2459).  Returns depth (S,S) f32 in
+        10 m units and K (3,3) f32."""
+        from PIL import Image
+        S = self.image_size
+        lap_odd = (abs_idx // PAIRS_PER_LAP) % 2 == 1
+        rel = info_train["tgt" if lap_odd else "src"][abs_idx % PAIRS_PER_LAP]
+        info_path = os.path.join("./dataset/indoor/data", rel).replace(".pth", ".info.txt")
+        with open(info_path) as f:
+            scene_name, seq_name, f0, _f1 = f.readline().rstrip("\n").split()
+        root = os.path.join(self.folder, scene_name)
+        K = G.intrinsic_transform(np.loadtxt(os.path.join(root, "camera-intrinsics.txt")), resize=S,
+                                  centercrop=S).astype(np.float32)
+        img = Image.open(os.path.join(root, seq_name, "frame-{:0>6d}.depth.png".format(int(f0))))
+        w, h = img.size                                   # Resize(S): short side -> S (sd:2356-2361)
+        if w <= h:
+            nw, nh = S, int(S * h / w)
+        else:
+            nw, nh = int(S * w / h), S
+        img = img.resize((nw, nh), Image.NEAREST)
+        left, top = int(round((nw - S) / 2.0)), int(round((nh - S) / 2.0))
+        img = img.crop((left, top, left + S, top + S))
+        depth = np.asarray(img).astype(np.float32) * np.float32(1e-4)      # uint16 mm -> 10 m units
+        depth[depth > 1] = 0
+        return depth, K
+
+    def _scene_inputs(self, abs_idx: int, info_train, scene_dir: Path):
+        if self.synthetic_seed is not None:
+            depth, K, _pose = synthetic.synth_scene(self.synthetic_seed, abs_idx, self.image_size)
+            return depth, K
+        return self._real_scene(abs_idx, info_train, scene_dir)
+
+    def _poses(self, idxs: List[int], sample_idx: int) -> np.ndarray:
+        if self.synthetic_seed is None:
+            return G.random_sample_pose(len(idxs)).astype(np.float32)      # numpy legacy stream, as the reference
+        out = []
+        for i in idxs:                                                      # shard-invariant per-scene stream
+            rng = synthetic.scene_rng(self.synthetic_seed, i)
+            rng.random(4096 + 64 * sample_idx)                              # decorrelate from the depth draw
+            out.append(synthetic.synth_pose(rng))
+        return np.stack(out)
+
+    # -- the pipeline ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, start_scene_index, stop_scene_index, num_samples, memory_voxel_size=0.002,
+                 save_voxel_size=0.025, has_refine_step=False, depth_correction=None, mask_threshold=0.99,
+                 noise_seed: int = 0, progress: bool = False):
+        if has_refine_step:
+            raise NotImplementedError("has_refine_step=True is not on the generator CLI's path (generate_dataset.py:62)")
+        S, dev = self.image_size, self.device
+        info_train = None
+        if self.synthetic_seed is None:
+            with open("./dataset/indoor/metadata/train_info.pkl", "rb") as f:
+                info_train = pickle.load(f)
+        num_scenes = stop_scene_index - start_scene_index
+        first = start_scene_index
+        for batch in num_to_groups(num_scenes, self.batch_size):
+            idxs = list(range(first, first + batch))
+            first += batch
+            # resume: skip a batch whose last scene already has its generated cloud (sd:2371-2381)
+            done = self.samples_folder / "scene-{:0>6d}/sample-{:0>6d}.cloud.ply".format(idxs[-1], num_samples // 2)
+            if done.is_file():
+                print("Skip completed scene {:0>6d} - {:0>6d}.".format(idxs[0], idxs[-1]))
+                continue
+            K = np.zeros((batch, 3, 3), dtype=np.float32)
+            memory: List[np.ndarray] = []
+            for j, idx in enumerate(idxs):
+                sdir = self.samples_folder / "scene-{:0>6d}".format(idx)
+                if sdir.exists():
+                    shutil.rmtree(str(sdir), ignore_errors=True)
+                sdir.mkdir(parents=True, exist_ok=True)
+                depth, K[j] = self._scene_inputs(idx, info_train, sdir)
+                np.savetxt(str(sdir / "camera-intrinsics.txt"), K[j])
+                PP.save_image01(depth, str(sdir / "sample-{:0>6d}.image.png".format(0)))
+                d_dev = torch.from_numpy(depth[None, None]).to(dev)
+                frame = G.point_clouds(d_dev, torch.from_numpy(K[j][None]).to(dev), None)[0].astype(np.float32)
+                scene_pc = PP.crop_aabb(frame).astype(np.float32)           # the scene "memory" (sd:2484-2490)
+                memory.append(scene_pc)
+                PP.write_ply(str(sdir / "sample-{:0>6d}.cloud.ply".format(0)), PP.voxel_down_sample(scene_pc, save_voxel_size))
+            K_dev = torch.from_numpy(K).to(dev)
+            param_cond = G.param_vector(K_dev)
+            fragments: List[np.ndarray] = [None] * batch
+            poses0 = None
+            for sample_idx in range(num_samples):
+                pose = self._poses(idxs, sample_idx)
+                if sample_idx == 0:
+                    poses0 = pose
+                pose_dev = torch.from_numpy(pose).to(dev)
+                rpj, hit = G.project_clouds(memory, pose, K, S, dev, depth_scale=0.1)
+                rpj_host = rpj.cpu().numpy()
+                prob = depth_correction(rpj)
+                rpj_c, hit_c, cond = G.apply_mask(prob, rpj, hit, mask_threshold)
+                seeds = [synthetic.noise_seed(noise_seed, i * 4096 + sample_idx) for i in idxs]
+                images = self.model.sample(param_cond=param_cond, img_cond=cond, seeds=seeds)
+                prob2 = depth_correction(images)
+                images, _, _ = G.apply_mask(prob2, images, None, mask_threshold, want_cond=False)
+                clouds = G.point_clouds(images, K_dev, pose_dev)            # common frame, float64 (sd:2623-2628)
+                img_host, crt_host = images.cpu().numpy(), rpj_c.cpu().numpy()
+                for j, idx in enumerate(idxs):
+                    sdir = self.samples_folder / "scene-{:0>6d}".format(idx)
+                    PP.save_image01(rpj_host[j], str(sdir / "reprojected.image.png"))
+                    np.savetxt(str(sdir / "sample-{:0>6d}.pose.txt".format(sample_idx + 1)), np.linalg.inv(pose[j]))
+                    PP.save_image01(crt_host[j], str(sdir / "corrected.image.png"))
+                    PP.save_image01(img_host[j], str(sdir / "sample-{:0>6d}.image.png".format(sample_idx + 1)))
+                    PP.save_depth16(img_host[j], str(sdir / "sample-{:0>6d}.depth.png".format(sample_idx + 1)))
+                    pc = clouds[j]
+                    fragments[j] = pc if sample_idx == 0 else np.concatenate([fragments[j], pc], axis=0)
+                    if sample_idx == num_samples - 1:                       # sd:2640-2658
+                        frag = PP.transform(fragments[j], poses0[j])
+                        frag = PP.voxel_down_sample(PP.crop_aabb(frag), save_voxel_size)
+                        frag = PP.transform(frag, np.linalg.inv(poses0[j]))
+                        PP.write_ply(str(sdir / "sample-{:0>6d}.cloud.ply".format(1)), frag)
+                    if sample_idx < num_samples - 1:                        # memory update (sd:2661-2680)
+                        merged = np.concatenate([memory[j], pc], axis=0)
+                        memory[j] = PP.voxel_down_sample(merged, memory_voxel_size).astype(np.float32)
+                if progress:
+                    print("batch {:0>6d}-{:0>6d}: sample {}/{}".format(idxs[0], idxs[-1], sample_idx + 1, num_samples))
+
+
+def generate_gt(dataset_name: str, start_scene_index: int, stop_scene_index: int, num_samples: int,
+                root: str = ".") -> None:
+    """generate_gt.py:105-175 — per scene, every pair of .cloud.ply -> overlap ratios -> scene gt.log."""
+    from itertools import combinations
+    data = Path(root) / dataset_name / "data"
+    for scene_idx in range(start_scene_index, stop_scene_index):
+        scene_name = "scene-{:0>6d}".format(scene_idx)
+        sdir = data / scene_name
+        gt_path = sdir / "gt.log"
+        if gt_path.exists():
+            print("scene gt log has existed, skip over it")
+            continue
+        lines = []
+        for s, t in combinations(range(num_samples), 2):
+            ps, pt = sdir / "sample-{:0>6d}.cloud.ply".format(s), sdir / "sample-{:0>6d}.cloud.ply".format(t)
+            if not ps.exists() or not pt.exists():
+                continue
+            src, tgt = PP.read_ply(str(ps)), PP.read_ply(str(pt))
+            if len(src) < 1000 or len(tgt) < 1000:
+                continue
+            o_s, o_t = PP.compute_overlap_ratio(src, tgt)
+            if np.isnan(o_s) or np.isnan(o_t) or (o_s < 0.1 and o_t < 0.1):
+                continue
+            lines.append("{}\t{}\t{}\t{:.4f}\t{:.4f}\n".format(scene_name, s, t, o_s, o_t))
+        gt_path.parent.mkdir(exist_ok=True)
+        with open(gt_path, "w") as f:
+            f.writelines(lines)
+
+
+def gather_gt(dataset_name: str, start_index: int, stop_index: int, root: str = ".") -> None:
+    """generate_gt.py:177-188 — concatenate the scene logs in index order into metadata/gt.log (replacing it)."""
+    final = Path(root) / dataset_name / "metadata" / "gt.log"
+    final.parent.mkdir(parents=True, exist_ok=True)
+    if final.exists():
+        os.remove(str(final))
+    with open(final, "ab") as out:
+        for scene_idx in range(start_index, stop_index):
+            p = Path(root) / dataset_name / "data" / "scene-{:0>6d}".format(scene_idx) / "gt.log"
+            if p.exists():
+                out.write(p.read_bytes())

@@ -295,3 +295,52 @@ def test_end_to_end_pair_64(hip, golden):
         linf = float(np.abs(cloud - g["cloud"]).max())
         print(f"point-XYZ L-infinity vs reference: {linf:.3e} m")
         assert linf <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CLI: generate_dataset.py + generate_gt.py keep the reference's command line and on-disk layout
+# ------------------------------------------------------------------------------------------------------------------
+def test_cli_generates_dataset_and_gt(tmp_path):
+    import os
+    import subprocess
+    import sys
+    from oracle import geometry as OG
+    from pointreggpt_amd import postprocess as PP, synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    common = ["--dataset_name", "ds", "-start", "2", "-stop", "5"]
+    cmd = [sys.executable, os.path.join(root, "generate_dataset.py"), "--resume", "synthetic:3", "--synthetic", "7",
+           "--image_size", "64", "--sampling_timesteps", "4", "--batch_size", "2", "--dim", "16", "--dtype", "fp32",
+           "--mask_threshold", "0.5"] + common
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    for idx in (2, 3, 4):
+        d = tmp_path / "ds" / "data" / "scene-{:0>6d}".format(idx)
+        for name in ("sample-000000.cloud.ply", "sample-000001.cloud.ply", "camera-intrinsics.txt", "sample-000001.pose.txt",
+                     "sample-000000.image.png", "sample-000001.image.png", "sample-000001.depth.png",
+                     "reprojected.image.png", "corrected.image.png"):
+            assert (d / name).is_file(), name
+        # sample 0 is the real (here: synthetic) frame: unproject -> crop box -> 0.025 voxel grid (sd:2479-2500)
+        depth, K, _ = synthetic.synth_scene(7, idx, 64)
+        assert np.allclose(np.loadtxt(d / "camera-intrinsics.txt"), K)
+        ref = PP.voxel_down_sample(PP.crop_aabb(OG.point_cloud(depth * 10, K, (0.5, 10)).astype(np.float32)), 0.025)
+        got = PP.read_ply(str(d / "sample-000000.cloud.ply"))
+        assert got.shape == ref.shape and np.allclose(got, ref, atol=1e-12)
+        gen = PP.read_ply(str(d / "sample-000001.cloud.ply"))
+        assert len(gen) > 500 and np.isfinite(gen).all()
+        pose_inv = np.loadtxt(d / "sample-000001.pose.txt")
+        assert pose_inv.shape == (4, 4) and abs(np.linalg.det(pose_inv[:3, :3]) - 1) < 1e-5
+        from PIL import Image
+        d16 = np.asarray(Image.open(d / "sample-000001.depth.png"))
+        assert d16.dtype == np.uint16 and d16.shape == (64, 64) and d16.max() <= 10000
+    # resume: a second run skips finished batches (sd:2371-2381)
+    out2 = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0 and "Skip completed scene" in out2.stdout
+    gt = subprocess.run([sys.executable, os.path.join(root, "generate_gt.py"), "--disable_tqdm"] + common, cwd=tmp_path,
+                        env=env, capture_output=True, text=True, timeout=600)
+    assert gt.returncode == 0, gt.stderr[-2000:]
+    lines = open(tmp_path / "ds" / "metadata" / "gt.log").read().splitlines()
+    assert 1 <= len(lines) <= 3
+    for line in lines:
+        name, s, t, o1, o2 = line.split("\t")
+        assert name.startswith("scene-") and (int(s), int(t)) == (0, 1) and 0 <= float(o1) <= 1 and 0 <= float(o2) <= 1
