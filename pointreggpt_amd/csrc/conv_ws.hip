@@ -22,7 +22,9 @@
 //
 // Covers every 3x3 / stride 1 / pad 1 conv of the U-Nets at dim = 64 (widths multiples of 64): Block.proj, the last
 // down/up convs, Upsample's conv (x2 nearest gather folded into the halo load), skip concat as two sources.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "conv.h"
 
@@ -47,9 +49,24 @@ __device__ inline uint32_t pack_bf16(float a, float b) {
 // waits vmcnt(0), which would drain the producers' in-flight global prefetches at every phase and expose the full
 // memory latency nine times per step.  Global loads stay in flight across it; hipcc still inserts the counted
 // vmcnt before the first use of each loaded register.
-__device__ __forceinline__ void phase_barrier() {
+// Optional barrier trace (PRG_WS_TRACE=<launch index>): workgroup 0 records, per wave, the shader clock when it
+// arrives at and when it leaves every phase barrier of that launch.  Shows which role the others wait for.
+constexpr int kTraceStride = 4096;   // u64 slots per wave: [0] = count, then (arrive, leave) pairs
+
+__device__ __forceinline__ void phase_barrier(unsigned long long* tr) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const bool rec = tr != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
+  unsigned long long n = 0;
+  if (rec) {
+    tr += (threadIdx.x >> 6) * kTraceStride;
+    n = tr[0];
+    if (n < (kTraceStride - 2) / 2) tr[1 + 2 * n] = clock64();
+  }
   __builtin_amdgcn_s_barrier();
+  if (rec && n < (kTraceStride - 2) / 2) {
+    tr[2 + 2 * n] = clock64();
+    tr[0] = n + 1;
+  }
   asm volatile("" ::: "memory");
 }
 
@@ -148,6 +165,7 @@ struct ProdBase {
   char* St;
   const TileMap& tm;
   int lane, tiles_x, tiles_y, nsteps, nchunks, fuse_stats, dbg;
+  unsigned long long* trace = nullptr;
 
   __device__ __forceinline__ ProdBase(const ConvLaunch<bf16_t>& L_, char* smem, int lane_, const TileMap& tm_,
                                       int nsteps_, int nchunks_, int fuse, int dbg_)
@@ -160,44 +178,66 @@ struct ProdBase {
   __device__ __forceinline__ void decode(int it, int& b, int& y0, int& x0, int& tn) const { tm.decode(it, b, y0, x0, tn); }
 };
 
-// ---- wave 4 -----------------------------------------------------------------------------------------
+// ---- weight wave(s) ----------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
 template <int TH, int TW, int BN>
 struct WeightWave : ProdBase<TH, TW, BN> {
   using Base = ProdBase<TH, TW, BN>;
   using G = typename Base::G;
-  using Base::L; using Base::d; using Base::Bw0; using Base::St; using Base::lane; using Base::nsteps;
-  using Base::nchunks; using Base::fuse_stats; using Base::dbg; using Base::tiles_x; using Base::tiles_y;
+  using Base::L; using Base::d; using Base::Bw0; using Base::lane; using Base::nsteps; using Base::nchunks;
+  using Base::dbg; using Base::trace;
   static constexpr int NW = 8;              // weight units per lane per tap: each weight wave stages 64 rows
-  static constexpr int UPP = BN / 8;        // stage units per pixel (8 or 16)
-  uint4 wset[3][NW];
-  float gs, gq;
-  int slot, wrow, ecc, widx;
+  // The loads are inline asm on purpose: hipcc's own waitcnt bookkeeping falls back to vmcnt(0) at every merge of
+  // this unrolled, branchy stream, which drains the two younger tiles on every phase and exposes the full L2
+  // latency nine times per step.  Hidden from the compiler, this wave's ONLY vector-memory traffic is 8 loads per
+  // phase, so a hand-counted `s_waitcnt vmcnt(16)` (two younger tiles may stay in flight) is exact.
+  u32x4 wset[3][NW];
+  const bf16_t* wb;
+  int slot, wrow, widx;
 
   __device__ __forceinline__ WeightWave(const ConvLaunch<bf16_t>& L_, char* smem, int lane_, int widx_, const TileMap& tm_,
                                         int nsteps_, int nchunks_, int fuse, int dbg_)
       : Base(L_, smem, lane_, tm_, nsteps_, nchunks_, fuse, dbg_), widx(widx_) {
     slot = lane & 7;
     wrow = widx * 64 + (lane >> 3);   // this wave stages weight rows [64 widx, 64 widx + 64)
-    ecc = lane % UPP;
-    gs = gq = 0.0f;
+    wb = L.w + ((size_t)(slot >> 2) * d.CoutPad + wrow) * 32 + (slot & 3) * 8;
   }
 
+  // weight tile of (tap, chunk, tn): `wb` = L.w + this lane's (row, unit) offset, hoisted out of the phase path
   template <int SET>
-  __device__ __forceinline__ void w_issue(int phx) {
-    int step = phx / 9;
-    const int tap = phx - step * 9;
+  __device__ __forceinline__ void w_issue_at(int tap, int chunk, int tn) {
+    const bf16_t* base = wb + ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tn * BN) * 32;
+    // rows wrow + 8 j are 8 * 32 * 2 = 512 bytes apart: one base address, immediate offsets
+#define PRG_WLOAD(J) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(wset[SET][J]) : "v"(base), "i"((J) * 512) : "memory")
+    PRG_WLOAD(0); PRG_WLOAD(1); PRG_WLOAD(2); PRG_WLOAD(3); PRG_WLOAD(4); PRG_WLOAD(5); PRG_WLOAD(6); PRG_WLOAD(7);
+#undef PRG_WLOAD
+  }
+  __device__ __forceinline__ int tn_of_step(int step) const {
     if (step >= nsteps) step = nsteps - 1;       // past the end: harmless reload
     int b, y0, x0, tn;
     this->decode(step / nchunks, b, y0, x0, tn);
-    const int chunk = step % nchunks;
-    const bf16_t* base = L.w + ((size_t)(tap * d.kchunks + 2 * chunk + (slot >> 2)) * d.CoutPad + tn * BN) * 32 +
-                         (slot & 3) * 8;
-#pragma unroll
-    for (int j = 0; j < NW; ++j) wset[SET][j] = *reinterpret_cast<const uint4*>(base + (size_t)(wrow + j * 8) * 32);
+    return tn;
+  }
+  template <int SET>
+  __device__ __forceinline__ void w_issue(int phx) {   // general form (prologue only)
+    int step = phx / 9;
+    const int tap = phx - step * 9;
+    if (step >= nsteps) step = nsteps - 1;
+    w_issue_at<SET>(tap, step % nchunks, tn_of_step(step));
+  }
+  // N = loads that may remain outstanding (younger tiles): 16 in steady state, 0 in the prologue
+  template <int SET, int N>
+  __device__ __forceinline__ void w_wait() {
+    asm volatile("s_waitcnt vmcnt(%[n])"
+                 : "+v"(wset[SET][0]), "+v"(wset[SET][1]), "+v"(wset[SET][2]), "+v"(wset[SET][3]), "+v"(wset[SET][4]),
+                   "+v"(wset[SET][5]), "+v"(wset[SET][6]), "+v"(wset[SET][7])
+                 : [n] "i"(N)
+                 : "memory");
   }
   template <int SET>
   __device__ __forceinline__ void w_write(int phx) {
-    uint4* Bw = Bw0 + (phx % 3) * BN * 8;
+    u32x4* Bw = reinterpret_cast<u32x4*>(Bw0 + (phx % 3) * BN * 8);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int n = wrow + j * 8;
@@ -205,102 +245,42 @@ struct WeightWave : ProdBase<TH, TW, BN> {
     }
   }
 
-  __device__ __forceinline__ void drain_slice(int it_prev, int p8) {
-    int b, y0, x0, tn;
-    this->decode(it_prev, b, y0, x0, tn);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int px = (p8 * 256 + j * 64 + lane) / UPP;
-      const int k = px & 15;
-      const int slot8 = ((2 * ecc) ^ k) & ~1;
-      uint4 v = *reinterpret_cast<const uint4*>(St + (size_t)px * (BN * 2) + slot8 * 8);
-      if (k & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float lo = bf_lo(w[q]), hi2 = bf_hi(w[q]);
-        gs += lo + hi2;
-        gq = fmaf(lo, lo, gq);
-        gq = fmaf(hi2, hi2, gq);
-      }
-      const int64_t m = ((int64_t)b * d.Hout + y0 + px / TW) * d.Wout + x0 + px % TW;
-      *reinterpret_cast<uint4*>(L.out + m * d.Cout + tn * BN + ecc * 8) = v;
-    }
-  }
-  __device__ __forceinline__ void stats_flush(int it_prev) {
-    // lanes with equal (lane % UPP) hold the same 8-channel chunk: fold, then lanes 0..UPP-1 own chunk totals
-#pragma unroll
-    for (int o = UPP; o < 64; o <<= 1) {
-      gs += __shfl_xor(gs, o, 64);
-      gq += __shfl_xor(gq, o, 64);
-    }
-    int b, y0, x0, tn;
-    this->decode(it_prev, b, y0, x0, tn);
-    const int cpg = d.Cout / L.gn_groups;        // multiple of 8, <= BN
-    const int per = cpg / 8, ngrp = BN / cpg;
-    float ss = 0.0f, qq = 0.0f;
-    for (int ch = 0; ch < per; ++ch) {           // fixed order: deterministic
-      const int src = (lane < ngrp ? lane : 0) * per + ch;
-      ss += __shfl(gs, src, 64);
-      qq += __shfl(gq, src, 64);
-    }
-    if (lane < ngrp) {
-      const int nsplit = tiles_x * tiles_y;
-      const int slab = (y0 / TH) * tiles_x + x0 / TW;
-      float* dst = L.gn_partials + (((size_t)b * nsplit + slab) * L.gn_groups + tn * BN / cpg + lane) * 2;
-      dst[0] = ss;
-      dst[1] = qq;
-    }
-    gs = 0.0f;
-    gq = 0.0f;
-  }
-
   __device__ __forceinline__ void prologue() {
     w_issue<0>(0);
-    w_write<0>(0);          // tile 0 -> ring slot 0
     w_issue<1>(1);
+    w_wait<0, 0>();
+    w_wait<1, 0>();
+    w_write<0>(0);          // tile 0 -> ring slot 0
     w_write<1>(1);          // tile 1 -> ring slot 1 (consumers prefetch one phase ahead)
     w_issue<2>(2);          // invariant before phase ph: set (ph+k) % 3 holds tile ph+k, k = 2..4
     w_issue<0>(3);
     w_issue<1>(4);
   }
+  // tile ph + 5 lies in this step (PH + 5 < 9) or the next one: its (chunk, tn) are per-step values
   template <int PH>
-  __device__ __forceinline__ void phase(int g, bool draining, int it_prev) {
+  __device__ __forceinline__ void phase(int g, int chunk0, int tn0, int chunk1, int tn1) {
     constexpr int SET = (PH + 2) % 3;            // (9 g + PH + 2) % 3: register set == ring slot of tile ph + 2
     const int ph = g * 9 + PH;
     if (!(dbg & 6)) {
+      w_wait<SET, 16>();
       w_write<SET>(ph + 2);
-      w_issue<SET>(ph + 5);
+      if constexpr (PH + 5 < 9) w_issue_at<SET>(PH + 5, chunk0, tn0);
+      else w_issue_at<SET>(PH + 5 - 9, chunk1, tn1);
     }
-    if (draining && !(dbg & 18)) {
-      if constexpr (PH < 8) {
-        drain_slice(it_prev, PH);
-      } else {
-        if (fuse_stats) stats_flush(it_prev);
-      }
-    }
-    if (!(dbg & 32) || PH % 3 == 2) phase_barrier();
+    if (!(dbg & 32) || PH % 3 == 2) phase_barrier(trace);
   }
   __device__ __forceinline__ void step(int g) {
-    const int chunk = g % nchunks;
-    const bool draining = widx == 0 && chunk == 0 && g >= nchunks;
-    const int it_prev = g / nchunks - 1;
-    phase<0>(g, draining, it_prev); phase<1>(g, draining, it_prev); phase<2>(g, draining, it_prev);
-    phase<3>(g, draining, it_prev); phase<4>(g, draining, it_prev); phase<5>(g, draining, it_prev);
-    phase<6>(g, draining, it_prev); phase<7>(g, draining, it_prev); phase<8>(g, draining, it_prev);
+    const int g1 = g + 1 < nsteps ? g + 1 : nsteps - 1;
+    const int chunk0 = g % nchunks, chunk1 = g1 % nchunks;
+    const int tn0 = tn_of_step(g), tn1 = tn_of_step(g1);
+    phase<0>(g, chunk0, tn0, chunk1, tn1); phase<1>(g, chunk0, tn0, chunk1, tn1); phase<2>(g, chunk0, tn0, chunk1, tn1);
+    phase<3>(g, chunk0, tn0, chunk1, tn1); phase<4>(g, chunk0, tn0, chunk1, tn1); phase<5>(g, chunk0, tn0, chunk1, tn1);
+    phase<6>(g, chunk0, tn0, chunk1, tn1); phase<7>(g, chunk0, tn0, chunk1, tn1); phase<8>(g, chunk0, tn0, chunk1, tn1);
   }
-  __device__ __forceinline__ void drain_last(int it_last) {
+  __device__ __forceinline__ void finish() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail loads before the registers die
 #pragma unroll 1
-    for (int p = 0; p < 9; ++p) {
-      if (widx == 0) {
-        if (p < 8) {
-          drain_slice(it_last, p);
-        } else if (fuse_stats) {
-          stats_flush(it_last);
-        }
-      }
-      phase_barrier();
-    }
+    for (int p = 0; p < 9; ++p) phase_barrier(trace);
   }
 };
 
@@ -310,7 +290,9 @@ struct HaloWaves : ProdBase<TH, TW, BN> {
   using Base = ProdBase<TH, TW, BN>;
   using G = typename Base::G;
   using Base::L; using Base::d; using Base::Ah0; using Base::nsteps; using Base::nchunks; using Base::dbg;
+  using Base::trace; using Base::St; using Base::lane; using Base::fuse_stats; using Base::tiles_x; using Base::tiles_y;
   static constexpr int HP = G::HP, HALO = G::HALO;
+  static constexpr int UPP = BN / 8;                   // stage units per pixel (8 or 16)
   static constexpr int NHW = 4 - BN / 64;              // halo waves: 3 (BN = 64) or 2 (BN = 128: two weight waves)
   static constexpr int RPP = NHW * 8;                  // halo rows per pass (8 lanes per 128-byte row)
   static constexpr int KU = (HALO + RPP - 1) / RPP;    // units per thread
@@ -318,21 +300,43 @@ struct HaloWaves : ProdBase<TH, TW, BN> {
   static constexpr int NWP = (KU + UPW - 1) / UPW;     // write phases (the last NWP phases of a step)
   static constexpr int WRITE0 = 8 - NWP;               // written in phases WRITE0 .. 7 (visible before phase 8 ends)
   static_assert(WRITE0 >= 2, "halo loads need at least two phases of lead");
+  static constexpr int NHT = NHW * 64;                 // halo/drain threads (192 or 128)
+  static constexpr int DPP = (256 + NHT - 1) / NHT;    // drain passes per phase (256 stage units per phase)
   uint4 hreg[KU];
+  int hrel[KU];                                        // source-pixel offset of unit k relative to the tile origin
+  unsigned hedge[KU];                                  // which tile edges (or the halo end) invalidate unit k
   unsigned hvalid;
   float pa[8], pb[8];
-  int htid, slot, hrow, Hl, Wl;
+  float gs, gq;
+  float* red;                                          // [NHW][16][2] cross-wave statistics scratch
+  int htid, hwave, slot, hrow, ecc, Hl, Wl;
 
   __device__ __forceinline__ HaloWaves(const ConvLaunch<bf16_t>& L_, char* smem, int htid_, int lane_, const TileMap& tm_,
                                        int nsteps_, int nchunks_, int fuse, int dbg_)
       : Base(L_, smem, lane_, tm_, nsteps_, nchunks_, fuse, dbg_), htid(htid_) {
     slot = htid & 7;
     hrow = htid >> 3;           // 0..RPP-1
+    hwave = htid >> 6;
+    ecc = htid % UPP;           // NHT is a multiple of UPP: a thread always drains the same 8-channel chunk
+    gs = gq = 0.0f;
+    red = reinterpret_cast<float*>(St + G::ST_BYTES);
     Hl = d.Hout;
     Wl = d.Wout;
     hvalid = 0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) { pa[u] = 1.0f; pb[u] = 0.0f; }
+    // tile-independent part of every halo unit's address and validity, computed once: the per-step issue is then
+    // two or three instructions per load instead of a division, four compares and a 64-bit multiply
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int hp = k * RPP + hrow;
+      const int hy = hp / HP, hx = hp - hy * HP;
+      int ry = hy - 1, rx = hx - 1;                    // tile origins are even, so the x2 gather is (origin/2) + (r >> 1)
+      if (d.ups) { ry >>= 1; rx >>= 1; }
+      hrel[k] = ry * d.Win + rx;
+      hedge[k] = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) |
+                 (hp >= HALO ? 16u : 0u);
+    }
   }
 
   __device__ __forceinline__ void issue_all(int g_next) {
@@ -344,16 +348,18 @@ struct HaloWaves : ProdBase<TH, TW, BN> {
     const bf16_t* base = first ? L.src0 : L.src1;
     const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
     hvalid = 0;
+    const unsigned tedge = (y0 == 0 ? 1u : 0u) | (y0 + TH == Hl ? 2u : 0u) | (x0 == 0 ? 4u : 0u) |
+                           (x0 + TW == Wl ? 8u : 0u) | 16u;
+    const int64_t img0 = (int64_t)b * d.Hin * d.Win;                       // pixel (0,0) of the image: always mapped
+    const int64_t org = img0 + (int64_t)(y0 >> d.ups) * d.Win + (x0 >> d.ups);
+    const bf16_t* p_org = base + org * Cs + cc;
+    const bf16_t* p_img = base + img0 * Cs + cc;
 #pragma unroll
     for (int k = 0; k < KU; ++k) {
-      const int hp = k * RPP + hrow;
-      const int hy = hp / HP, hx = hp - hy * HP;
-      int y = y0 - 1 + hy, x = x0 - 1 + hx;
-      const bool ok = hp < HALO && (unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl;
-      if (d.ups) { y >>= 1; x >>= 1; }
-      // out-of-image taps read pixel (0,0) of the image (always mapped) and are zeroed at write time
-      const int64_t pix = ok ? ((int64_t)b * d.Hin + y) * d.Win + x : (int64_t)b * d.Hin * d.Win;
-      hreg[k] = *reinterpret_cast<const uint4*>(base + pix * Cs + cc);
+      const bool ok = (hedge[k] & tedge) == 0;
+      // out-of-image taps read pixel (0,0) of the image and are zeroed at write time
+      const bf16_t* p = ok ? p_org + (int64_t)hrel[k] * Cs : p_img;
+      hreg[k] = *reinterpret_cast<const uint4*>(p);
       hvalid |= (ok ? 1u : 0u) << k;
     }
     if (L.pro_a) {
@@ -403,26 +409,122 @@ struct HaloWaves : ProdBase<TH, TW, BN> {
     issue_all(0);
     prologue_writes<0>();
   }
+  // ---- stage drain + GroupNorm partial sums (previous tile) -------------------------------------------------
+  // destination of the tile being drained, decoded once per step (not per phase: runtime divisions)
+  int64_t dr_m0;
+  bf16_t* dr_out;
+  __device__ __forceinline__ void drain_setup(int it_prev) {
+    int b, y0, x0, tn;
+    this->decode(it_prev, b, y0, x0, tn);
+    dr_m0 = ((int64_t)b * d.Hout + y0) * d.Wout + x0;
+    dr_out = L.out + tn * BN + ecc * 8;
+  }
+  __device__ __forceinline__ void drain_slice(int p8) {
+#pragma unroll
+    for (int j = 0; j < DPP; ++j) {
+      const int u = j * NHT + htid;                      // unit within this phase's 256
+      if (u < 256) {
+        const int px = (p8 * 256 + u) / UPP;
+        const int k = px & 15;
+        const int slot8 = ((2 * ecc) ^ k) & ~1;
+        uint4 v = *reinterpret_cast<const uint4*>(St + (size_t)px * (BN * 2) + slot8 * 8);
+        if (k & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = bf_lo(w[q]), hi2 = bf_hi(w[q]);
+          gs += lo + hi2;
+          gq = fmaf(lo, lo, gq);
+          gq = fmaf(hi2, hi2, gq);
+        }
+        const int64_t m = dr_m0 + (int64_t)(px / TW) * d.Wout + px % TW;
+        *reinterpret_cast<uint4*>(dr_out + m * d.Cout) = v;
+      }
+    }
+  }
+  __device__ __forceinline__ void stats_reduce() {       // fold the row lanes of this wave, park per-wave chunk totals
+#pragma unroll
+    for (int o = UPP; o < 64; o <<= 1) {
+      gs += __shfl_xor(gs, o, 64);
+      gq += __shfl_xor(gq, o, 64);
+    }
+    if (lane < UPP) {
+      red[(hwave * 16 + lane) * 2 + 0] = gs;
+      red[(hwave * 16 + lane) * 2 + 1] = gq;
+    }
+    gs = 0.0f;
+    gq = 0.0f;
+  }
+  __device__ __forceinline__ void stats_store(int it_prev) {   // fixed-order cross-wave sum: deterministic
+    int b, y0, x0, tn;
+    this->decode(it_prev, b, y0, x0, tn);
+    const int cpg = d.Cout / L.gn_groups;                // multiple of 8, <= BN
+    const int per = cpg / 8, ngrp = BN / cpg;
+    if (htid < ngrp) {
+      float ss = 0.0f, qq = 0.0f;
+      for (int ch = 0; ch < per; ++ch)
+        for (int w = 0; w < NHW; ++w) {
+          ss += red[(w * 16 + htid * per + ch) * 2 + 0];
+          qq += red[(w * 16 + htid * per + ch) * 2 + 1];
+        }
+      const int nsplit = tiles_x * tiles_y;
+      const int slab = (y0 / TH) * tiles_x + x0 / TW;
+      float* dst = L.gn_partials + (((size_t)b * nsplit + slab) * L.gn_groups + tn * BN / cpg + htid) * 2;
+      dst[0] = ss;
+      dst[1] = qq;
+    }
+  }
+
   template <int PH>
-  __device__ __forceinline__ void phase(int g, bool have_next) {
+  __device__ __forceinline__ void phase(int g, bool have_next, bool draining, int it_prev) {
     if (have_next && !(dbg & 10)) {
       if constexpr (PH == 0) issue_all(g + 1);
       if constexpr (PH >= WRITE0 && PH - WRITE0 < NWP) write_phase<PH - WRITE0>(g + 1);
     }
-    if (!(dbg & 32) || PH % 3 == 2) phase_barrier();
+    if (draining && !(dbg & 18)) {
+      if constexpr (PH < 8) {
+        drain_slice(PH);
+      } else {
+        if (fuse_stats) stats_reduce();
+      }
+    }
+    if (!(dbg & 32) || PH % 3 == 2) phase_barrier(trace);
+    if constexpr (PH == 8) {
+      if (draining && fuse_stats && !(dbg & 18)) stats_store(it_prev);   // red[] complete; next write is a tile away
+    }
   }
   __device__ __forceinline__ void step(int g) {
     const bool have_next = g + 1 < nsteps;
-    phase<0>(g, have_next); phase<1>(g, have_next); phase<2>(g, have_next); phase<3>(g, have_next);
-    phase<4>(g, have_next); phase<5>(g, have_next); phase<6>(g, have_next); phase<7>(g, have_next);
-    phase<8>(g, have_next);
+    const int chunk = g % nchunks;
+    const bool draining = chunk == 0 && g >= nchunks;      // a finished tile sits in the stage
+    const int it_prev = g / nchunks - 1;
+    if (draining) drain_setup(it_prev);
+    phase<0>(g, have_next, draining, it_prev); phase<1>(g, have_next, draining, it_prev);
+    phase<2>(g, have_next, draining, it_prev); phase<3>(g, have_next, draining, it_prev);
+    phase<4>(g, have_next, draining, it_prev); phase<5>(g, have_next, draining, it_prev);
+    phase<6>(g, have_next, draining, it_prev); phase<7>(g, have_next, draining, it_prev);
+    phase<8>(g, have_next, draining, it_prev);
+  }
+  __device__ __forceinline__ void drain_last(int it_last) {
+    drain_setup(it_last);
+#pragma unroll 1
+    for (int p = 0; p < 9; ++p) {
+      if (p < 8) {
+        drain_slice(p);
+      } else if (fuse_stats) {
+        stats_reduce();
+      }
+      phase_barrier(trace);
+    }
+    if (fuse_stats) stats_store(it_last);
   }
 };
 
 template <int TH, int TW, int BN>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf16_t> L, const int tiles_x,
                                                             const int tiles_y, const int tiles_n,
-                                                            const int total_tiles, const int fuse_stats, const int dbg) {
+                                                            const int total_tiles, const int fuse_stats, const int dbg,
+                                                            unsigned long long* const trace) {
   using G = WsGeom<TH, TW, BN>;
   constexpr int HP = G::HP, HALO = G::HALO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -447,6 +549,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 
   // ===================================================================================================
   if (consumer) {
+    // The MFMA waves share each SIMD's issue port with one producer wave: static priority keeps the matrix pipe fed
+    // (instruction arbitration is by priority, then age) while the producers fill the gaps.
+    __builtin_amdgcn_s_setprio(3);
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
     int ahp[2];
@@ -469,10 +574,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
 
-    phase_barrier();   // prologue barrier: first halo + weight tiles 0,1 are in LDS
+    phase_barrier(trace);   // prologue barrier: first halo + weight tiles 0,1 are in LDS
     // Fragment double buffer: the reads of call c+1 (or of the NEXT phase's call 0) are issued before the MFMAs
     // of call c, so LDS latency hides behind 128 cycles of matrix work instead of idling the pipe.
-    bf16x8 fw[2][2], fx[2][2];
+    bf16x8 fw[4][2], fx[4][2];   // one fragment set per call of a phase; loads run TWO calls (256 MFMA cycles) ahead
     auto frag_load = [&](int set, const uint4* Ahb, const uint4* Bwb, int toff, int call) {
       const int unit = call * 2 + hi;
 #pragma unroll
@@ -484,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
       }
     };
     frag_load(0, Ah0, Bw0, 0, 0);
+    frag_load(1, Ah0, Bw0, 0, 1);
     int ph = 0;
     for (int g = 0; g < nsteps; ++g) {
       const uint4* Ah = Ah0 + (g & 1) * HALO * 8;
@@ -491,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
       const int chunk = g % nchunks;
 #pragma unroll 1
       for (int p = 0; p < 9; ++p, ++ph) {
-        if (dbg & 1) { if (!(dbg & 32) || p % 3 == 2) phase_barrier(); continue; }
+        if (dbg & 1) { if (!(dbg & 32) || p % 3 == 2) phase_barrier(trace); continue; }
         const uint4* Bw = Bw0 + (ph % 3) * BN * 8;
         const uint4* BwN = Bw0 + ((ph + 1) % 3) * BN * 8;
         const int kh = (p * 11) >> 5, kw = p - kh * 3;
@@ -501,13 +607,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
         const int toffN = khn * HP + kwn;
 #pragma unroll
         for (int call = 0; call < 4; ++call) {
-          if (call < 3) frag_load((call + 1) & 1, Ah, Bw, toff, call + 1);
-          else frag_load(0, p == 8 ? AhN : Ah, BwN, toffN, 0);
+          // set (call + 2) % 4 was consumed two calls ago: refill it for the call two ahead (this phase's calls 2,3
+          // or the NEXT phase's calls 0,1 — its weight tile and halo are already visible in LDS)
+          if (call < 2) frag_load(call + 2, Ah, Bw, toff, call + 2);
+          else frag_load(call - 2, p == 8 ? AhN : Ah, BwN, toffN, call - 2);
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt)
-              acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[call & 1][ct], fx[call & 1][pt], acc[ct][pt], 0, 0, 0);
+              acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[call][ct], fx[call][pt], acc[ct][pt], 0, 0, 0);
         }
         if (p == 8 && chunk == nchunks - 1) {
           // tile finished: bias, round, park in the stage.  Lane holds pixel (pt*32 + l31), channels
@@ -541,12 +649,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 #pragma unroll
               for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
         }
-        if (!(dbg & 32) || p % 3 == 2) phase_barrier();
+        if (!(dbg & 32) || p % 3 == 2) phase_barrier(trace);
       }
     }
     // drain rounds: the producers flush the last tile (8 slices + statistics), consumers only keep the barrier count
 #pragma unroll 1
-    for (int p = 0; p < 9; ++p) phase_barrier();
+    for (int p = 0; p < 9; ++p) phase_barrier(trace);
     return;
   }
 
@@ -555,19 +663,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
   constexpr int NWW = BN / 64;                       // weight waves
   if (wave < 4 + NWW) {
     WeightWave<TH, TW, BN> Wv(L, smem, lane, wave - 4, tmap, nsteps, nchunks, fuse_stats, dbg);
+    Wv.trace = trace;
     Wv.prologue();
-    phase_barrier();
+    phase_barrier(trace);
 #pragma unroll 1
     for (int g = 0; g < nsteps; ++g) Wv.step(g);
-    Wv.drain_last(my_tiles - 1);
+    Wv.finish();
   } else {
     HaloWaves<TH, TW, BN> Hv(L, smem, tid - (4 + NWW) * 64, lane, tmap, nsteps, nchunks, fuse_stats, dbg);
+    Hv.trace = trace;
     Hv.prologue();
-    phase_barrier();
+    phase_barrier(trace);
 #pragma unroll 1
     for (int g = 0; g < nsteps; ++g) Hv.step(g);
-#pragma unroll 1
-    for (int p = 0; p < 9; ++p) phase_barrier();
+    Hv.drain_last(my_tiles - 1);
   }
 }
 
@@ -589,8 +698,28 @@ int launch_ws_cfg(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, in
     attr_done = true;
   }
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
-  conv3x3_ws_kernel<TH, TW, BN><<<dim3(grid), 512, G::LDS, s>>>(L, tiles_x, tiles_y, tiles_n, total, fuse_stats, dbg);
+  static const int trace_at = [] { const char* e = std::getenv("PRG_WS_TRACE"); return e ? std::atoi(e) : -1; }();
+  static int launch_no = 0;
+  unsigned long long* tbuf = nullptr;
+  if (trace_at >= 0 && launch_no++ == trace_at) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&tbuf), 8 * kTraceStride * sizeof(unsigned long long)) == hipSuccess) {
+      std::memset(tbuf, 0, 8 * kTraceStride * sizeof(unsigned long long));
+      (void)hipStreamSynchronize(s);
+    }
+  }
+  conv3x3_ws_kernel<TH, TW, BN><<<dim3(grid), 512, G::LDS, s>>>(L, tiles_x, tiles_y, tiles_n, total, fuse_stats, dbg, tbuf);
   PRG_LAUNCH_CHECK();
+  if (tbuf) {
+    (void)hipStreamSynchronize(s);
+    char path[256];
+    std::snprintf(path, sizeof(path), "%s/ws_trace_%d_%d_%d_cin%d.bin", std::getenv("PRG_WS_TRACE_DIR") ? std::getenv("PRG_WS_TRACE_DIR") : "/tmp",
+                  TH, TW, BN, d.C0 + d.C1);
+    if (FILE* f = std::fopen(path, "wb")) {
+      std::fwrite(tbuf, sizeof(unsigned long long), 8 * kTraceStride, f);
+      std::fclose(f);
+    }
+    (void)hipHostFree(tbuf);
+  }
   return PRG_OK;
 }
 
