@@ -83,11 +83,12 @@ struct WsGeom {
   static constexpr int HP = TW + 2;
   static constexpr int HALO = (TH + 2) * HP;
   static constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
-  static constexpr int NWW = BN / 64;                      // weight waves (each stages 64 weight rows per tap)
-  static constexpr int NHW = 4 - NWW;                      // halo waves
   static constexpr size_t AH_BYTES = (size_t)HALO * 128;
   static constexpr size_t BW_BYTES = (size_t)BN * 128;
-  static constexpr size_t LDS = 2 * AH_BYTES + 3 * BW_BYTES + 4 * 16 * 2 * sizeof(float);
+  static constexpr size_t RED_BYTES = 4 * 16 * 2 * sizeof(float);     // GroupNorm chunk totals of the consumer waves
+  static constexpr size_t STG_BYTES = 4 * 64 * 128;                   // per consumer wave: 64 pixels x 64 channels bf16
+  static constexpr size_t LDS = 2 * AH_BYTES + 3 * BW_BYTES + RED_BYTES + STG_BYTES;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(BM / WAVES_M == 64, "consumer wave tile is 64 pixels x 64 channels");
 };
 
@@ -138,147 +139,71 @@ struct TileMap {
 };
 
 // =====================================================================================================
-// weight wave(s)
-// =====================================================================================================
-template <int TH, int TW, int BN>
-struct WeightWave {
-  using G = WsGeom<TH, TW, BN>;
-  static constexpr int NW = 8;              // 16-byte units per lane per tap (64 rows x 8 units / 64 lanes)
-  const ConvLaunch<bf16_t>& L;
-  const ConvDesc& d;
-  const TileMap& tm;
-  uint4* Bw0;
-  unsigned long long* trace;
-  u32x4 wset[3][NW];
-  const bf16_t* wb;
-  int slot, wrow, nsteps, nchunks;
-
-  __device__ __forceinline__ WeightWave(const ConvLaunch<bf16_t>& L_, char* smem, int lane, int widx, const TileMap& tm_,
-                                        int nsteps_, int nchunks_, unsigned long long* tr)
-      : L(L_), d(L_.d), tm(tm_), trace(tr), nsteps(nsteps_), nchunks(nchunks_) {
-    Bw0 = reinterpret_cast<uint4*>(smem + 2 * G::AH_BYTES);
-    slot = lane & 7;
-    wrow = widx * 64 + (lane >> 3);   // this wave stages weight rows [64 widx, 64 widx + 64): wrow + 8 j
-    wb = L.w + ((size_t)(slot >> 2) * d.CoutPad + wrow) * 32 + (slot & 3) * 8;
-  }
-  __device__ __forceinline__ int tn_of_step(int step) const {
-    if (step >= nsteps) step = nsteps - 1;       // past the end: harmless reload keeps the load count periodic
-    int b, y0, x0, tn;
-    tm.decode(step / nchunks, b, y0, x0, tn);
-    return tn;
-  }
-  template <int SET>
-  __device__ __forceinline__ void issue_at(int tap, int chunk, int tn) {
-    const bf16_t* base = wb + ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tn * BN) * 32;
-    // rows wrow + 8 j are 8 * 32 * 2 = 512 bytes apart: one base address, immediate offsets
-#define PRG_WLOAD(J) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(wset[SET][J]) : "v"(base), "i"((J) * 512) : "memory")
-    PRG_WLOAD(0); PRG_WLOAD(1); PRG_WLOAD(2); PRG_WLOAD(3); PRG_WLOAD(4); PRG_WLOAD(5); PRG_WLOAD(6); PRG_WLOAD(7);
-#undef PRG_WLOAD
-  }
-  template <int SET>
-  __device__ __forceinline__ void issue_phase(int phx) {   // general form (prologue)
-    int step = phx / 9;
-    const int tap = phx - step * 9;
-    if (step >= nsteps) step = nsteps - 1;
-    issue_at<SET>(tap, step % nchunks, tn_of_step(step));
-  }
-  template <int SET, int N>                                // N younger loads may stay in flight
-  __device__ __forceinline__ void wait() {
-    asm volatile("s_waitcnt vmcnt(%[n])"
-                 : "+v"(wset[SET][0]), "+v"(wset[SET][1]), "+v"(wset[SET][2]), "+v"(wset[SET][3]), "+v"(wset[SET][4]),
-                   "+v"(wset[SET][5]), "+v"(wset[SET][6]), "+v"(wset[SET][7])
-                 : [n] "i"(N)
-                 : "memory");
-  }
-  template <int SET>
-  __device__ __forceinline__ void write(int ring) {
-    u32x4* Bw = reinterpret_cast<u32x4*>(Bw0 + ring * BN * 8);
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int n = wrow + j * 8;
-      Bw[n * 8 + (slot ^ ((n >> 1) & 7))] = wset[SET][j];
-    }
-  }
-  __device__ __forceinline__ void prologue() {
-    issue_phase<0>(0);
-    issue_phase<1>(1);
-    wait<0, 0>();
-    wait<1, 0>();
-    write<0>(0);            // tile 0 -> ring slot 0
-    write<1>(1);            // tile 1 -> ring slot 1 (consumers prefetch one phase ahead)
-    issue_phase<2>(2);      // invariant before phase ph: set (ph+k) % 3 holds tile ph+k, k = 2..4
-    issue_phase<0>(3);
-    issue_phase<1>(4);
-  }
-  // tile ph + 5 lies in this step (PH + 5 < 9) or the next one: its (chunk, tn) are per-step values
-  template <int PH>
-  __device__ __forceinline__ void phase(int chunk0, int tn0, int chunk1, int tn1) {
-    constexpr int SET = (PH + 2) % 3;            // (9 g + PH + 2) % 3: register set == ring slot of tile ph + 2
-    wait<SET, 16>();
-    write<SET>(SET);
-    if constexpr (PH + 5 < 9) issue_at<SET>(PH + 5, chunk0, tn0);
-    else issue_at<SET>(PH + 5 - 9, chunk1, tn1);
-    phase_barrier(trace);
-  }
-  __device__ __forceinline__ void step(int g) {
-    const int g1 = g + 1 < nsteps ? g + 1 : nsteps - 1;
-    const int c0 = g % nchunks, c1 = g1 % nchunks;
-    const int t0 = tn_of_step(g), t1 = tn_of_step(g1);
-    phase<0>(c0, t0, c1, t1); phase<1>(c0, t0, c1, t1); phase<2>(c0, t0, c1, t1);
-    phase<3>(c0, t0, c1, t1); phase<4>(c0, t0, c1, t1); phase<5>(c0, t0, c1, t1);
-    phase<6>(c0, t0, c1, t1); phase<7>(c0, t0, c1, t1); phase<8>(c0, t0, c1, t1);
-  }
-  __device__ __forceinline__ void finish() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail loads before the registers die
-    phase_barrier(trace);
-  }
-};
-
-// =====================================================================================================
-// halo waves
+// producer waves: every one of the four stages a quarter of each weight tile and a quarter of each halo
 // =====================================================================================================
 template <int TH, int TW, int BN, bool PRO>
-struct HaloWaves {
+struct Producer {
   using G = WsGeom<TH, TW, BN>;
   static constexpr int HP = G::HP, HALO = G::HALO;
-  static constexpr int RPP = G::NHW * 8;               // halo rows per pass (8 lanes per 128-byte row)
-  static constexpr int KU = (HALO + RPP - 1) / RPP;    // units per thread
+  static constexpr int NWL = BN / 32;                  // weight units per thread per tap (BN rows x 8 units / 256)
+  static constexpr int RPP = 32;                       // halo rows per pass (8 lanes per 128-byte row)
+  static constexpr int KU = (HALO + RPP - 1) / RPP;    // halo units per thread
   static constexpr int UPH = (KU + 7) / 8;             // units handled per phase (phases 0..7)
   static constexpr int NCO = PRO ? 4 : 0;              // coefficient loads per step
-  static constexpr int YOUNGER = KU - 1 + NCO;         // loads younger than the one being waited for (see header)
-  static_assert(YOUNGER <= 63, "vmcnt range");
+  // The load stream of a wave is periodic with period one step:
+  //   phase 0: [coefficients of halo s+2] [weight tile ph+5] [units of phase 0]; phase p: [weight tile ph+5] [units of p]
+  static constexpr int PER_STEP = 9 * NWL + KU + NCO;
+  static constexpr int U_YOUNGER = PER_STEP - 1;       // a unit is used exactly one period after its issue
+  static_assert(U_YOUNGER <= 63, "vmcnt range");
+  static constexpr int n_units(int p) {
+    p = ((p % 9) + 9) % 9;
+    if (p == 8) return 0;
+    const int lo = p * UPH, hi = (p + 1) * UPH < KU ? (p + 1) * UPH : KU;
+    return hi > lo ? hi - lo : 0;
+  }
+  static constexpr int n_coef(int p) { return ((p % 9) + 9) % 9 == 0 ? NCO : 0; }
+  // weight tile ph+2 was issued first thing (after the coefficients) in phase ph-3; everything after it is younger
+  static constexpr int w_younger(int ph) {
+    return n_units(ph - 3) + n_coef(ph - 2) + NWL + n_units(ph - 2) + n_coef(ph - 1) + NWL + n_units(ph - 1) + n_coef(ph);
+  }
+
   const ConvLaunch<bf16_t>& L;
   const ConvDesc& d;
   const TileMap& tm;
   uint4* Ah0;
+  uint4* Bw0;
   unsigned long long* trace;
+  u32x4 wset[3][NWL];
   u32x4 hreg[KU];
   u32x4 cf[2][4];            // [halo parity][a0..3, a4..7, b0..3, b4..7] as raw bits
   int hrel[KU];              // source-pixel offset of unit k relative to the tile origin
   unsigned hedge[KU];        // which tile edges (or the halo end) invalidate unit k
   unsigned hvalid, hvalid_nxt;
+  const bf16_t* wb;
   const bf16_t* ld_org;      // per-step context of the halo being ISSUED
   const bf16_t* ld_img;
   const float* ld_ca;        // its coefficient rows (this thread's 8 channels)
   const float* ld_cb;
   int ld_cs;
   unsigned ld_tedge;
-  int htid, slot, hrow, nsteps, nchunks, Hl, Wl;
+  int slot, row, nsteps, nchunks, Hl, Wl;
 
-  __device__ __forceinline__ HaloWaves(const ConvLaunch<bf16_t>& L_, char* smem, int htid_, const TileMap& tm_, int nsteps_,
-                                       int nchunks_, unsigned long long* tr)
-      : L(L_), d(L_.d), tm(tm_), trace(tr), htid(htid_), nsteps(nsteps_), nchunks(nchunks_) {
+  __device__ __forceinline__ Producer(const ConvLaunch<bf16_t>& L_, char* smem, int ptid, const TileMap& tm_, int nsteps_,
+                                      int nchunks_, unsigned long long* tr)
+      : L(L_), d(L_.d), tm(tm_), trace(tr), nsteps(nsteps_), nchunks(nchunks_) {
     Ah0 = reinterpret_cast<uint4*>(smem);
-    slot = htid & 7;
-    hrow = htid >> 3;           // 0..RPP-1
+    Bw0 = reinterpret_cast<uint4*>(smem + 2 * G::AH_BYTES);
+    slot = ptid & 7;
+    row = ptid >> 3;            // 0..31
     Hl = d.Hout;
     Wl = d.Wout;
     hvalid = hvalid_nxt = 0;
     ld_ca = ld_cb = nullptr;
+    wb = L.w + ((size_t)(slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8;
     // tile-independent part of every halo unit's address and validity, computed once
 #pragma unroll
     for (int k = 0; k < KU; ++k) {
-      const int hp = k * RPP + hrow;
+      const int hp = k * RPP + row;
       const int hy = hp / HP, hx = hp - hy * HP;
       int ry = hy - 1, rx = hx - 1;                    // tile origins are even, so the x2 gather is (origin/2) + (r >> 1)
       if (d.ups) { ry >>= 1; rx >>= 1; }
@@ -288,8 +213,49 @@ struct HaloWaves {
     }
   }
 
+  // ---- weights ----
+  __device__ __forceinline__ int clamp_step(int step) const {
+    // outside [0, nsteps): harmless reload of a valid tile keeps the load count periodic
+    return step < 0 ? 0 : (step >= nsteps ? nsteps - 1 : step);
+  }
+  __device__ __forceinline__ int tn_of_step(int step) const {
+    int b, y0, x0, tn;
+    tm.decode(clamp_step(step) / nchunks, b, y0, x0, tn);
+    return tn;
+  }
+  template <int SET>
+  __device__ __forceinline__ void w_issue(int tap, int chunk, int tn) {
+    const bf16_t* base = wb + ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tn * BN) * 32;
+    // rows row + 32 j are 32 * 32 * 2 = 2048 bytes apart (immediate offsets reach 4095: second base for j >= 2)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wset[SET][0]) : "v"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(wset[SET][1]) : "v"(base) : "memory");
+    if constexpr (NWL == 4) {
+      const bf16_t* base2 = base + 2048;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wset[SET][NWL - 2]) : "v"(base2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(wset[SET][NWL - 1]) : "v"(base2) : "memory");
+    }
+  }
+  template <int SET, int N>                                // N younger loads may stay in flight
+  __device__ __forceinline__ void w_wait() {
+    if constexpr (NWL == 4)
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]), "+v"(wset[SET][2]), "+v"(wset[SET][3]) : [n] "i"(N) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]) : [n] "i"(N) : "memory");
+    static_assert(NWL == 4 || NWL == 2, "weight units per thread");
+  }
+  template <int SET>
+  __device__ __forceinline__ void w_write(int ring) {
+    u32x4* Bw = reinterpret_cast<u32x4*>(Bw0 + ring * BN * 8);
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+      const int n = row + j * 32;
+      Bw[n * 8 + (slot ^ ((n >> 1) & 7))] = wset[SET][j];
+    }
+  }
+
+  // ---- halo ----
   __device__ __forceinline__ void issue_setup(int g_tgt) {
-    if (g_tgt >= nsteps) g_tgt = nsteps - 1;           // past the end: harmless reload keeps the load count periodic
+    g_tgt = clamp_step(g_tgt);
     int b, y0, x0, tn;
     tm.decode(g_tgt / nchunks, b, y0, x0, tn);
     const int chunk = g_tgt % nchunks;
@@ -340,7 +306,7 @@ struct HaloWaves {
   }
   template <int K, int CS>
   __device__ __forceinline__ void write_unit(int g_tgt, bool wr) {
-    const int hp = K * RPP + hrow;
+    const int hp = K * RPP + row;
     if (hp < HALO && wr) {
       uint4* Ah = Ah0 + (g_tgt & 1) * HALO * 8;
       u32x4 v = hreg[K];
@@ -363,17 +329,52 @@ struct HaloWaves {
     }
   }
   // phase PH handles units K = PH * UPH + J.  CSW = coefficient set of the halo being written
-  template <int PH, int J, int CSW>
+  template <int PH, int J, int CSW, bool LIVE>
   __device__ __forceinline__ void unit_pass(int g, bool wr) {
     if constexpr (J < UPH) {
       constexpr int K = PH * UPH + J;
       if constexpr (K < KU) {
-        wait_unit<K, CSW, YOUNGER>();
-        write_unit<K, CSW>(g + 1, wr);
+        if constexpr (LIVE) {
+          wait_unit<K, CSW, U_YOUNGER>();
+          write_unit<K, CSW>(g + 1, wr);
+        }
         issue_unit<K>();
       }
-      unit_pass<PH, J + 1, CSW>(g, wr);
+      unit_pass<PH, J + 1, CSW, LIVE>(g, wr);
     }
+  }
+  // tile ph + 5 lies in this step (PH + 5 < 9) or the next one: its (chunk, tn) are per-step values
+  template <int GP, int PH, bool LIVE>
+  __device__ __forceinline__ void phase(int g, bool wr, int chunk0, int tn0, int chunk1, int tn1) {
+    constexpr int SET = (PH + 2) % 3;            // (9 g + PH + 2) % 3: register set == ring slot of tile ph + 2
+    // the prologue's issue-only step: from phase 3 on the set holds an earlier (placeholder, then real) tile and the
+    // three phases behind it are regular, so the steady-state wait + write applies (the consumers have not started)
+    if constexpr (LIVE || PH >= 3) {
+      w_wait<SET, w_younger(PH)>();
+      w_write<SET>(SET);
+    }
+    if constexpr (PH + 5 < 9) w_issue<SET>(PH + 5, chunk0, tn0);
+    else w_issue<SET>(PH + 5 - 9, chunk1, tn1);
+    if constexpr (PH < 8) unit_pass<PH, 0, (GP + 1) & 1, LIVE>(g, wr);
+    if constexpr (LIVE) phase_barrier(trace);
+  }
+  // GP = g & 1.  Writes halo g+1 (coefficient set (g+1)&1) and weight tiles 9g+2..9g+10; issues halo g+2 (set g&1) and
+  // weight tiles 9g+5..9g+13.  LIVE = false is the issue-only "step -1" of the prologue: it puts exactly the loads a
+  // real step would leave in flight into the queue, in the same order, so step 0 can use the steady-state wait counts.
+  template <int GP, bool LIVE>
+  __device__ __forceinline__ void step(int g) {
+    const bool wr = g + 1 < nsteps;
+    const int ga = clamp_step(g), gb = clamp_step(g + 1);
+    const int c0 = ga % nchunks, c1 = gb % nchunks;
+    const int t0 = tn_of_step(ga), t1 = tn_of_step(gb);
+    issue_setup(g + 2);
+    issue_coeffs<GP>();
+    phase<GP, 0, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 1, LIVE>(g, wr, c0, t0, c1, t1);
+    phase<GP, 2, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 3, LIVE>(g, wr, c0, t0, c1, t1);
+    phase<GP, 4, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 5, LIVE>(g, wr, c0, t0, c1, t1);
+    phase<GP, 6, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 7, LIVE>(g, wr, c0, t0, c1, t1);
+    phase<GP, 8, LIVE>(g, wr, c0, t0, c1, t1);
+    hvalid = hvalid_nxt;
   }
   template <int K>
   __device__ __forceinline__ void prologue_issue() {
@@ -390,34 +391,40 @@ struct HaloWaves {
       prologue_write<K + 1>();
     }
   }
+  // Every asm load's destination must stay owned by its variable until a wait has proven the load complete: a dead
+  // destination could be handed to another value while the load is still in flight.  So no load is ever left unused:
+  // the prologue's placeholder weight loads are waited for and written like real ones, and finish() keeps the clamped
+  // tail loads alive past the final vmcnt(0).
   __device__ __forceinline__ void prologue() {
     issue_setup(0);
     issue_coeffs<0>();
     prologue_issue<0>();
     hvalid = hvalid_nxt;
-    prologue_write<0>();                  // halo 0 in LDS (vmcnt(0) waits)
-    issue_setup(1);
-    issue_coeffs<1>();                    // halo 1 in flight: [coeffs, unit 0 .. KU-1] — the periodic order
-    prologue_issue<0>();
-    hvalid = hvalid_nxt;
+    prologue_write<0>();      // halo 0 (vmcnt(0) waits)
+    // issue-only step "-1": afterwards weight tiles 0, 1 are in ring slots 0, 1 and the queue holds, in steady-state
+    // order, the coefficients + units of halo 1 and weight tiles 2, 3, 4
+    step<1, false>(-1);
   }
-  template <int GP, int PH>
-  __device__ __forceinline__ void phase(int g, bool wr) {
-    if constexpr (PH < 8) unit_pass<PH, 0, (GP + 1) & 1>(g, wr);
-    phase_barrier(trace);
-  }
-  // GP = g & 1.  Writes halo g+1 (coefficient set (g+1)&1), issues halo g+2 (set g&1).
-  template <int GP>
-  __device__ __forceinline__ void step(int g) {
-    const bool wr = g + 1 < nsteps;
-    issue_setup(g + 2);
-    issue_coeffs<GP>();
-    phase<GP, 0>(g, wr); phase<GP, 1>(g, wr); phase<GP, 2>(g, wr); phase<GP, 3>(g, wr); phase<GP, 4>(g, wr);
-    phase<GP, 5>(g, wr); phase<GP, 6>(g, wr); phase<GP, 7>(g, wr); phase<GP, 8>(g, wr);
-    hvalid = hvalid_nxt;
+  template <int K>
+  __device__ __forceinline__ void keep_units() {
+    if constexpr (K < KU) {
+      asm volatile("" : "+v"(hreg[K])::"memory");
+      keep_units<K + 1>();
+    }
   }
   __device__ __forceinline__ void finish() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int sidx = 0; sidx < 3; ++sidx)
+#pragma unroll
+      for (int j = 0; j < NWL; ++j) asm volatile("" : "+v"(wset[sidx][j])::"memory");
+    keep_units<0>();
+    if constexpr (PRO) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(cf[c][j])::"memory");
+    }
     phase_barrier(trace);
   }
 };
@@ -435,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
   uint4* const Ah0 = reinterpret_cast<uint4*>(smem);
   uint4* const Bw0 = reinterpret_cast<uint4*>(smem + 2 * G::AH_BYTES);
   float* const red = reinterpret_cast<float*>(smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES);   // [WAVES_M][16 chunks][2]
+  char* const stage = smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES + G::RED_BYTES;
 
   const ConvDesc& d = L.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -535,13 +543,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
           // store; the 8 channels of chunk (ct, q) are shared by the whole wave -> full-wave shuffle reduction.
           int b, y0, x0, tn;
           tmap.decode(g / nchunks, b, y0, x0, tn);
-          bf16_t* obase[2];
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
-            const int px = wm * 64 + pt * 32 + l31;
-            const int64_t m = ((int64_t)b * d.Hout + y0 + px / TW) * d.Wout + x0 + px % TW;
-            obase[pt] = L.out + m * d.Cout + tn * BN + wn * 64 + 4 * hi;
-          }
+          char* const stg = stage + wave * (64 * 128);
           float cs[2][4], cq[2][4];
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
@@ -566,11 +568,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
                 uint2 w;
                 w.x = pack_bf16(v[0], v[1]);
                 w.y = pack_bf16(v[2], v[3]);
-                *reinterpret_cast<uint2*>(obase[pt] + ct * 32 + 8 * q) = w;
+                // transpose through this wave's own stage: row = pixel, 16-byte unit = ct*4 + q (swizzled), half = hi
+                const int px = pt * 32 + l31;
+                *reinterpret_cast<uint2*>(stg + px * 128 + (((ct * 4 + q) ^ ((px >> 1) & 7)) << 4) + hi * 8) = w;
               }
               cs[ct][q] = s;
               cq[ct][q] = sq;
             }
+          // ... and out as full 128-byte pixel rows, 16 bytes per lane (same wave wrote them: LDS ops are in order)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int r = i * 8 + (lane >> 3), u = lane & 7;
+            const uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + ((u ^ ((r >> 1) & 7)) << 4));
+            const int px = wm * 64 + r;
+            const int64_t m = ((int64_t)b * d.Hout + y0 + px / TW) * d.Wout + x0 + px % TW;
+            *reinterpret_cast<uint4*>(L.out + m * d.Cout + tn * BN + wn * 64 + u * 8) = val;
+          }
           if (fuse_stats) {
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
@@ -604,23 +617,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
   }
 
   // ---------------------------------------------------------------------------------------------------
-  if (wave < 4 + G::NWW) {
-    WeightWave<TH, TW, BN> Wv(L, smem, lane, wave - 4, tmap, nsteps, nchunks, trace);
-    Wv.prologue();
-    phase_barrier(trace);
-#pragma unroll 1
-    for (int g = 0; g < nsteps; ++g) Wv.step(g);
-    Wv.finish();
-  } else {
-    HaloWaves<TH, TW, BN, PRO> Hv(L, smem, tid - (4 + G::NWW) * 64, tmap, nsteps, nchunks, trace);
-    Hv.prologue();
+  {
+    Producer<TH, TW, BN, PRO> Pv(L, smem, tid - 256, tmap, nsteps, nchunks, trace);
+    Pv.prologue();
     phase_barrier(trace);
 #pragma unroll 1
     for (int g = 0; g < nsteps; g += 2) {
-      Hv.template step<0>(g);
-      if (g + 1 < nsteps) Hv.template step<1>(g + 1);
+      Pv.template step<0, true>(g);
+      if (g + 1 < nsteps) Pv.template step<1, true>(g + 1);
     }
-    Hv.finish();
+    Pv.finish();
   }
 }
 
@@ -699,12 +705,15 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
   auto fuse_for = [&](int TH, int TW, int BN) {
     return want && cpg % 8 == 0 && cpg <= BN && (W / TW) * (H / TH) <= kGnMaxSplit ? 1 : 0;
   };
+  static const int cfg_mask = [] { const char* e = std::getenv("PRG_WS_CFGS"); return e ? std::atoi(e) : 7; }();   // debugging aid
   int rc = 0;
   if (d.Cout % 128 == 0) {
+    if (!(cfg_mask & (W % 32 == 0 && H % 4 == 0 ? 1 : 2))) return 0;
     if (W % 32 == 0 && H % 4 == 0) rc = launch_ws_cfg<4, 32, 128>(L, s, fuse_for(4, 32, 128), gn_nsplit_out, num_cus);
     else if (W % 16 == 0 && H % 8 == 0) rc = launch_ws_cfg<8, 16, 128>(L, s, fuse_for(8, 16, 128), gn_nsplit_out, num_cus);
     else return 0;
   } else {
+    if (!(cfg_mask & 4)) return 0;
     if (W % 32 == 0 && H % 8 == 0) rc = launch_ws_cfg<8, 32, 64>(L, s, fuse_for(8, 32, 64), gn_nsplit_out, num_cus);
     else return 0;
   }
