@@ -25,13 +25,14 @@
 // bookkeeping degrades to vmcnt(0) at the merges of such unrolled, branchy streams, which drains the prefetch queue
 // every phase and exposes the whole memory latency nine times per step — measured: 2x on the kernel.)
 // One raw s_barrier per phase (lgkmcnt(0) only, never vmcnt) is the only synchronisation.
-// LDS images use the 16-byte XOR swizzle of conv.hip (unit ^= (row >> 1) & 7): conflict-free ds_read_b128.
+// LDS rows are padded to 144 bytes (WsGeom): conflict-free ds_read_b128 with purely immediate tap/unit/slot offsets.
 //
 // Covers every 3x3 / stride 1 / pad 1 conv of the U-Nets at dim = 64 (widths multiples of 64): Block.proj, the last
 // down/up convs, Upsample's conv (x2 nearest gather folded into the halo load), skip concat as two sources.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "conv.h"
 
@@ -58,21 +59,27 @@ __device__ inline float fast_silu(float x) {
 
 // Optional barrier trace (PRG_WS_TRACE=<launch index>): workgroup 0 records, per wave, the shader clock when it
 // arrives at and when it leaves every phase barrier of that launch (tools/ws_trace.py shows who the others wait for).
+// The record is stores only (device memory, count kept in a register): a load would put its latency into every phase
+// of the traced workgroup.  Stores raise vmcnt, which only makes the producers' counted waits stricter.
 constexpr int kTraceStride = 4096;   // u64 slots per wave: [0] = count, then (arrive, leave) pairs
 
-__device__ __forceinline__ void phase_barrier(unsigned long long* tr) {
+struct TraceCtx {
+  unsigned long long* p;   // this wave's slots, or nullptr
+  int n;
+  __device__ __forceinline__ TraceCtx(unsigned long long* base)
+      : p(base != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 ? base + (threadIdx.x >> 6) * kTraceStride : nullptr),
+        n(0) {}
+};
+
+__device__ __forceinline__ void phase_barrier(TraceCtx& tr) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const bool rec = tr != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
-  unsigned long long n = 0;
-  if (rec) {
-    tr += (threadIdx.x >> 6) * kTraceStride;
-    n = tr[0];
-    if (n < (kTraceStride - 2) / 2) tr[1 + 2 * n] = clock64();
-  }
+  const bool rec = tr.p != nullptr && tr.n < (kTraceStride - 2) / 2;
+  if (rec) tr.p[1 + 2 * tr.n] = clock64();
   __builtin_amdgcn_s_barrier();
-  if (rec && n < (kTraceStride - 2) / 2) {
-    tr[2 + 2 * n] = clock64();
-    tr[0] = n + 1;
+  if (rec) {
+    tr.p[2 + 2 * tr.n] = clock64();
+    ++tr.n;
+    tr.p[0] = tr.n;
   }
   asm volatile("" ::: "memory");
 }
@@ -83,8 +90,12 @@ struct WsGeom {
   static constexpr int HP = TW + 2;
   static constexpr int HALO = (TH + 2) * HP;
   static constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
-  static constexpr size_t AH_BYTES = (size_t)HALO * 128;
-  static constexpr size_t BW_BYTES = (size_t)BN * 128;
+  // LDS rows (one halo pixel / one weight row = 64 bf16) are padded from 128 to 144 bytes instead of XOR-swizzled:
+  // 36-dword stride makes every ds_read_b128 lane group (16 rows, one 16-byte unit each) hit 64 distinct banks
+  // (9 r mod 16 is a permutation), and keeps addresses linear so taps, units and ring slots are immediate offsets.
+  static constexpr int ROWB = 144;
+  static constexpr size_t AH_BYTES = (size_t)HALO * ROWB;
+  static constexpr size_t BW_BYTES = (size_t)BN * ROWB;
   static constexpr size_t RED_BYTES = 4 * 16 * 2 * sizeof(float);     // GroupNorm chunk totals of the consumer waves
   static constexpr size_t STG_BYTES = 4 * 64 * 128;                   // per consumer wave: 64 pixels x 64 channels bf16
   static constexpr size_t LDS = 2 * AH_BYTES + 3 * BW_BYTES + RED_BYTES + STG_BYTES;
@@ -170,9 +181,9 @@ struct Producer {
   const ConvLaunch<bf16_t>& L;
   const ConvDesc& d;
   const TileMap& tm;
-  uint4* Ah0;
-  uint4* Bw0;
-  unsigned long long* trace;
+  char* Ah0;
+  char* Bw0;
+  TraceCtx& trace;
   u32x4 wset[3][NWL];
   u32x4 hreg[KU];
   u32x4 cf[2][4];            // [halo parity][a0..3, a4..7, b0..3, b4..7] as raw bits
@@ -189,10 +200,10 @@ struct Producer {
   int slot, row, nsteps, nchunks, Hl, Wl;
 
   __device__ __forceinline__ Producer(const ConvLaunch<bf16_t>& L_, char* smem, int ptid, const TileMap& tm_, int nsteps_,
-                                      int nchunks_, unsigned long long* tr)
+                                      int nchunks_, TraceCtx& tr)
       : L(L_), d(L_.d), tm(tm_), trace(tr), nsteps(nsteps_), nchunks(nchunks_) {
-    Ah0 = reinterpret_cast<uint4*>(smem);
-    Bw0 = reinterpret_cast<uint4*>(smem + 2 * G::AH_BYTES);
+    Ah0 = smem + (ptid >> 3) * G::ROWB + (ptid & 7) * 16;            // this thread's unit of halo row `row`
+    Bw0 = smem + 2 * G::AH_BYTES + (ptid >> 3) * G::ROWB + (ptid & 7) * 16;
     slot = ptid & 7;
     row = ptid >> 3;            // 0..31
     Hl = d.Hout;
@@ -245,12 +256,9 @@ struct Producer {
   }
   template <int SET>
   __device__ __forceinline__ void w_write(int ring) {
-    u32x4* Bw = reinterpret_cast<u32x4*>(Bw0 + ring * BN * 8);
 #pragma unroll
-    for (int j = 0; j < NWL; ++j) {
-      const int n = row + j * 32;
-      Bw[n * 8 + (slot ^ ((n >> 1) & 7))] = wset[SET][j];
-    }
+    for (int j = 0; j < NWL; ++j)      // weight row `row + 32 j`
+      *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 32 * G::ROWB) = wset[SET][j];
   }
 
   // ---- halo ----
@@ -308,7 +316,6 @@ struct Producer {
   __device__ __forceinline__ void write_unit(int g_tgt, bool wr) {
     const int hp = K * RPP + row;
     if (hp < HALO && wr) {
-      uint4* Ah = Ah0 + (g_tgt & 1) * HALO * 8;
       u32x4 v = hreg[K];
       if constexpr (PRO) {
 #pragma unroll
@@ -325,7 +332,7 @@ struct Producer {
         }
       }
       if (!((hvalid >> K) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
-      reinterpret_cast<u32x4*>(Ah)[hp * 8 + (slot ^ ((hp >> 1) & 7))] = v;
+      *reinterpret_cast<u32x4*>(Ah0 + (g_tgt & 1) * G::AH_BYTES + K * RPP * G::ROWB) = v;
     }
   }
   // phase PH handles units K = PH * UPH + J.  CSW = coefficient set of the halo being written
@@ -435,14 +442,14 @@ struct Producer {
 template <int TH, int TW, int BN, bool PRO>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf16_t> L, const int tiles_x,
                                                             const int tiles_y, const int tiles_n, const int fuse_stats,
-                                                            unsigned long long* const trace) {
+                                                            unsigned long long* const trace_buf) {
   using G = WsGeom<TH, TW, BN>;
-  constexpr int HP = G::HP, HALO = G::HALO;
+  constexpr int HP = G::HP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* const Ah0 = reinterpret_cast<uint4*>(smem);
-  uint4* const Bw0 = reinterpret_cast<uint4*>(smem + 2 * G::AH_BYTES);
+  constexpr int ROWB = G::ROWB;
   float* const red = reinterpret_cast<float*>(smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES);   // [WAVES_M][16 chunks][2]
   char* const stage = smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES + G::RED_BYTES;
+  TraceCtx trace(trace_buf);
 
   const ConvDesc& d = L.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -458,18 +465,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     __builtin_amdgcn_s_setprio(3);   // the MFMA waves share each SIMD's issue port with one producer wave
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
-    int ahp[2];
+    // per-lane LDS byte addresses of the fragments of call 0 / tap 0: pixel rows of the wave's two 32-pixel groups and
+    // weight rows of its two 32-channel groups; lanes 32-63 take the second 16-byte unit of each 32-byte k-slice.
+    // Everything else (tap, call, ring slot) is an immediate offset.
+    const char* xrow[2];
+    const char* wrowp[2];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
       const int p = wm * 64 + pt * 32 + l31;
-      ahp[pt] = (p / TW) * HP + (p % TW);
+      xrow[pt] = smem + ((p / TW) * HP + (p % TW)) * ROWB + hi * 16;
     }
-    int wrow[2], wswz[2];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      wrow[ct] = wn * 64 + ct * 32 + l31;
-      wswz[ct] = (wrow[ct] >> 1) & 7;
-    }
+    for (int ct = 0; ct < 2; ++ct) wrowp[ct] = smem + 2 * G::AH_BYTES + (wn * 64 + ct * 32 + l31) * ROWB + hi * 16;
     f32x16 acc[2][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -501,28 +508,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 
     phase_barrier(trace);   // prologue barrier: first halo + weight tiles 0,1 are in LDS
     bf16x8 fw[4][2], fx[4][2];   // one fragment set per call of a phase; loads run TWO calls (256 MFMA cycles) ahead
-    auto frag_load = [&](int set, const uint4* Ahb, const uint4* Bwb, int toff, int call) {
-      const int unit = call * 2 + hi;
+    auto frag_load = [&](int set, int abuf, int ring, int toff, int call) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) fw[set][ct] = *reinterpret_cast<const bf16x8*>(Bwb + wrow[ct] * 8 + (unit ^ wswz[ct]));
+      for (int ct = 0; ct < 2; ++ct)
+        fw[set][ct] = *reinterpret_cast<const bf16x8*>(wrowp[ct] + ring * (int)G::BW_BYTES + call * 32);
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        const int hp = ahp[pt] + toff;
-        fx[set][pt] = *reinterpret_cast<const bf16x8*>(Ahb + hp * 8 + (unit ^ ((hp >> 1) & 7)));
-      }
+      for (int pt = 0; pt < 2; ++pt)
+        fx[set][pt] = *reinterpret_cast<const bf16x8*>(xrow[pt] + abuf + toff * ROWB + call * 32);
     };
-    frag_load(0, Ah0, Bw0, 0, 0);
-    frag_load(1, Ah0, Bw0, 0, 1);
+    frag_load(0, 0, 0, 0, 0);
+    frag_load(1, 0, 0, 0, 1);
     for (int g = 0; g < nsteps; ++g) {
-      const uint4* Ah = Ah0 + (g & 1) * HALO * 8;
-      const uint4* AhN = Ah0 + ((g + 1) & 1) * HALO * 8;
+      const int Ah = (g & 1) * (int)G::AH_BYTES, AhN = ((g + 1) & 1) * (int)G::AH_BYTES;
       const bool tile_end = (g % nchunks) == nchunks - 1;
       // The nine taps are fully unrolled: tap offsets, the weight ring slot (9 g + p) % 3 == p % 3 and the fragment
       // set indices are compile-time constants, so a phase is 16 ds_read + 16 MFMA + a handful of address adds.
 #pragma unroll
       for (int p = 0; p < 9; ++p) {
-        const uint4* Bw = Bw0 + (p % 3) * BN * 8;
-        const uint4* BwN = Bw0 + ((p + 1) % 3) * BN * 8;
         const int toff = (p / 3) * HP + (p % 3);
         const int pn = p == 8 ? 0 : p + 1;
         const int toffN = (pn / 3) * HP + (pn % 3);
@@ -530,8 +532,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
         for (int call = 0; call < 4; ++call) {
           // set (call + 2) % 4 was consumed two calls ago: refill it for the call two ahead (this phase's calls 2,3
           // or the NEXT phase's calls 0,1 — its weight tile and halo are already visible in LDS)
-          if (call < 2) frag_load(call + 2, Ah, Bw, toff, call + 2);
-          else frag_load(call - 2, p == 8 ? AhN : Ah, BwN, toffN, call - 2);
+          if (call < 2) frag_load(call + 2, Ah, p % 3, toff, call + 2);
+          else frag_load(call - 2, p == 8 ? AhN : Ah, (p + 1) % 3, toffN, call - 2);
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -651,8 +653,8 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
   static int launch_no = 0;
   unsigned long long* tbuf = nullptr;
   if (trace_at >= 0 && launch_no++ == trace_at) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&tbuf), 8 * kTraceStride * sizeof(unsigned long long)) == hipSuccess) {
-      std::memset(tbuf, 0, 8 * kTraceStride * sizeof(unsigned long long));
+    if (hipMalloc(reinterpret_cast<void**>(&tbuf), 8 * kTraceStride * sizeof(unsigned long long)) == hipSuccess) {
+      (void)hipMemsetAsync(tbuf, 0, 8 * kTraceStride * sizeof(unsigned long long), s);
       (void)hipStreamSynchronize(s);
     }
   }
@@ -664,11 +666,13 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
     std::snprintf(path, sizeof(path), "%s/ws_trace_%d_%d_%d_cin%d_pro%d.bin",
                   std::getenv("PRG_WS_TRACE_DIR") ? std::getenv("PRG_WS_TRACE_DIR") : "/tmp", TH, TW, BN, d.C0 + d.C1,
                   (int)PRO);
+    std::vector<unsigned long long> host(8 * kTraceStride);
+    (void)hipMemcpy(host.data(), tbuf, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     if (FILE* f = std::fopen(path, "wb")) {
-      std::fwrite(tbuf, sizeof(unsigned long long), 8 * kTraceStride, f);
+      std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
       std::fclose(f);
     }
-    (void)hipHostFree(tbuf);
+    (void)hipFree(tbuf);
   }
   return PRG_OK;
 }
