@@ -46,6 +46,14 @@ namespace {
 
 constexpr int kCH = 64;   // channels per 128-byte pixel row (bf16)
 
+// Timing experiments only (results become garbage): -DPRG_WS_EXP=1 drops the weight waits, 2 the halo-unit waits,
+// 4 the fused prologue arithmetic, 8 the producers' LDS writes.
+#ifndef PRG_WS_EXP
+#define PRG_WS_EXP 0
+#endif
+constexpr bool kExpNoWaitW = (PRG_WS_EXP & 1) != 0, kExpNoWaitU = (PRG_WS_EXP & 2) != 0;
+constexpr bool kExpNoPro = (PRG_WS_EXP & 4) != 0, kExpNoLdsWrite = (PRG_WS_EXP & 8) != 0;
+
 __device__ inline float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ inline float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ inline uint32_t pack_bf16(float a, float b) {
@@ -71,8 +79,9 @@ struct TraceCtx {
         n(0) {}
 };
 
+template <bool LDS_DONE = true>   // wait for this wave's own LDS operations first (writers always must)
 __device__ __forceinline__ void phase_barrier(TraceCtx& tr) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (LDS_DONE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const bool rec = tr.p != nullptr && tr.n < (kTraceStride - 2) / 2;
   if (rec) tr.p[1 + 2 * tr.n] = clock64();
   __builtin_amdgcn_s_barrier();
@@ -249,16 +258,16 @@ struct Producer {
   template <int SET, int N>                                // N younger loads may stay in flight
   __device__ __forceinline__ void w_wait() {
     if constexpr (NWL == 4)
-      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]), "+v"(wset[SET][2]), "+v"(wset[SET][3]) : [n] "i"(N) : "memory");
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]), "+v"(wset[SET][2]), "+v"(wset[SET][3]) : [n] "i"(kExpNoWaitW ? 63 : N) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]) : [n] "i"(N) : "memory");
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]) : [n] "i"(kExpNoWaitW ? 63 : N) : "memory");
     static_assert(NWL == 4 || NWL == 2, "weight units per thread");
   }
   template <int SET>
   __device__ __forceinline__ void w_write(int ring) {
 #pragma unroll
     for (int j = 0; j < NWL; ++j)      // weight row `row + 32 j`
-      *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 32 * G::ROWB) = wset[SET][j];
+      if (!kExpNoLdsWrite) *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 32 * G::ROWB) = wset[SET][j];
   }
 
   // ---- halo ----
@@ -306,10 +315,10 @@ struct Producer {
     if constexpr (PRO) {
       asm volatile("s_waitcnt vmcnt(%[n])"
                    : "+v"(hreg[K]), "+v"(cf[CS][0]), "+v"(cf[CS][1]), "+v"(cf[CS][2]), "+v"(cf[CS][3])
-                   : [n] "i"(N)
+                   : [n] "i"(kExpNoWaitU && N != 0 ? 63 : N)
                    : "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(hreg[K]) : [n] "i"(N) : "memory");
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(hreg[K]) : [n] "i"(kExpNoWaitU && N != 0 ? 63 : N) : "memory");
     }
   }
   template <int K, int CS>
@@ -317,7 +326,7 @@ struct Producer {
     const int hp = K * RPP + row;
     if (hp < HALO && wr) {
       u32x4 v = hreg[K];
-      if constexpr (PRO) {
+      if constexpr (PRO && !kExpNoPro) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           // v[j] holds channels 2j (low half) and 2j+1 of this thread's 8: coefficients a[2j], a[2j+1] live in
@@ -332,7 +341,8 @@ struct Producer {
         }
       }
       if (!((hvalid >> K) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(Ah0 + (g_tgt & 1) * G::AH_BYTES + K * RPP * G::ROWB) = v;
+      if (!kExpNoLdsWrite) *reinterpret_cast<u32x4*>(Ah0 + (g_tgt & 1) * G::AH_BYTES + K * RPP * G::ROWB) = v;
+      else asm volatile("" ::"v"(v));
     }
   }
   // phase PH handles units K = PH * UPH + J.  CSW = coefficient set of the halo being written
@@ -486,9 +496,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
         for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
 
     // GroupNorm partials of a finished tile: fixed-order sum over the pixel-waves' chunk totals, one store per group
-    auto stats_store = [&](int it) {
-      int b, y0, x0, tn;
-      tmap.decode(it, b, y0, x0, tn);
+    auto stats_store = [&](int b, int y0, int x0, int tn) {
       const int cpg = d.Cout / L.gn_groups;              // multiple of 8, <= BN
       const int per = cpg / 8, ngrp = BN / cpg;
       if (lane < ngrp) {
@@ -506,57 +514,74 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
       }
     };
 
-    phase_barrier(trace);   // prologue barrier: first halo + weight tiles 0,1 are in LDS
+    // Consumers never wait for their own LDS reads at a barrier: every fragment of phase p is consumed by an MFMA of
+    // phase p (which cannot issue before the data is back), and the fragments prefetched for phase p+1 come from a
+    // ring slot / halo buffer that no producer touches before phase p+2.
+    phase_barrier<false>(trace);   // prologue barrier: first halo + weight tiles 0,1 are in LDS
     bf16x8 fw[4][2], fx[4][2];   // one fragment set per call of a phase; loads run TWO calls (256 MFMA cycles) ahead
-    auto frag_load = [&](int set, int abuf, int ring, int toff, int call) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-        fw[set][ct] = *reinterpret_cast<const bf16x8*>(wrowp[ct] + ring * (int)G::BW_BYTES + call * 32);
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-        fx[set][pt] = *reinterpret_cast<const bf16x8*>(xrow[pt] + abuf + toff * ROWB + call * 32);
-    };
-    frag_load(0, 0, 0, 0, 0);
-    frag_load(1, 0, 0, 0, 1);
+    const char* xa[2] = {xrow[0], xrow[1]};                                 // halo buffer of this step
+    const char* xn[2] = {xrow[0] + G::AH_BYTES, xrow[1] + G::AH_BYTES};     // ... of the next one
+#define PRG_LW(SET, CT, RING, CALL) fw[SET][CT] = *reinterpret_cast<const bf16x8*>(wrowp[CT] + (RING) * (int)G::BW_BYTES + (CALL) * 32)
+#define PRG_LX(SET, PT, BASE, TOFF, CALL) fx[SET][PT] = *reinterpret_cast<const bf16x8*>(BASE[PT] + (TOFF) * ROWB + (CALL) * 32)
+#define PRG_MM(SET, CT, PT) acc[CT][PT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[SET][CT], fx[SET][PT], acc[CT][PT], 0, 0, 0)
+#define PRG_SB() __builtin_amdgcn_sched_barrier(0)
+    PRG_LW(0, 0, 0, 0); PRG_LX(0, 0, xa, 0, 0); PRG_LX(0, 1, xa, 0, 0); PRG_LW(0, 1, 0, 0);
+    PRG_LW(1, 0, 0, 1); PRG_LX(1, 0, xa, 0, 1); PRG_LX(1, 1, xa, 0, 1); PRG_LW(1, 1, 0, 1);
+    int chunk = 0, it = 0;                 // step g = it * nchunks + chunk
+    int tb = 0, ty0 = 0, tx0 = 0, ttn = 0; // tile `it`
+    tmap.decode(0, tb, ty0, tx0, ttn);
+    float4 bias_r[2][4];
     for (int g = 0; g < nsteps; ++g) {
-      const int Ah = (g & 1) * (int)G::AH_BYTES, AhN = ((g + 1) & 1) * (int)G::AH_BYTES;
-      const bool tile_end = (g % nchunks) == nchunks - 1;
+      const bool tile_end = chunk == nchunks - 1;
       // The nine taps are fully unrolled: tap offsets, the weight ring slot (9 g + p) % 3 == p % 3 and the fragment
-      // set indices are compile-time constants, so a phase is 16 ds_read + 16 MFMA + a handful of address adds.
+      // set indices are compile-time constants and all LDS offsets are immediates.  The sched_barriers pin the
+      // interleave (one ds_read for the call two ahead, one MFMA) that the scheduler otherwise collapses into
+      // load bursts followed by waits.
 #pragma unroll
       for (int p = 0; p < 9; ++p) {
         const int toff = (p / 3) * HP + (p % 3);
         const int pn = p == 8 ? 0 : p + 1;
         const int toffN = (pn / 3) * HP + (pn % 3);
+        if (p == 0 && tile_end) {
+          // bias of this lane's channels, needed eight phases from now
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              bias_r[ct][q] = L.bias ? *reinterpret_cast<const float4*>(L.bias + ttn * BN + wn * 64 + ct * 32 + 8 * q + 4 * hi)
+                                     : float4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int call = 0; call < 4; ++call) {
           // set (call + 2) % 4 was consumed two calls ago: refill it for the call two ahead (this phase's calls 2,3
           // or the NEXT phase's calls 0,1 — its weight tile and halo are already visible in LDS)
-          if (call < 2) frag_load(call + 2, Ah, p % 3, toff, call + 2);
-          else frag_load(call - 2, p == 8 ? AhN : Ah, (p + 1) % 3, toffN, call - 2);
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-              acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[call][ct], fx[call][pt], acc[ct][pt], 0, 0, 0);
+          if (call < 2) {
+            PRG_LW(call + 2, 0, p % 3, call + 2); PRG_MM(call, 0, 0); PRG_SB();
+            PRG_LX(call + 2, 0, xa, toff, call + 2); PRG_MM(call, 0, 1); PRG_SB();
+            PRG_LX(call + 2, 1, xa, toff, call + 2); PRG_MM(call, 1, 0); PRG_SB();
+            PRG_LW(call + 2, 1, p % 3, call + 2); PRG_MM(call, 1, 1); PRG_SB();
+          } else if (p == 8) {
+            PRG_LW(call - 2, 0, (p + 1) % 3, call - 2); PRG_MM(call, 0, 0); PRG_SB();
+            PRG_LX(call - 2, 0, xn, toffN, call - 2); PRG_MM(call, 0, 1); PRG_SB();
+            PRG_LX(call - 2, 1, xn, toffN, call - 2); PRG_MM(call, 1, 0); PRG_SB();
+            PRG_LW(call - 2, 1, (p + 1) % 3, call - 2); PRG_MM(call, 1, 1); PRG_SB();
+          } else {
+            PRG_LW(call - 2, 0, (p + 1) % 3, call - 2); PRG_MM(call, 0, 0); PRG_SB();
+            PRG_LX(call - 2, 0, xa, toffN, call - 2); PRG_MM(call, 0, 1); PRG_SB();
+            PRG_LX(call - 2, 1, xa, toffN, call - 2); PRG_MM(call, 1, 0); PRG_SB();
+            PRG_LW(call - 2, 1, (p + 1) % 3, call - 2); PRG_MM(call, 1, 1); PRG_SB();
+          }
         }
         if (p == 8 && tile_end) {
-          // tile finished.  Lane holds pixel (pt*32 + l31), channels ct*32 + 8q + 4hi + {0..3}: bias, round, 8-byte
-          // store; the 8 channels of chunk (ct, q) are shared by the whole wave -> full-wave shuffle reduction.
-          int b, y0, x0, tn;
-          tmap.decode(g / nchunks, b, y0, x0, tn);
+          // tile finished.  Lane holds pixel (pt*32 + l31), channels ct*32 + 8q + 4hi + {0..3}: bias, round, transpose
+          // through the wave's LDS stage, 16-byte stores; the 8 channels of chunk (ct, q) are shared by the whole wave.
           char* const stg = stage + wave * (64 * 128);
-          float cs[2][4], cq[2][4];
+          float V[16];   // [sum | sum of squares][ct][q]
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const int c = wn * 64 + ct * 32 + 8 * q + 4 * hi;      // channel within the BN tile
-              float bv[4] = {0, 0, 0, 0};
-              if (L.bias) {
-                const float4 t4 = *reinterpret_cast<const float4*>(L.bias + tn * BN + c);
-                bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
-              }
+              const float bv[4] = {bias_r[ct][q].x, bias_r[ct][q].y, bias_r[ct][q].z, bias_r[ct][q].w};
               float s = 0.0f, sq = 0.0f;
 #pragma unroll
               for (int pt = 0; pt < 2; ++pt) {
@@ -570,12 +595,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
                 uint2 w;
                 w.x = pack_bf16(v[0], v[1]);
                 w.y = pack_bf16(v[2], v[3]);
-                // transpose through this wave's own stage: row = pixel, 16-byte unit = ct*4 + q (swizzled), half = hi
+                // row = pixel, 16-byte unit = ct*4 + q (XOR-swizzled), half = hi
                 const int px = pt * 32 + l31;
                 *reinterpret_cast<uint2*>(stg + px * 128 + (((ct * 4 + q) ^ ((px >> 1) & 7)) << 4) + hi * 8) = w;
               }
-              cs[ct][q] = s;
-              cq[ct][q] = sq;
+              V[ct * 4 + q] = s;
+              V[8 + ct * 4 + q] = sq;
             }
           // ... and out as full 128-byte pixel rows, 16 bytes per lane (same wave wrote them: LDS ops are in order)
 #pragma unroll
@@ -583,25 +608,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
             const int r = i * 8 + (lane >> 3), u = lane & 7;
             const uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + ((u ^ ((r >> 1) & 7)) << 4));
             const int px = wm * 64 + r;
-            const int64_t m = ((int64_t)b * d.Hout + y0 + px / TW) * d.Wout + x0 + px % TW;
-            *reinterpret_cast<uint4*>(L.out + m * d.Cout + tn * BN + wn * 64 + u * 8) = val;
+            const int64_t m = ((int64_t)tb * d.Hout + ty0 + px / TW) * d.Wout + tx0 + px % TW;
+            *reinterpret_cast<uint4*>(L.out + m * d.Cout + ttn * BN + wn * 64 + u * 8) = val;
           }
           if (fuse_stats) {
+            // 16 full-wave sums with 17 shuffles: each butterfly round halves the values a lane carries (it keeps the
+            // half selected by its lane bit and sends the other half to its partner); fixed order -> deterministic
+            const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+            float A8[8], B4[4], C2[2];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int j = 0; j < 8; ++j) A8[j] = (b5 ? V[8 + j] : V[j]) + __shfl_xor(b5 ? V[j] : V[8 + j], 32, 64);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
+            for (int j = 0; j < 4; ++j) B4[j] = (b4 ? A8[4 + j] : A8[j]) + __shfl_xor(b4 ? A8[j] : A8[4 + j], 16, 64);
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                  cs[ct][q] += __shfl_xor(cs[ct][q], o, 64);
-                  cq[ct][q] += __shfl_xor(cq[ct][q], o, 64);
-                }
-                if (lane == 0) {
-                  const int cc = wn * 8 + ct * 4 + q;              // 8-channel chunk within the BN tile
-                  red[(wm * 16 + cc) * 2 + 0] = cs[ct][q];
-                  red[(wm * 16 + cc) * 2 + 1] = cq[ct][q];
-                }
-              }
+            for (int j = 0; j < 2; ++j) C2[j] = (b3 ? B4[2 + j] : B4[j]) + __shfl_xor(b3 ? B4[j] : B4[2 + j], 8, 64);
+            float D = (b2 ? C2[1] : C2[0]) + __shfl_xor(b2 ? C2[0] : C2[1], 4, 64);
+            D += __shfl_xor(D, 2, 64);
+            D += __shfl_xor(D, 1, 64);
+            if ((lane & 3) == 0) {
+              const int i = (lane >> 2) & 15;                        // = 8 b5 + 4 b4 + 2 b3 + b2: [sq][ct][q]
+              red[(wm * 16 + wn * 8 + (i & 7)) * 2 + (i >> 3)] = D;  // 8-channel chunk (wn, ct, q) of the BN tile
+            }
           }
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
@@ -610,11 +637,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 #pragma unroll
               for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
         }
-        phase_barrier(trace);
-        if (p == 8 && tile_end && fuse_stats && wave == 0) stats_store(g / nchunks);   // red[] complete; next write a tile away
+        if (p == 8 && tile_end && fuse_stats) phase_barrier<true>(trace);   // red[] must be visible to wave 0
+        else phase_barrier<false>(trace);
+        if (p == 8 && tile_end && fuse_stats && wave == 0) stats_store(tb, ty0, tx0, ttn);   // next red[] write: a tile away
+      }
+      // next step
+      { const char* t0 = xa[0]; xa[0] = xn[0]; xn[0] = t0; const char* t1 = xa[1]; xa[1] = xn[1]; xn[1] = t1; }
+      if (++chunk == nchunks) {
+        chunk = 0;
+        if (++it < my_tiles) tmap.decode(it, tb, ty0, tx0, ttn);
       }
     }
-    phase_barrier(trace);   // matches the producers' finish()
+#undef PRG_LW
+#undef PRG_LX
+#undef PRG_MM
+#undef PRG_SB
+    phase_barrier<false>(trace);   // matches the producers' finish()
     return;
   }
 

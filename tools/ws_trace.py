@@ -1,4 +1,8 @@
-"""Print a barrier trace written by conv_ws.hip under PRG_WS_TRACE (see phase_barrier)."""
+"""Print a barrier trace written by conv_ws.hip under PRG_WS_TRACE (see phase_barrier).
+
+For every wave (0-3 consumers, 4-7 producers) and phase-in-step p: mean work time (barrier leave -> next arrive) and
+the barrier period.  Usage: python tools/ws_trace.py <trace.bin> ...
+"""
 import sys
 
 import numpy as np
@@ -9,24 +13,13 @@ for path in sys.argv[1:]:
     n = int(a[:, 0].min())
     arr = a[:, 1:1 + 2 * n].reshape(8, n, 2).astype(np.int64)
     arrive, leave = arr[..., 0], arr[..., 1]
-    t0 = arrive.min()
-    print(f"== {path}: {n} barriers; total {(leave.max() - t0)} clk")
-    last = np.argmax(arrive, axis=0)                 # which wave arrived last at each barrier
+    work = arrive[:, 1:] - leave[:, :-1]            # work[:, k-1] = work before barrier k
     period = np.diff(leave.max(axis=0))
-    print("  median barrier period (clk):", int(np.median(period)), " p90:", int(np.percentile(period, 90)))
-    print("  last-arriver histogram (wave 0-3 consumers, 4.. producers):", np.bincount(last, minlength=8).tolist())
-    wait = leave - arrive                            # time each wave spent inside the barrier
-    print("  mean wait per wave (clk):", [int(x) for x in wait.mean(axis=1)])
-    per = leave.max(axis=0)
-    dper = np.diff(per)                                # dper[k-1] = duration of the interval ending at barrier k
-    print("  by phase-in-step p = (k-1) % 9: mean period / most frequent last arriver")
+    print(f"== {path.split('/')[-1]}: {n} barriers, total {leave.max() - arrive.min()} clk, median period {int(np.median(period))}")
     for p in range(9):
-        ks = [k for k in range(10, n) if (k - 1) % 9 == p]
-        if ks:
-            lastw = np.bincount(last[ks], minlength=8)
-            print(f"    p{p}: {int(np.mean([dper[k - 1] for k in ks])):6d} clk   last: wave {int(lastw.argmax())} ({int(lastw.max())}/{len(ks)})")
-    k0 = min(40, n - 1)
-    print("  arrival offsets vs earliest, barriers", k0, "..", k0 + 17)
-    for k in range(k0, min(n, k0 + 18)):
-        rel = arrive[:, k] - arrive[:, k].min()
-        print(f"   b{k:4d} period {int(leave[:, k].max() - leave[:, k - 1].max()):6d}  " + " ".join(f"{int(x):5d}" for x in rel))
+        ks = [k for k in range(10, n - 1) if (k - 1) % 9 == p]
+        if not ks:
+            continue
+        w = np.array([work[:, k - 1] for k in ks])
+        per = np.mean([period[k - 1] for k in ks])
+        print(f"  p{p}: period {int(per):5d}  work mean {[int(x) for x in w.mean(0)]}  (median {[int(x) for x in np.median(w, 0)]})")
