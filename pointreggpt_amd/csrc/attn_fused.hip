@@ -1,0 +1,483 @@
+// attn_fused.hip — Residual(PreNorm(LinearAttention)) of the U-Net (sd:583-589, 631-639, 737-769) as four kernels that
+// never materialise q, k, v for the bf16 throughput path.
+//
+// The unfused path (blocks.hip) moves ~3 GB per instance at 128x128 / B=64 (LayerNorm out, the 384-channel qkv tensor
+// written once and read three times, the 128-channel attention output, the to_out result): it is HBM-bound at 8x the
+// bytes the block needs.  Here every pass re-reads only x (C channels per pixel) and recomputes what it needs with MFMA:
+//
+//   la_kmax   x -> LayerNorm -> k = Wk x^        column maxima per slab            (softmax over pixels needs max_n k)
+//   la_ctx    x -> LayerNorm -> k, v             p = exp(k - max);  sum_n p,  ctx[d][e] += p[n][d] v[n][e]   per slab
+//   la_fin    slabs summed in fixed order, ctx / sum / N * 32^-1/2 -> bf16, stored in the k-slot order la_out's MFMA wants
+//   la_out    x -> LayerNorm -> q -> softmax_d -> out = ctx^T q -> y = Wout out + b -> LayerNorm -> + x     -> store
+//
+// Tiles are 64 pixels; a block of four waves keeps the projection weights in LDS (rows padded to C+8 / 136 bf16 so the
+// 16 lanes of a ds_read_b128 group hit distinct banks) and walks kTilesPerBlock tiles of one image.  Wave w owns head w.
+// MFMA: v_mfma_f32_32x32x16_bf16, D[i][j] = sum_k A[i][k] B[k][j]; lane l supplies A[l&31][8(l>>5)..+7] and
+// B[8(l>>5)..+7][l&31] and receives D[(r&3) + 8(r>>2) + 4(l>>5)][l&31] in register r.
+// The LayerNorm gain of PreNorm is folded into the projection weights on the host (unet.hip).
+#include "blocks.h"
+
+namespace prg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+constexpr int kTP = 64;              // pixels per tile
+constexpr int kHid = 128;            // heads x dim_head
+constexpr int kTilesPerBlock = 8;
+constexpr int kLdO = kHid + 8;       // LDS row stride of 128-wide rows (bf16 elements)
+constexpr int kLdP = kTP + 8;        // LDS row stride of the transposed p / v tiles
+constexpr float kLnEps = 1e-5f;
+
+__device__ inline uint32_t pack2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ inline float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ inline float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+template <int C>
+struct Geo {
+  static constexpr int LDW = C + 8;       // LDS row stride of C-wide rows (bf16 elements)
+  static constexpr int VPT = C / 32;      // 16-byte vectors per thread of a 64 x C tile (4 threads per pixel row)
+  static constexpr int KK = C / 16;       // MFMA k-steps over C
+};
+
+// ---- x tile: global -> registers -> LayerNorm -> LDS ------------------------------------------------------------
+// thread t: pixel row t >> 2, vectors (t & 3) + 4 i (interleaved so that a row's four threads read one contiguous run)
+template <int C>
+struct XTile {
+  uint4 v[Geo<C>::VPT];
+  __device__ inline void load(const bf16_t* x, int64_t pix0, int valid) {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+#pragma unroll
+    for (int i = 0; i < Geo<C>::VPT; ++i)
+      v[i] = row < valid ? *reinterpret_cast<const uint4*>(x + (pix0 + row) * C + (part + 4 * i) * 8) : make_uint4(0, 0, 0, 0);
+  }
+  // (x - mean) * rstd as bf16 into xn[row][c]  (biased variance, two-pass on the registers, eps 1e-5)
+  __device__ inline void normalize_to(__bf16* xn) const {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float f[Geo<C>::VPT][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < Geo<C>::VPT; ++i) {
+      const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[i][2 * j] = bf_lo(w[j]);
+        f[i][2 * j + 1] = bf_hi(w[j]);
+        s += f[i][2 * j] + f[i][2 * j + 1];
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < Geo<C>::VPT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f[i][j] -= mean;
+        q = fmaf(f[i][j], f[i][j], q);
+      }
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + kLnEps);
+#pragma unroll
+    for (int i = 0; i < Geo<C>::VPT; ++i) {
+      uint4 o;
+      o.x = pack2(f[i][0] * rstd, f[i][1] * rstd);
+      o.y = pack2(f[i][2] * rstd, f[i][3] * rstd);
+      o.z = pack2(f[i][4] * rstd, f[i][5] * rstd);
+      o.w = pack2(f[i][6] * rstd, f[i][7] * rstd);
+      *reinterpret_cast<uint4*>(xn + row * Geo<C>::LDW + (part + 4 * i) * 8) = o;
+    }
+  }
+};
+
+// rows [r0, r0 + nrows) of a row-major [.][C] bf16 matrix -> LDS rows of stride LD (all 256 threads)
+template <int COLS, int LD>
+__device__ inline void stage_rows(__bf16* dst, const bf16_t* src, int nrows) {
+  constexpr int VR = COLS / 8;
+  for (int i = threadIdx.x; i < nrows * VR; i += 256) {
+    const int r = i / VR, v = i - r * VR;
+    *reinterpret_cast<uint4*>(dst + r * LD + v * 8) = *reinterpret_cast<const uint4*>(src + (size_t)r * COLS + v * 8);
+  }
+}
+
+__device__ inline bf16x8 frag(const __bf16* rows, int ld, int l31, int hi, int kk) {
+  return *reinterpret_cast<const bf16x8*>(rows + l31 * ld + kk * 16 + hi * 8);
+}
+
+__device__ inline f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+  return z;
+}
+
+// =====================================================================================================
+// pass 1: column maxima of k per slab
+// =====================================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+                                                            float* __restrict__ pmax, int N, int nslab) {
+  using G = Geo<C>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Wl = reinterpret_cast<__bf16*>(smem);      // k rows of the projection: [128][LDW]
+  __bf16* xn = Wl + kHid * G::LDW;                   // [64][LDW]
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int ntiles = (N + kTP - 1) / kTP;
+  const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
+  stage_rows<C, G::LDW>(Wl, wqkv + (size_t)kHid * C, kHid);
+  float m = -INFINITY;                                 // column 32 wave + l31, this lane's pixel rows
+  XTile<C> xt;
+  if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
+  for (int t = t0; t < t1; ++t) {
+    xt.normalize_to(xn);
+    __syncthreads();
+    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kk = 0; kk < G::KK; ++kk) {
+      const bf16x8 wf = frag(Wl + 32 * wave * G::LDW, G::LDW, l31, hi, kk);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk), wf, acc[pt], 0, 0, 0);
+    }
+    const int valid = min(kTP, N - t * kTP);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (px < valid) m = fmaxf(m, acc[pt][r]);
+      }
+    __syncthreads();
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (hi == 0) pmax[((size_t)b * nslab + slab) * kHid + 32 * wave + l31] = m;
+}
+
+// =====================================================================================================
+// pass 2: per-slab sums of p = exp(k - max) and of p v^T
+// =====================================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+                                                           const float* __restrict__ pmax, float* __restrict__ ctxp,
+                                                           float* __restrict__ sump, int N, int nslab) {
+  using G = Geo<C>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Wl = reinterpret_cast<__bf16*>(smem);      // [256][LDW]: k rows then v rows
+  __bf16* xn = Wl + 2 * kHid * G::LDW;               // [64][LDW]
+  __bf16* pv = xn + kTP * G::LDW;                    // per wave: pT [32][kLdP], vT [32][kLdP]
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  __bf16* pT = pv + wave * 2 * 32 * kLdP;
+  __bf16* vT = pT + 32 * kLdP;
+  const int ntiles = (N + kTP - 1) / kTP;
+  const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
+  stage_rows<C, G::LDW>(Wl, wqkv + (size_t)kHid * C, 2 * kHid);
+  float m = -INFINITY;                                 // global column maximum: fixed-order reduce of the slab maxima
+  for (int s2 = 0; s2 < nslab; ++s2) m = fmaxf(m, pmax[((size_t)b * nslab + s2) * kHid + 32 * wave + l31]);
+  f32x16 ctx = zero16();                               // rows d, column e = l31 of head `wave`
+  float ssum = 0.0f;
+  XTile<C> xt;
+  if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
+  for (int t = t0; t < t1; ++t) {
+    xt.normalize_to(xn);
+    __syncthreads();
+    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
+    f32x16 ka[2] = {zero16(), zero16()}, va[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kk = 0; kk < G::KK; ++kk) {
+      const bf16x8 wk = frag(Wl + 32 * wave * G::LDW, G::LDW, l31, hi, kk);
+      const bf16x8 wv = frag(Wl + (kHid + 32 * wave) * G::LDW, G::LDW, l31, hi, kk);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const bf16x8 xf = frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk);
+        ka[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wk, ka[pt], 0, 0, 0);
+        va[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv, va[pt], 0, 0, 0);
+      }
+    }
+    const int valid = min(kTP, N - t * kTP);
+    // p and v, transposed to [channel][pixel] so that pixels become the MFMA k index
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int px0 = pt * 32 + 8 * g4 + 4 * hi;
+        float p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          p[j] = px0 + j < valid ? fast_exp(ka[pt][4 * g4 + j] - m) : 0.0f;
+          ssum += p[j];
+        }
+        uint2 pw, vw;
+        pw.x = pack2(p[0], p[1]);
+        pw.y = pack2(p[2], p[3]);
+        vw.x = pack2(va[pt][4 * g4], va[pt][4 * g4 + 1]);
+        vw.y = pack2(va[pt][4 * g4 + 2], va[pt][4 * g4 + 3]);
+        *reinterpret_cast<uint2*>(pT + l31 * kLdP + px0) = pw;
+        *reinterpret_cast<uint2*>(vT + l31 * kLdP + px0) = vw;
+      }
+    // ctx[d][e] += sum_px p[px][d] v[px][e]   (same wave wrote the tiles: LDS operations of a wave stay in order)
+#pragma unroll
+    for (int kk = 0; kk < kTP / 16; ++kk)
+      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pT, kLdP, l31, hi, kk), frag(vT, kLdP, l31, hi, kk), ctx, 0, 0, 0);
+    __syncthreads();
+  }
+  ssum += __shfl_xor(ssum, 32, 64);
+  const size_t ph = ((size_t)b * 4 + wave) * nslab + slab;
+  if (hi == 0) sump[ph * 32 + l31] = ssum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ctxp[ph * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = ctx[r];
+}
+
+// =====================================================================================================
+// pass 3: ctx = sum_slabs(ctxp) / sum_slabs(sump) / N * 32^-1/2, as bf16 [b][h][e][slot(d)]
+// slot(d) orders the 32 d of a row the way la_out's q registers supply them to the MFMA (see there)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void la_fin_fused_kernel(const float* __restrict__ ctxp, const float* __restrict__ sump,
+                                                           bf16_t* __restrict__ ctxT, int N, int nslab) {
+  const int h = blockIdx.x, b = blockIdx.y;
+  const size_t ph = ((size_t)b * 4 + h) * nslab;
+  const float scale = 0.17677669529663687f / (float)N;    // 32^-1/2 (q) and 1/N (v)
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const int d = idx >> 5, e = idx & 31;
+    float c = 0.0f, s = 0.0f;
+    for (int s2 = 0; s2 < nslab; ++s2) {
+      c += ctxp[(ph + s2) * 1024 + idx];
+      s += sump[(ph + s2) * 32 + d];
+    }
+    const int slot = (d >> 4) * 16 + ((d >> 2) & 1) * 8 + ((d >> 3) & 1) * 4 + (d & 3);
+    ctxT[((size_t)b * 4 + h) * 1024 + e * 32 + slot] = f32_to_bf16(c / s * scale);
+  }
+}
+
+// =====================================================================================================
+// pass 4: q, softmax over d, ctx^T q, to_out conv + bias, LayerNorm, residual
+// =====================================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+                                                           const bf16_t* __restrict__ wout, const float* __restrict__ bias,
+                                                           const float* __restrict__ out_g, const bf16_t* __restrict__ ctxT,
+                                                           bf16_t* __restrict__ out, int N) {
+  using G = Geo<C>;
+  constexpr int RT = C / 32;                 // 32-channel row tiles of y
+  constexpr int NA = RT / 2;                 // y accumulators per wave (RT x 2 pixel tiles over 4 waves)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* Wq = reinterpret_cast<__bf16*>(smem);      // [128][LDW]
+  __bf16* Wo = Wq + kHid * G::LDW;                   // [C][kLdO]
+  __bf16* xn = Wo + C * kLdO;                        // [64][LDW]   (later: the normalised y tile)
+  __bf16* ot = xn + kTP * G::LDW;                    // [64][kLdO]  attention output, pixel-major
+  float* lnb = reinterpret_cast<float*>(ot + kTP * kLdO);   // [64][4][2] LayerNorm partial sums
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int ntiles = (N + kTP - 1) / kTP;
+  const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
+  stage_rows<C, G::LDW>(Wq, wqkv, kHid);
+  stage_rows<kHid, kLdO>(Wo, wout, C);
+  // ctx^T rows e = l31 of head `wave`; k-slot s of half hi in k-step i is d = 16 i + 8 (s >> 2) + 4 hi + (s & 3):
+  // exactly the d of q-accumulator register 8 i + s of a lane in half hi, so q feeds the MFMA without any shuffle
+  bf16x8 ca[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    ca[i] = *reinterpret_cast<const bf16x8*>(ctxT + (((size_t)b * 4 + wave) * 32 + l31) * 32 + i * 16 + hi * 8);
+  // y accumulators of this wave: row tile / pixel tile
+  int yrt[NA], ypt[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    if (RT == 2) { yrt[a] = wave & 1; ypt[a] = wave >> 1; }
+    else { yrt[a] = wave; ypt[a] = a; }
+  }
+  XTile<C> xt;
+  if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
+  for (int t = t0; t < t1; ++t) {
+    const XTile<C> xraw = xt;                          // residual
+    const int valid = min(kTP, N - t * kTP);
+    xt.normalize_to(xn);
+    __syncthreads();                                                                            // (1) xn ready
+    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
+    // q^T[d][px] of head `wave`
+    f32x16 qa[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kk = 0; kk < G::KK; ++kk) {
+      const bf16x8 wf = frag(Wq + 32 * wave * G::LDW, G::LDW, l31, hi, kk);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        qa[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk), qa[pt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      // softmax over the 32 d of pixel pt*32 + l31: 16 in this lane, 16 in lane ^ 32
+      float mx = qa[pt][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qa[pt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sm = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        qa[pt][r] = fast_exp(qa[pt][r] - mx);
+        sm += qa[pt][r];
+      }
+      sm += __shfl_xor(sm, 32, 64);
+      const float inv = 1.0f / sm;
+      f32x16 oa = zero16();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 qb;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) qb[s2] = (__bf16)(qa[pt][8 * i + s2] * inv);
+        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], qb, oa, 0, 0, 0);      // rows e, column px
+      }
+      const int px = pt * 32 + l31;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 w;
+        w.x = pack2(oa[4 * g4], oa[4 * g4 + 1]);
+        w.y = pack2(oa[4 * g4 + 2], oa[4 * g4 + 3]);
+        *reinterpret_cast<uint2*>(ot + px * kLdO + 32 * wave + 8 * g4 + 4 * hi) = w;
+      }
+    }
+    __syncthreads();                                                                            // (2) ot ready, xn free
+    // y^T[c][px] = Wout[c][:] . o[px][:] + bias
+    f32x16 ya[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) ya[a] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < kHid / 16; ++kk) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        ya[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Wo + yrt[a] * 32 * kLdO, kLdO, l31, hi, kk),
+                                                        frag(ot + ypt[a] * 32 * kLdO, kLdO, l31, hi, kk), ya[a], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = yrt[a] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        ya[a][r] += bias[c];
+        s1 += ya[a][r];
+        s2 = fmaf(ya[a][r], ya[a][r], s2);
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) {
+        float* dst = lnb + ((ypt[a] * 32 + l31) * 4 + yrt[a]) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+    __syncthreads();                                                                            // (3) partial sums
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int px = ypt[a] * 32 + l31;
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        s1 += lnb[(px * 4 + rt) * 2];
+        s2 += lnb[(px * 4 + rt) * 2 + 1];
+      }
+      const float mean = s1 * (1.0f / C);
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.0f) + kLnEps);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c0 = yrt[a] * 32 + 8 * g4 + 4 * hi;
+        const float4 gg = *reinterpret_cast<const float4*>(out_g + c0);
+        uint2 w;
+        w.x = pack2((ya[a][4 * g4] - mean) * rstd * gg.x, (ya[a][4 * g4 + 1] - mean) * rstd * gg.y);
+        w.y = pack2((ya[a][4 * g4 + 2] - mean) * rstd * gg.z, (ya[a][4 * g4 + 3] - mean) * rstd * gg.w);
+        *reinterpret_cast<uint2*>(xn + px * G::LDW + c0) = w;
+      }
+    }
+    __syncthreads();                                                                            // (4) y tile in xn
+    {
+      const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+      if (row < valid) {
+#pragma unroll
+        for (int i = 0; i < G::VPT; ++i) {
+          const uint4 yv = *reinterpret_cast<const uint4*>(xn + row * G::LDW + (part + 4 * i) * 8);
+          const uint4 xv = xraw.v[i];
+          uint4 o;
+          o.x = pack2(bf_lo(yv.x) + bf_lo(xv.x), bf_hi(yv.x) + bf_hi(xv.x));
+          o.y = pack2(bf_lo(yv.y) + bf_lo(xv.y), bf_hi(yv.y) + bf_hi(xv.y));
+          o.z = pack2(bf_lo(yv.z) + bf_lo(xv.z), bf_hi(yv.z) + bf_hi(xv.z));
+          o.w = pack2(bf_lo(yv.w) + bf_lo(xv.w), bf_hi(yv.w) + bf_hi(xv.w));
+          *reinterpret_cast<uint4*>(out + ((int64_t)b * N + (int64_t)t * kTP + row) * C + (part + 4 * i) * 8) = o;
+        }
+      }
+    }
+    __syncthreads();                                                                            // (5) xn free again
+  }
+}
+
+template <int C>
+size_t lds_kmax() { return (size_t)(kHid + kTP) * Geo<C>::LDW * 2; }
+template <int C>
+size_t lds_ctx() { return (size_t)(2 * kHid + kTP) * Geo<C>::LDW * 2 + (size_t)4 * 2 * 32 * kLdP * 2; }
+template <int C>
+size_t lds_out() { return (size_t)(kHid + kTP) * Geo<C>::LDW * 2 + (size_t)(C + kTP) * kLdO * 2 + (size_t)kTP * 4 * 2 * 4; }
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(fused attention): ") + hipGetErrorString(e));
+  return PRG_OK;
+}
+
+int la_slabs(int N) { return ceil_div(ceil_div(N, kTP), kTilesPerBlock); }
+
+template <int C>
+int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias, const float* out_g, bf16_t* out,
+             float* ws, int B, int N, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    int rc;
+    if ((rc = set_lds(&la_kmax_fused_kernel<C>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C>, lds_ctx<C>()))) return rc;
+    if ((rc = set_lds(&la_out_fused_kernel<C>, lds_out<C>()))) return rc;
+    attr = true;
+  }
+  const int nslab = la_slabs(N);
+  float* pmax = ws;
+  float* ctxp = pmax + (size_t)B * nslab * kHid;
+  float* sump = ctxp + (size_t)B * 4 * nslab * 1024;
+  bf16_t* ctxT = reinterpret_cast<bf16_t*>(sump + (size_t)B * 4 * nslab * 32);
+  const dim3 grid(nslab, B);
+  la_kmax_fused_kernel<C><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, N, nslab);
+  PRG_LAUNCH_CHECK();
+  la_ctx_fused_kernel<C><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, ctxp, sump, N, nslab);
+  PRG_LAUNCH_CHECK();
+  la_fin_fused_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctxT, N, nslab);
+  PRG_LAUNCH_CHECK();
+  la_out_fused_kernel<C><<<grid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+}  // namespace
+
+bool linattn_fused_supported(int C) { return C == 64 || C == 128; }
+
+size_t linattn_fused_ws_floats(int B, int N) {
+  const size_t ns = la_slabs(N);
+  return (size_t)B * ns * kHid + (size_t)B * 4 * ns * 1024 + (size_t)B * 4 * ns * 32 + (size_t)B * 4 * 1024 / 2 + 64;
+}
+
+// x, out: (B, N, C) bf16.  wqkv: [384][C] with the PreNorm gain folded in (q | k | v rows, head-major); wout: [C][128].
+int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias,
+                                  const float* out_g, bf16_t* out, float* ws, int B, int N, int C, hipStream_t s) {
+  PRG_CHECK(linattn_fused_supported(C), "fused linear attention: unsupported width");
+  PRG_CHECK(la_slabs(N) <= 4096, "fused linear attention: too many slabs");
+  if (C == 64) return launch_c<64>(x, wqkv, wout, bias, out_g, out, ws, B, N, s);
+  return launch_c<128>(x, wqkv, wout, bias, out_g, out, ws, B, N, s);
+}
+
+}  // namespace prg

@@ -48,6 +48,13 @@ size_t linattn_ws_floats(int B, int N);
 template <typename T>
 int launch_linear_attention(const T* qkv, T* out, float* ws, int B, int N, hipStream_t s);
 
+// Residual(PreNorm(LinearAttention)) fused for the bf16 path (attn_fused.hip): x, out (B, N, C); wqkv [384][C] bf16 with
+// the PreNorm gain folded in, wout [C][128] bf16.  ws: at least linattn_fused_ws_floats(B, N) floats.
+bool linattn_fused_supported(int C);
+size_t linattn_fused_ws_floats(int B, int N);
+int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias,
+                                  const float* out_g, bf16_t* out, float* ws, int B, int N, int C, hipStream_t s);
+
 // Attention core (sd:789-795) on qkv NHWC (B, N, 384) -> out NHWC (B, N, 128).
 template <typename T>
 int launch_full_attention(const T* qkv, T* out, int B, int N, hipStream_t s);

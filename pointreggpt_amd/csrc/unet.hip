@@ -10,6 +10,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "blocks.h"
@@ -78,6 +79,7 @@ struct AttnP {
   bool linear = true;
   ConvP qkv, out;
   int64_t out_g = -1, norm_g = -1;
+  int64_t fw_qkv = -1, fw_out = -1;   // bf16 element offsets into the fused-attention weight arena (-1: unfused path)
 };
 struct LevelP {
   ResP r0, r1;
@@ -220,6 +222,7 @@ struct prg_unet {
   float* d_flat = nullptr;      // the float32 state_dict on device (biases, norm gains, MLPs read in place)
   void* d_packed = nullptr;     // packed conv weights of T
   float* d_stem = nullptr;      // stem weights [49*Cin][dim]
+  bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
   Arena arena;
   int resB = 0, resS = 0;
   bool taps_on = false;
@@ -361,6 +364,18 @@ struct UnetImpl : prg_unet {
     const size_t m = arena.mark();
     const int N = H * Wd;
     const size_t M = (size_t)B * N;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (a.linear && a.fw_qkv >= 0 && d_attn) {
+        float* ws = alloc<float>(linattn_fused_ws_floats(B, N));
+        PRG_CHECK(arena.dry || ws, "workspace exhausted (fused attention)");
+        int rc = PRG_OK;
+        if (!arena.dry)
+          rc = launch_linear_attention_fused(x, d_attn + a.fw_qkv, d_attn + a.fw_out, F(a.out.b_off), F(a.out_g), out, ws, B, N,
+                                             a.C, s);
+        arena.reset(m);
+        return rc;
+      }
+    }
     T* xn = alloc<T>(M * a.C);
     T* qkv = alloc<T>(M * 3 * kHidden);
     T* o = alloc<T>(M * kHidden);
@@ -543,6 +558,11 @@ struct UnetImpl : prg_unet {
 };
 
 // ---- weight preparation (host) ---------------------------------------------------------------
+static bool fused_attention_enabled() {
+  static const int on = [] { const char* e = std::getenv("PRG_FUSED_ATTN"); return e ? std::atoi(e) : 1; }();
+  return on != 0;
+}
+
 static void standardize(const float* w, int Cout, int K, std::vector<float>& out) {
   out.resize((size_t)Cout * K);
   for (int o = 0; o < Cout; ++o) {
@@ -600,6 +620,27 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
   PRG_HIP(hipMemcpy(u->d_flat, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   PRG_HIP(hipMemcpy(u->d_packed, packed.data(), packed.size() * sizeof(T), hipMemcpyHostToDevice));
   PRG_HIP(hipMemcpy(u->d_stem, stem.data(), stem.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (std::is_same<T, bf16_t>::value && fused_attention_enabled()) {
+    // fused linear attention (attn_fused.hip): to_qkv with the PreNorm gain folded in, to_out as is, both [out][in] bf16
+    std::vector<bf16_t> aw;
+    auto add = [&](AttnP& a) {
+      if (!a.linear || !linattn_fused_supported(a.C)) return;
+      aw.resize((aw.size() + 63) / 64 * 64);
+      a.fw_qkv = (int64_t)aw.size();
+      for (int o = 0; o < 3 * kHidden; ++o)
+        for (int c = 0; c < a.C; ++c)
+          aw.push_back(f32_to_bf16(weights[a.qkv.w_flat + (size_t)o * a.C + c] * weights[a.norm_g + c]));
+      a.fw_out = (int64_t)aw.size();
+      for (int c = 0; c < a.C; ++c)
+        for (int j = 0; j < kHidden; ++j) aw.push_back(f32_to_bf16(weights[a.out.w_flat + (size_t)c * kHidden + j]));
+    };
+    for (auto& lv : u->lay.downs) add(lv.at);
+    for (auto& lv : u->lay.ups) add(lv.at);
+    if (!aw.empty()) {
+      if (hipMalloc(&u->d_attn, aw.size() * sizeof(bf16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(attention weights)");
+      PRG_HIP(hipMemcpy(u->d_attn, aw.data(), aw.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    }
+  }
   *out = u.release();
   return PRG_OK;
 }
@@ -727,6 +768,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_flat) hipFree(h->d_flat);
   if (h->d_packed) hipFree(h->d_packed);
   if (h->d_stem) hipFree(h->d_stem);
+  if (h->d_attn) hipFree(h->d_attn);
   if (h->arena.base) hipFree(h->arena.base);
   delete h;
   return PRG_OK;
