@@ -47,12 +47,13 @@ namespace {
 constexpr int kCH = 64;   // channels per 128-byte pixel row (bf16)
 
 // Timing experiments only (results become garbage): -DPRG_WS_EXP=1 drops the weight waits, 2 the halo-unit waits,
-// 4 the fused prologue arithmetic, 8 the producers' LDS writes.
+// 4 the fused prologue arithmetic, 8 the producers' LDS writes, 16 the whole tile epilogue, 32 its statistics.
 #ifndef PRG_WS_EXP
 #define PRG_WS_EXP 0
 #endif
 constexpr bool kExpNoWaitW = (PRG_WS_EXP & 1) != 0, kExpNoWaitU = (PRG_WS_EXP & 2) != 0;
 constexpr bool kExpNoPro = (PRG_WS_EXP & 4) != 0, kExpNoLdsWrite = (PRG_WS_EXP & 8) != 0;
+constexpr bool kExpNoEpilogue = (PRG_WS_EXP & 16) != 0, kExpNoStats = (PRG_WS_EXP & 32) != 0;
 
 __device__ inline float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ inline float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -60,6 +61,15 @@ __device__ inline uint32_t pack_bf16(float a, float b) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   bf16x2 v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(uint32_t, v);
+}
+// lane exchanges inside a wave without the LDS crossbar's address VGPR: DPP quad permute / ds_swizzle xor mask
+template <int CTRL>
+__device__ inline float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int XOR>   // partner = lane ^ XOR, XOR < 32
+__device__ inline float swz_xor(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1F));
 }
 __device__ inline float fast_silu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
@@ -105,7 +115,7 @@ struct WsGeom {
   static constexpr int ROWB = 144;
   static constexpr size_t AH_BYTES = (size_t)HALO * ROWB;
   static constexpr size_t BW_BYTES = (size_t)BN * ROWB;
-  static constexpr size_t RED_BYTES = 4 * 16 * 2 * sizeof(float);     // GroupNorm chunk totals of the consumer waves
+  static constexpr size_t RED_BYTES = 0;
   static constexpr size_t STG_BYTES = 4 * 64 * 128;                   // per consumer wave: 64 pixels x 64 channels bf16
   static constexpr size_t LDS = 2 * AH_BYTES + 3 * BW_BYTES + RED_BYTES + STG_BYTES;
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -116,10 +126,41 @@ struct WsGeom {
 // observed placement, used for speed only).  When the conv has several output-channel tiles, every XCD is pinned to
 // ONE of them (tn = xcd % tiles_n) and walks pixel tiles only: its 32 CUs then stream the same weight slice at
 // the same time, so the slice stays resident in the XCD's 4 MB L2.
+struct TileCur { int n, x, y, b; };   // mixed-radix digits of a tile index: channel tile, tile column, tile row, image
+
 struct TileMap {
   int tiles_x, tiles_y, tiles_n, TH, TW;
   int pinned, tn_fixed;
   int first, stride, count;   // tile (or pixel-tile) index of iteration it = first + it * stride, it < count
+  TileCur c0, dc;             // digits of `first` and of `stride`: iterating is digit-wise addition, no divisions
+
+  __device__ __forceinline__ void digits(int t, TileCur& c) const {
+    if (pinned) {
+      c.n = 0;
+    } else {
+      c.n = t % tiles_n;
+      t /= tiles_n;
+    }
+    c.x = t % tiles_x; t /= tiles_x;
+    c.y = t % tiles_y;
+    c.b = t / tiles_y;
+  }
+  __device__ __forceinline__ void next(TileCur& c) const {
+    int carry = 0;
+    if (!pinned) {
+      c.n += dc.n;
+      if (c.n >= tiles_n) { c.n -= tiles_n; carry = 1; }
+    }
+    c.x += dc.x + carry; carry = 0;
+    if (c.x >= tiles_x) { c.x -= tiles_x; carry = 1; }
+    c.y += dc.y + carry; carry = 0;
+    if (c.y >= tiles_y) { c.y -= tiles_y; carry = 1; }
+    c.b += dc.b + carry;
+  }
+  __device__ __forceinline__ void fill(const TileCur& c, int& b, int& y0, int& x0, int& tn) const {
+    b = c.b; y0 = c.y * TH; x0 = c.x * TW;
+    tn = pinned ? tn_fixed : c.n;
+  }
 
   __device__ __forceinline__ void init(int bid, int GR, int tx, int ty, int tn, int nb, int th, int tw) {
     tiles_x = tx; tiles_y = ty; tiles_n = tn; TH = th; TW = tw;
@@ -142,6 +183,8 @@ struct TileMap {
       const int total = npix * tn;
       count = first < total ? (total - first + stride - 1) / stride : 0;
     }
+    digits(first, c0);
+    digits(stride, dc);
   }
   __device__ __forceinline__ void decode(int it, int& b, int& y0, int& x0, int& tn) const {
     int t = first + it * stride;
@@ -207,6 +250,13 @@ struct Producer {
   int ld_cs;
   unsigned ld_tedge;
   int slot, row, nsteps, nchunks, Hl, Wl;
+  // wave-uniform bookkeeping, advanced by counters (no divisions in the loop): steps g, g+1, g+2 and the finished tile
+  struct StepInfo { int chunk, b, y0, x0, tn; TileCur cur; };
+  StepInfo sA, sB, sC, dr;
+  int gC;                    // step index of sC (clamped to the last step)
+  bool drain_on;
+  char* stage_rd;            // this thread's 16-byte unit of the consumers' output stage (row ptid >> 3 of a 32-row half)
+  int dr_r0;                 // ... and its row
 
   __device__ __forceinline__ Producer(const ConvLaunch<bf16_t>& L_, char* smem, int ptid, const TileMap& tm_, int nsteps_,
                                       int nchunks_, TraceCtx& tr)
@@ -219,6 +269,17 @@ struct Producer {
     Wl = d.Wout;
     hvalid = hvalid_nxt = 0;
     ld_ca = ld_cb = nullptr;
+    drain_on = false;
+    dr_r0 = ptid >> 3;
+    stage_rd = smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES + G::RED_BYTES + dr_r0 * 128 + (((ptid & 7) ^ ((dr_r0 >> 1) & 7)) << 4);
+    sA.chunk = 0;
+    sA.cur = tm.c0;
+    tm.fill(sA.cur, sA.b, sA.y0, sA.x0, sA.tn);
+    sB = sA; gC = 0;
+    advance(sB);
+    sC = sB;
+    advance(sC);
+    dr = sA;
     wb = L.w + ((size_t)(slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8;
     // tile-independent part of every halo unit's address and validity, computed once
 #pragma unroll
@@ -234,14 +295,17 @@ struct Producer {
   }
 
   // ---- weights ----
-  __device__ __forceinline__ int clamp_step(int step) const {
-    // outside [0, nsteps): harmless reload of a valid tile keeps the load count periodic
-    return step < 0 ? 0 : (step >= nsteps ? nsteps - 1 : step);
-  }
-  __device__ __forceinline__ int tn_of_step(int step) const {
-    int b, y0, x0, tn;
-    tm.decode(clamp_step(step) / nchunks, b, y0, x0, tn);
-    return tn;
+  // next step after `si` (whose index is gC); past the last step it stays there: harmless reloads keep the load
+  // stream periodic
+  __device__ __forceinline__ void advance(StepInfo& si) {
+    if (gC + 1 < nsteps) {
+      ++gC;
+      if (++si.chunk == nchunks) {
+        si.chunk = 0;
+        tm.next(si.cur);
+        tm.fill(si.cur, si.b, si.y0, si.x0, si.tn);
+      }
+    }
   }
   template <int SET>
   __device__ __forceinline__ void w_issue(int tap, int chunk, int tn) {
@@ -271,11 +335,8 @@ struct Producer {
   }
 
   // ---- halo ----
-  __device__ __forceinline__ void issue_setup(int g_tgt) {
-    g_tgt = clamp_step(g_tgt);
-    int b, y0, x0, tn;
-    tm.decode(g_tgt / nchunks, b, y0, x0, tn);
-    const int chunk = g_tgt % nchunks;
+  __device__ __forceinline__ void issue_setup(const StepInfo& si) {
+    const int b = si.b, y0 = si.y0, x0 = si.x0, chunk = si.chunk;
     const int c = chunk * kCH + slot * 8;
     const bool first = c < d.C0;
     const bf16_t* base = first ? L.src0 : L.src1;
@@ -345,6 +406,19 @@ struct Producer {
       else asm volatile("" ::"v"(v));
     }
   }
+  // Output drain: the consumers leave a finished tile as bf16 [wave][64 pixels][64 channels] in the LDS stage; during
+  // the next step's phases 0..7 every producer thread moves one 16-byte unit per phase to HBM (full 128-byte rows per
+  // 8 lanes), so the tile's write burst overlaps the next tile's MFMAs instead of stalling the consumers.
+  template <int PH>
+  __device__ __forceinline__ void drain_unit() {
+    constexpr int w = PH >> 1;                                   // consumer wave whose stage this phase drains
+    constexpr int wm = w / G::WAVES_N, wn = w % G::WAVES_N;
+    const int r = (PH & 1) * 32 + dr_r0;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stage_rd + w * 8192 + (PH & 1) * 32 * 128);
+    const int px = wm * 64 + r;
+    const int64_t m = ((int64_t)dr.b * Hl + dr.y0 + px / TW) * Wl + dr.x0 + px % TW;
+    *reinterpret_cast<u32x4*>(L.out + m * d.Cout + dr.tn * BN + wn * 64 + slot * 8) = v;
+  }
   // phase PH handles units K = PH * UPH + J.  CSW = coefficient set of the halo being written
   template <int PH, int J, int CSW, bool LIVE>
   __device__ __forceinline__ void unit_pass(int g, bool wr) {
@@ -373,6 +447,9 @@ struct Producer {
     if constexpr (PH + 5 < 9) w_issue<SET>(PH + 5, chunk0, tn0);
     else w_issue<SET>(PH + 5 - 9, chunk1, tn1);
     if constexpr (PH < 8) unit_pass<PH, 0, (GP + 1) & 1, LIVE>(g, wr);
+    if constexpr (LIVE && PH < 8) {
+      if (drain_on) drain_unit<PH>();
+    }
     if constexpr (LIVE) phase_barrier(trace);
   }
   // GP = g & 1.  Writes halo g+1 (coefficient set (g+1)&1) and weight tiles 9g+2..9g+10; issues halo g+2 (set g&1) and
@@ -381,16 +458,31 @@ struct Producer {
   template <int GP, bool LIVE>
   __device__ __forceinline__ void step(int g) {
     const bool wr = g + 1 < nsteps;
-    const int ga = clamp_step(g), gb = clamp_step(g + 1);
-    const int c0 = ga % nchunks, c1 = gb % nchunks;
-    const int t0 = tn_of_step(ga), t1 = tn_of_step(gb);
-    issue_setup(g + 2);
-    issue_coeffs<GP>();
-    phase<GP, 0, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 1, LIVE>(g, wr, c0, t0, c1, t1);
-    phase<GP, 2, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 3, LIVE>(g, wr, c0, t0, c1, t1);
-    phase<GP, 4, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 5, LIVE>(g, wr, c0, t0, c1, t1);
-    phase<GP, 6, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 7, LIVE>(g, wr, c0, t0, c1, t1);
-    phase<GP, 8, LIVE>(g, wr, c0, t0, c1, t1);
+    if constexpr (LIVE) {
+      const int c0 = sA.chunk, t0 = sA.tn, c1 = sB.chunk, t1 = sB.tn;
+      drain_on = g > 0 && sA.chunk == 0;          // the previous step finished tile `dr`
+      issue_setup(sC);
+      issue_coeffs<GP>();
+      phase<GP, 0, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 1, LIVE>(g, wr, c0, t0, c1, t1);
+      phase<GP, 2, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 3, LIVE>(g, wr, c0, t0, c1, t1);
+      phase<GP, 4, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 5, LIVE>(g, wr, c0, t0, c1, t1);
+      phase<GP, 6, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 7, LIVE>(g, wr, c0, t0, c1, t1);
+      phase<GP, 8, LIVE>(g, wr, c0, t0, c1, t1);
+      dr = sA;
+      sA = sB;
+      sB = sC;
+      advance(sC);
+    } else {
+      // step -1: weights of step 0 (placeholders where the tile index is negative), halo of step 1
+      const int c0 = sA.chunk, t0 = sA.tn;
+      issue_setup(sB);
+      issue_coeffs<GP>();
+      phase<GP, 0, LIVE>(g, wr, c0, t0, c0, t0); phase<GP, 1, LIVE>(g, wr, c0, t0, c0, t0);
+      phase<GP, 2, LIVE>(g, wr, c0, t0, c0, t0); phase<GP, 3, LIVE>(g, wr, c0, t0, c0, t0);
+      phase<GP, 4, LIVE>(g, wr, c0, t0, c0, t0); phase<GP, 5, LIVE>(g, wr, c0, t0, c0, t0);
+      phase<GP, 6, LIVE>(g, wr, c0, t0, c0, t0); phase<GP, 7, LIVE>(g, wr, c0, t0, c0, t0);
+      phase<GP, 8, LIVE>(g, wr, c0, t0, c0, t0);
+    }
     hvalid = hvalid_nxt;
   }
   template <int K>
@@ -413,7 +505,7 @@ struct Producer {
   // the prologue's placeholder weight loads are waited for and written like real ones, and finish() keeps the clamped
   // tail loads alive past the final vmcnt(0).
   __device__ __forceinline__ void prologue() {
-    issue_setup(0);
+    issue_setup(sA);
     issue_coeffs<0>();
     prologue_issue<0>();
     hvalid = hvalid_nxt;
@@ -430,6 +522,9 @@ struct Producer {
     }
   }
   __device__ __forceinline__ void finish() {
+    // the last step always ends a tile: `dr` is that tile (consumers passed the last phase barrier: stage complete)
+    drain_unit<0>(); drain_unit<1>(); drain_unit<2>(); drain_unit<3>();
+    drain_unit<4>(); drain_unit<5>(); drain_unit<6>(); drain_unit<7>();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int sidx = 0; sidx < 3; ++sidx)
@@ -457,7 +552,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
   constexpr int HP = G::HP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWB = G::ROWB;
-  float* const red = reinterpret_cast<float*>(smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES);   // [WAVES_M][16 chunks][2]
   char* const stage = smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES + G::RED_BYTES;
   TraceCtx trace(trace_buf);
 
@@ -472,7 +566,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 
   // ---------------------------------------------------------------------------------------------------
   if (wave < 4) {
-    __builtin_amdgcn_s_setprio(3);   // the MFMA waves share each SIMD's issue port with one producer wave
+    __builtin_amdgcn_s_setprio((PRG_WS_EXP & 64) ? 0 : ((PRG_WS_EXP & 128) ? 1 : 3));   // the MFMA waves share each SIMD's issue port with one producer wave
+    // 8-channel chunks per GroupNorm group (a power of two <= 8 when the statistics are fused)
+    const int gn_per = fuse_stats ? (d.Cout / L.gn_groups) >> 3 : 1;
+    const int gn_per_sh = 31 - __builtin_clz(gn_per);
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
     // per-lane LDS byte addresses of the fragments of call 0 / tap 0: pixel rows of the wave's two 32-pixel groups and
@@ -495,25 +592,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
 
-    // GroupNorm partials of a finished tile: fixed-order sum over the pixel-waves' chunk totals, one store per group
-    auto stats_store = [&](int b, int y0, int x0, int tn) {
-      const int cpg = d.Cout / L.gn_groups;              // multiple of 8, <= BN
-      const int per = cpg / 8, ngrp = BN / cpg;
-      if (lane < ngrp) {
-        float ss = 0.0f, qq = 0.0f;
-        for (int ch = 0; ch < per; ++ch)
-          for (int w = 0; w < G::WAVES_M; ++w) {
-            ss += red[(w * 16 + lane * per + ch) * 2 + 0];
-            qq += red[(w * 16 + lane * per + ch) * 2 + 1];
-          }
-        const int nsplit = tiles_x * tiles_y;
-        const int slab = (y0 / TH) * tiles_x + x0 / TW;
-        float* dst = L.gn_partials + (((size_t)b * nsplit + slab) * L.gn_groups + tn * BN / cpg + lane) * 2;
-        dst[0] = ss;
-        dst[1] = qq;
-      }
-    };
-
     // Consumers never wait for their own LDS reads at a barrier: every fragment of phase p is consumed by an MFMA of
     // phase p (which cannot issue before the data is back), and the fragments prefetched for phase p+1 come from a
     // ring slot / halo buffer that no producer touches before phase p+2.
@@ -529,7 +607,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     PRG_LW(1, 0, 0, 1); PRG_LX(1, 0, xa, 0, 1); PRG_LX(1, 1, xa, 0, 1); PRG_LW(1, 1, 0, 1);
     int chunk = 0, it = 0;                 // step g = it * nchunks + chunk
     int tb = 0, ty0 = 0, tx0 = 0, ttn = 0; // tile `it`
-    tmap.decode(0, tb, ty0, tx0, ttn);
+    TileCur tcur = tmap.c0;
+    tmap.fill(tcur, tb, ty0, tx0, ttn);
     float4 bias_r[2][4];
     for (int g = 0; g < nsteps; ++g) {
       const bool tile_end = chunk == nchunks - 1;
@@ -548,8 +627,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              bias_r[ct][q] = L.bias ? *reinterpret_cast<const float4*>(L.bias + ttn * BN + wn * 64 + ct * 32 + 8 * q + 4 * hi)
-                                     : float4{0.f, 0.f, 0.f, 0.f};
+              bias_r[ct][q] = *reinterpret_cast<const float4*>(L.bias + ttn * BN + wn * 64 + ct * 32 + 8 * q + 4 * hi);
         }
 #pragma unroll
         for (int call = 0; call < 4; ++call) {
@@ -572,7 +650,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
             PRG_LW(call - 2, 1, (p + 1) % 3, call - 2); PRG_MM(call, 1, 1); PRG_SB();
           }
         }
-        if (p == 8 && tile_end) {
+        if (p == 8 && tile_end && !kExpNoEpilogue) {
           // tile finished.  Lane holds pixel (pt*32 + l31), channels ct*32 + 8q + 4hi + {0..3}: bias, round, transpose
           // through the wave's LDS stage, 16-byte stores; the 8 channels of chunk (ct, q) are shared by the whole wave.
           char* const stg = stage + wave * (64 * 128);
@@ -602,32 +680,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
               V[ct * 4 + q] = s;
               V[8 + ct * 4 + q] = sq;
             }
-          // ... and out as full 128-byte pixel rows, 16 bytes per lane (same wave wrote them: LDS ops are in order)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int r = i * 8 + (lane >> 3), u = lane & 7;
-            const uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + ((u ^ ((r >> 1) & 7)) << 4));
-            const int px = wm * 64 + r;
-            const int64_t m = ((int64_t)tb * d.Hout + ty0 + px / TW) * d.Wout + tx0 + px % TW;
-            *reinterpret_cast<uint4*>(L.out + m * d.Cout + ttn * BN + wn * 64 + u * 8) = val;
-          }
-          if (fuse_stats) {
-            // 16 full-wave sums with 17 shuffles: each butterfly round halves the values a lane carries (it keeps the
-            // half selected by its lane bit and sends the other half to its partner); fixed order -> deterministic
-            const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+          // the producer waves move the stage to HBM during the next step (Producer::drain_unit)
+          if (fuse_stats && !kExpNoStats) {
+            // 16 full-wave sums with 17 lane exchanges: each butterfly round halves the values a lane carries (it keeps
+            // the half selected by its lane bit and sends the other half to its partner).  The rounds that move many
+            // values use DPP quad permutes (VALU, no LDS crossbar); fixed order -> deterministic.
+            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
             float A8[8], B4[4], C2[2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) A8[j] = (b5 ? V[8 + j] : V[j]) + __shfl_xor(b5 ? V[j] : V[8 + j], 32, 64);
+            for (int j = 0; j < 8; ++j) A8[j] = (b0 ? V[8 + j] : V[j]) + dpp_f32<0xB1>(b0 ? V[j] : V[8 + j]);          // lane ^ 1
 #pragma unroll
-            for (int j = 0; j < 4; ++j) B4[j] = (b4 ? A8[4 + j] : A8[j]) + __shfl_xor(b4 ? A8[j] : A8[4 + j], 16, 64);
+            for (int j = 0; j < 4; ++j) B4[j] = (b1 ? A8[4 + j] : A8[j]) + dpp_f32<0x4E>(b1 ? A8[j] : A8[4 + j]);    // lane ^ 2
 #pragma unroll
-            for (int j = 0; j < 2; ++j) C2[j] = (b3 ? B4[2 + j] : B4[j]) + __shfl_xor(b3 ? B4[j] : B4[2 + j], 8, 64);
-            float D = (b2 ? C2[1] : C2[0]) + __shfl_xor(b2 ? C2[0] : C2[1], 4, 64);
-            D += __shfl_xor(D, 2, 64);
-            D += __shfl_xor(D, 1, 64);
-            if ((lane & 3) == 0) {
-              const int i = (lane >> 2) & 15;                        // = 8 b5 + 4 b4 + 2 b3 + b2: [sq][ct][q]
-              red[(wm * 16 + wn * 8 + (i & 7)) * 2 + (i >> 3)] = D;  // 8-channel chunk (wn, ct, q) of the BN tile
+            for (int j = 0; j < 2; ++j) C2[j] = (b2 ? B4[2 + j] : B4[j]) + swz_xor<4>(b2 ? B4[j] : B4[2 + j]);
+            float D = (b3 ? C2[1] : C2[0]) + swz_xor<8>(b3 ? C2[0] : C2[1]);
+            D += swz_xor<16>(D);
+            D += __shfl_xor(D, 32, 64);
+            // lane (< 16) now holds the wave total of value i = 8 b0 + 4 b1 + 2 b2 + b3 = [sq][ct][q]: the 8-channel chunk
+            // ct*4 + q of this wave's 64 channels.  Fold the chunks of one GroupNorm group (per = cpg / 8 <= 8 of them,
+            // neighbours in q, then ct) and let the group's first chunk store: one partial per (wave row, group).
+            const int per = gn_per;
+            if (per >= 2) D += swz_xor<8>(D);
+            if (per >= 4) D += swz_xor<4>(D);
+            if (per >= 8) D += dpp_f32<0x4E>(D);
+            const int i = (lane & 1) * 8 + (lane & 2) * 2 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
+            const int cc = i & 7;
+            if (lane < 16 && (cc & (per - 1)) == 0) {
+              const int nsplit = tiles_x * tiles_y * G::WAVES_M;
+              const int slab = ((ty0 / TH) * tiles_x + tx0 / TW) * G::WAVES_M + wm;
+              const int grp = (((ttn * BN + wn * 64) >> 3) + cc) >> gn_per_sh;
+              L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
             }
           }
 #pragma unroll
@@ -637,15 +719,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 #pragma unroll
               for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
         }
-        if (p == 8 && tile_end && fuse_stats) phase_barrier<true>(trace);   // red[] must be visible to wave 0
+        if (p == 8 && tile_end) phase_barrier<true>(trace);   // the stage must be visible to the producer waves
         else phase_barrier<false>(trace);
-        if (p == 8 && tile_end && fuse_stats && wave == 0) stats_store(tb, ty0, tx0, ttn);   // next red[] write: a tile away
       }
       // next step
       { const char* t0 = xa[0]; xa[0] = xn[0]; xn[0] = t0; const char* t1 = xa[1]; xa[1] = xn[1]; xn[1] = t1; }
       if (++chunk == nchunks) {
         chunk = 0;
-        if (++it < my_tiles) tmap.decode(it, tb, ty0, tx0, ttn);
+        if (++it < my_tiles) {
+          tmap.next(tcur);
+          tmap.fill(tcur, tb, ty0, tx0, ttn);
+        }
       }
     }
 #undef PRG_LW
@@ -658,6 +742,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
 
   // ---------------------------------------------------------------------------------------------------
   {
+    if (PRG_WS_EXP & (64 | 128)) __builtin_amdgcn_s_setprio((PRG_WS_EXP & 64) ? 3 : 1);
     Producer<TH, TW, BN, PRO> Pv(L, smem, tid - 256, tmap, nsteps, nchunks, trace);
     Pv.prologue();
     phase_barrier(trace);
@@ -686,7 +771,7 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(ws conv): ") + hipGetErrorString(e));
     attr_done = true;
   }
-  if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
+  if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * G::WAVES_M : 0;
   static const int trace_at = [] { const char* e = std::getenv("PRG_WS_TRACE"); return e ? std::atoi(e) : -1; }();
   static int launch_no = 0;
   unsigned long long* tbuf = nullptr;
@@ -733,7 +818,7 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
   const ConvDesc& d = L.d;
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
   if (d.C0 % kCH || d.C1 % kCH || d.Cout % 64) return 0;
-  if (L.residual) return 0;
+  if (L.residual || !L.bias) return 0;
   static int num_cus = 0;
   if (!num_cus) {
     int dev = 0;
@@ -745,7 +830,8 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
   const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
   const bool want = L.gn_partials != nullptr;
   auto fuse_for = [&](int TH, int TW, int BN) {
-    return want && cpg % 8 == 0 && cpg <= BN && (W / TW) * (H / TH) <= kGnMaxSplit ? 1 : 0;
+    // one partial per (tile, consumer wave row): a group must lie inside one wave's 64 channels
+    return want && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 && (W / TW) * (H / TH) * (4 / (BN / 64)) <= kGnMaxSplit ? 1 : 0;
   };
   static const int cfg_mask = [] { const char* e = std::getenv("PRG_WS_CFGS"); return e ? std::atoi(e) : 7; }();   // debugging aid
   int rc = 0;
