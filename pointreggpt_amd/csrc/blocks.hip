@@ -256,19 +256,29 @@ __global__ __launch_bounds__(256) void gn_coeff_kernel(const float* __restrict__
                                                        int G) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.x;
-  if (threadIdx.x < G) {
+  // LPG lanes (a power of two <= 64) share one group: strided partial sums, then a fixed shuffle tree (deterministic)
+  int LPG = 64;
+  while (LPG * G > 256) LPG >>= 1;
+  const int g = threadIdx.x / LPG, j = threadIdx.x % LPG;
+  if (g < G) {
     double ss = 0, qq = 0;
-    const float* pp = partials + ((size_t)b * nsplit * G + threadIdx.x) * 2;
-    for (int k = 0; k < nsplit; ++k) {
+    const float* pp = partials + ((size_t)b * nsplit * G + g) * 2;
+    for (int k = j; k < nsplit; k += LPG) {
       ss += (double)pp[(size_t)k * G * 2 + 0];
       qq += (double)pp[(size_t)k * G * 2 + 1];
     }
-    const double n = (double)HW * (C / G);
-    const double mean = ss / n;
-    double var = qq / n - mean * mean;
-    if (var < 0) var = 0;
-    s_mean[threadIdx.x] = (float)mean;
-    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+    for (int o = LPG >> 1; o > 0; o >>= 1) {
+      ss += __shfl_xor(ss, o, 64);
+      qq += __shfl_xor(qq, o, 64);
+    }
+    if (j == 0) {
+      const double n = (double)HW * (C / G);
+      const double mean = ss / n;
+      double var = qq / n - mean * mean;
+      if (var < 0) var = 0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+    }
   }
   __syncthreads();
   const float* ssa = nullptr;

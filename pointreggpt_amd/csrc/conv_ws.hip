@@ -47,7 +47,7 @@ namespace {
 constexpr int kCH = 64;   // channels per 128-byte pixel row (bf16)
 
 // Timing experiments only (results become garbage): -DPRG_WS_EXP=1 drops the weight waits, 2 the halo-unit waits,
-// 4 the fused prologue arithmetic, 8 the producers' LDS writes, 16 the whole tile epilogue, 32 its statistics.
+// 256 the producers' whole main loop, 512 the consumers' MFMA loop, 4 the fused prologue arithmetic, 8 the producers' LDS writes, 16 the whole tile epilogue, 32 its statistics.
 #ifndef PRG_WS_EXP
 #define PRG_WS_EXP 0
 #endif
@@ -87,16 +87,22 @@ struct TraceCtx {
   __device__ __forceinline__ TraceCtx(unsigned long long* base)
       : p(base != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 ? base + (threadIdx.x >> 6) * kTraceStride : nullptr),
         n(0) {}
+  // two extra time stamps inside the phase that ends at barrier n (producers: after the weight wait, before the LDS drain)
+  __device__ __forceinline__ void mark(int which) {
+    if (p != nullptr && n < 1000) p[kTraceStride / 2 + 2 * n + which] = clock64();
+  }
 };
 
 template <bool LDS_DONE = true>   // wait for this wave's own LDS operations first (writers always must)
 __device__ __forceinline__ void phase_barrier(TraceCtx& tr) {
   if constexpr (LDS_DONE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const bool rec = tr.p != nullptr && tr.n < (kTraceStride - 2) / 2;
+  const bool rec = tr.p != nullptr && tr.n < (kTraceStride - 4) / 2;
   if (rec) tr.p[1 + 2 * tr.n] = clock64();
-  __builtin_amdgcn_s_barrier();
+  if (!(PRG_WS_EXP & 4096)) __builtin_amdgcn_s_barrier();
   if (rec) {
     tr.p[2 + 2 * tr.n] = clock64();
+    if (tr.n == 0) tr.p[kTraceStride - 2] = wall_clock64();   // 100 MHz reference: the trace also yields the shader clock
+    tr.p[kTraceStride - 1] = wall_clock64();
     ++tr.n;
     tr.p[0] = tr.n;
   }
@@ -211,7 +217,9 @@ struct Producer {
   static constexpr int NWL = BN / 32;                  // weight units per thread per tap (BN rows x 8 units / 256)
   static constexpr int RPP = 32;                       // halo rows per pass (8 lanes per 128-byte row)
   static constexpr int KU = (HALO + RPP - 1) / RPP;    // halo units per thread
-  static constexpr int UPH = (KU + 7) / 8;             // units handled per phase (phases 0..7)
+  // units handled per phase (phases 0..7), at least two: the fused prologue of ONE unit is a latency-bound dependent
+  // chain (~840 clk measured, tools/micro/coissue.hip); two units interleave to about the VALU throughput bound
+  static constexpr int UPH = (KU + 7) / 8 > 2 ? (KU + 7) / 8 : 2;
   static constexpr int NCO = PRO ? 4 : 0;              // coefficient loads per step
   // The load stream of a wave is periodic with period one step:
   //   phase 0: [coefficients of halo s+2] [weight tile ph+5] [units of phase 0]; phase p: [weight tile ph+5] [units of p]
@@ -239,15 +247,20 @@ struct Producer {
   u32x4 wset[3][NWL];
   u32x4 hreg[KU];
   u32x4 cf[2][4];            // [halo parity][a0..3, a4..7, b0..3, b4..7] as raw bits
-  int hrel[KU];              // source-pixel offset of unit k relative to the tile origin
+  // Every global access is "wave-uniform SGPR base + per-thread 32-bit VGPR offset (+ immediate)": the bases come from
+  // a few scalar instructions per step, the offsets are constants of the thread, so a phase spends almost no VALU
+  // issue slots on addresses.
+  unsigned hpix[KU];         // source-pixel offset of unit k relative to the halo origin (tile origin - (1,1)): >= 0
+  unsigned w_voff;           // byte offset of this thread's first weight unit inside a tap's [2][CoutPad][32] slab
+  unsigned cf_voff;          // byte offset of this thread's 8 coefficients
+  unsigned dr_voff;          // byte offset of this thread's drain unit relative to a 32-pixel half of a wave tile
   unsigned hedge[KU];        // which tile edges (or the halo end) invalidate unit k
   unsigned hvalid, hvalid_nxt;
-  const bf16_t* wb;
-  const bf16_t* ld_org;      // per-step context of the halo being ISSUED
-  const bf16_t* ld_img;
-  const float* ld_ca;        // its coefficient rows (this thread's 8 channels)
-  const float* ld_cb;
-  int ld_cs;
+  const char* ld_base;       // per-step context of the halo being ISSUED: address of channel 0 of this chunk at the halo origin
+  unsigned ld_cs2;           // bytes per source pixel
+  unsigned ld_dummy;         // pixel offset of the tile origin itself (always inside the image): stand-in for padding taps
+  const char* ld_ca;         // its coefficient rows
+  const char* ld_cb;
   unsigned ld_tedge;
   int slot, row, nsteps, nchunks, Hl, Wl;
   // wave-uniform bookkeeping, advanced by counters (no divisions in the loop): steps g, g+1, g+2 and the finished tile
@@ -280,7 +293,10 @@ struct Producer {
     sC = sB;
     advance(sC);
     dr = sA;
-    wb = L.w + ((size_t)(slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8;
+    w_voff = (unsigned)((((slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8) * 2);
+    cf_voff = (unsigned)(slot * 8 * 4);
+    dr_voff = (unsigned)((((dr_r0 / TW) * d.Wout + dr_r0 % TW) * d.Cout + slot * 8) * 2);
+    ld_dummy = (unsigned)((d.Win + 1));
     // tile-independent part of every halo unit's address and validity, computed once
 #pragma unroll
     for (int k = 0; k < KU; ++k) {
@@ -288,7 +304,7 @@ struct Producer {
       const int hy = hp / HP, hx = hp - hy * HP;
       int ry = hy - 1, rx = hx - 1;                    // tile origins are even, so the x2 gather is (origin/2) + (r >> 1)
       if (d.ups) { ry >>= 1; rx >>= 1; }
-      hrel[k] = ry * d.Win + rx;
+      hpix[k] = (unsigned)((ry + 1) * d.Win + (rx + 1));
       hedge[k] = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) |
                  (hp >= HALO ? 16u : 0u);
     }
@@ -309,14 +325,16 @@ struct Producer {
   }
   template <int SET>
   __device__ __forceinline__ void w_issue(int tap, int chunk, int tn) {
-    const bf16_t* base = wb + ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tn * BN) * 32;
+    const char* base = reinterpret_cast<const char*>(L.w) +
+                       ((PRG_WS_EXP & 1024) ? 0   // timing experiment: always the same (L1-resident) weight tile
+                                            : ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tn * BN) * 64);
     // rows row + 32 j are 32 * 32 * 2 = 2048 bytes apart (immediate offsets reach 4095: second base for j >= 2)
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wset[SET][0]) : "v"(base) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(wset[SET][1]) : "v"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][0]) : "v"(w_voff), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wset[SET][1]) : "v"(w_voff), "s"(base) : "memory");
     if constexpr (NWL == 4) {
-      const bf16_t* base2 = base + 2048;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wset[SET][NWL - 2]) : "v"(base2) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(wset[SET][NWL - 1]) : "v"(base2) : "memory");
+      const char* base2 = base + 4096;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][NWL - 2]) : "v"(w_voff), "s"(base2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wset[SET][NWL - 1]) : "v"(w_voff), "s"(base2) : "memory");
     }
   }
   template <int SET, int N>                                // N younger loads may stay in flight
@@ -337,38 +355,40 @@ struct Producer {
   // ---- halo ----
   __device__ __forceinline__ void issue_setup(const StepInfo& si) {
     const int b = si.b, y0 = si.y0, x0 = si.x0, chunk = si.chunk;
-    const int c = chunk * kCH + slot * 8;
+    const int c = chunk * kCH;
     const bool first = c < d.C0;
-    const bf16_t* base = first ? L.src0 : L.src1;
-    ld_cs = first ? d.C0 : d.C1;
+    const bf16_t* src = first ? L.src0 : L.src1;
+    const int cs = first ? d.C0 : d.C1;
     const int cc = first ? c : c - d.C0;
+    ld_cs2 = (unsigned)(cs * 2);
     ld_tedge = (y0 == 0 ? 1u : 0u) | (y0 + TH == Hl ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == Wl ? 8u : 0u) | 16u;
-    const int64_t img0 = (int64_t)b * d.Hin * d.Win;                       // pixel (0,0) of the image: always mapped
-    const int64_t org = img0 + (int64_t)(y0 >> d.ups) * d.Win + (x0 >> d.ups);
-    ld_org = base + org * ld_cs + cc;
-    ld_img = base + img0 * ld_cs + cc;
+    // halo origin = source pixel of halo position (0,0); may lie one row/column outside the image (never dereferenced:
+    // padding taps load the tile origin instead and are zeroed when written)
+    const int64_t horg = ((int64_t)b * d.Hin + (y0 >> d.ups)) * d.Win + (x0 >> d.ups) - (d.Win + 1);
+    ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
     if constexpr (PRO) {
-      const size_t o = (size_t)b * d.C0 + chunk * kCH + slot * 8;
-      ld_ca = L.pro_a + o;
-      ld_cb = L.pro_b + o;
+      const size_t o = ((size_t)b * d.C0 + chunk * kCH) * 4;
+      ld_ca = reinterpret_cast<const char*>(L.pro_a) + o;
+      ld_cb = reinterpret_cast<const char*>(L.pro_b) + o;
     }
     hvalid_nxt = 0;
   }
   template <int CS>
   __device__ __forceinline__ void issue_coeffs() {
     if constexpr (PRO) {
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cf[CS][0]) : "v"(ld_ca) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(cf[CS][1]) : "v"(ld_ca) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cf[CS][2]) : "v"(ld_cb) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(cf[CS][3]) : "v"(ld_cb) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(cf[CS][0]) : "v"(cf_voff), "s"(ld_ca) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(cf[CS][1]) : "v"(cf_voff), "s"(ld_ca) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(cf[CS][2]) : "v"(cf_voff), "s"(ld_cb) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(cf[CS][3]) : "v"(cf_voff), "s"(ld_cb) : "memory");
     }
   }
   template <int K>
   __device__ __forceinline__ void issue_unit() {
     const bool ok = (hedge[K] & ld_tedge) == 0;
-    // out-of-image taps read pixel (0,0) of the image (always mapped) and are zeroed at write time
-    const bf16_t* p = ok ? ld_org + (int64_t)hrel[K] * ld_cs : ld_img;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hreg[K]) : "v"(p) : "memory");
+    // padding taps read the tile origin (always mapped) and are zeroed at write time
+    const unsigned pix = ok && !(PRG_WS_EXP & 2048) ? hpix[K] : ld_dummy;
+    const unsigned voff = __umul24(pix, ld_cs2) + (unsigned)(slot * 16);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hreg[K]) : "v"(voff), "s"(ld_base) : "memory");
     hvalid_nxt |= (ok ? 1u : 0u) << K;
   }
   template <int K, int CS, int N>
@@ -413,26 +433,45 @@ struct Producer {
   __device__ __forceinline__ void drain_unit() {
     constexpr int w = PH >> 1;                                   // consumer wave whose stage this phase drains
     constexpr int wm = w / G::WAVES_N, wn = w % G::WAVES_N;
-    const int r = (PH & 1) * 32 + dr_r0;
     const u32x4 v = *reinterpret_cast<const u32x4*>(stage_rd + w * 8192 + (PH & 1) * 32 * 128);
-    const int px = wm * 64 + r;
-    const int64_t m = ((int64_t)dr.b * Hl + dr.y0 + px / TW) * Wl + dr.x0 + px % TW;
-    *reinterpret_cast<u32x4*>(L.out + m * d.Cout + dr.tn * BN + wn * 64 + slot * 8) = v;
+    // pixels wm*64 + (PH&1)*32 + [0,32) of the tile: whole tile rows, so the row part is wave-uniform
+    constexpr int prow = (wm * 64 + (PH & 1) * 32) / TW;
+    const int64_t m0 = ((int64_t)dr.b * Hl + dr.y0 + prow) * Wl + dr.x0;
+    char* base = reinterpret_cast<char*>(L.out) + (m0 * d.Cout + dr.tn * BN + wn * 64) * 2;
+    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(dr_voff), "v"(v), "s"(base) : "memory");
   }
   // phase PH handles units K = PH * UPH + J.  CSW = coefficient set of the halo being written
-  template <int PH, int J, int CSW, bool LIVE>
-  __device__ __forceinline__ void unit_pass(int g, bool wr) {
-    if constexpr (J < UPH) {
-      constexpr int K = PH * UPH + J;
-      if constexpr (K < KU) {
-        if constexpr (LIVE) {
-          wait_unit<K, CSW, U_YOUNGER>();
-          write_unit<K, CSW>(g + 1, wr);
-        }
-        issue_unit<K>();
-      }
-      unit_pass<PH, J + 1, CSW, LIVE>(g, wr);
+  // A phase's units are waited for together, transformed and written together (so the compiler can interleave
+  // their arithmetic) and re-issued together.  Unit J of the group is waited for before J older re-issues happen,
+  // hence J fewer younger loads.
+  template <int PH, int J, int CSW>
+  __device__ __forceinline__ void units_wait() {
+    if constexpr (J < UPH && PH * UPH + J < KU) {
+      wait_unit<PH * UPH + J, CSW, U_YOUNGER - J>();
+      units_wait<PH, J + 1, CSW>();
     }
+  }
+  template <int PH, int J, int CSW>
+  __device__ __forceinline__ void units_write(int g, bool wr) {
+    if constexpr (J < UPH && PH * UPH + J < KU) {
+      write_unit<PH * UPH + J, CSW>(g + 1, wr);
+      units_write<PH, J + 1, CSW>(g, wr);
+    }
+  }
+  template <int PH, int J>
+  __device__ __forceinline__ void units_issue() {
+    if constexpr (J < UPH && PH * UPH + J < KU) {
+      issue_unit<PH * UPH + J>();
+      units_issue<PH, J + 1>();
+    }
+  }
+  template <int PH, int CSW, bool LIVE>
+  __device__ __forceinline__ void unit_pass(int g, bool wr) {
+    if constexpr (LIVE) {
+      units_wait<PH, 0, CSW>();
+      units_write<PH, 0, CSW>(g, wr);
+    }
+    units_issue<PH, 0>();
   }
   // tile ph + 5 lies in this step (PH + 5 < 9) or the next one: its (chunk, tn) are per-step values
   template <int GP, int PH, bool LIVE>
@@ -442,14 +481,16 @@ struct Producer {
     // three phases behind it are regular, so the steady-state wait + write applies (the consumers have not started)
     if constexpr (LIVE || PH >= 3) {
       w_wait<SET, w_younger(PH)>();
+      if constexpr (LIVE) trace.mark(0);
       w_write<SET>(SET);
     }
     if constexpr (PH + 5 < 9) w_issue<SET>(PH + 5, chunk0, tn0);
     else w_issue<SET>(PH + 5 - 9, chunk1, tn1);
-    if constexpr (PH < 8) unit_pass<PH, 0, (GP + 1) & 1, LIVE>(g, wr);
+    if constexpr (PH < 8) unit_pass<PH, (GP + 1) & 1, LIVE>(g, wr);
     if constexpr (LIVE && PH < 8) {
       if (drain_on) drain_unit<PH>();
     }
+    if constexpr (LIVE) trace.mark(1);
     if constexpr (LIVE) phase_barrier(trace);
   }
   // GP = g & 1.  Writes halo g+1 (coefficient set (g+1)&1) and weight tiles 9g+2..9g+10; issues halo g+2 (set g&1) and
@@ -572,6 +613,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     const int gn_per_sh = 31 - __builtin_clz(gn_per);
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
+    // Pixel of the wave's 32-pixel group that lane l31 owns.  With 16-pixel tile rows a group spans two halo rows
+    // (18 LDS rows apart): rotating the second row's columns by two keeps the 16 lanes of every ds_read_b128 lane
+    // group ({0-3,12-15,20-27}, {4-11,16-19,28-31}) on distinct residues mod 16 of the LDS row index, i.e. bank
+    // conflict free (SQ_LDS_BANK_CONFLICT was 57 % of the LDS cycles with the identity mapping).
+    const int lpx = (TW == 16 && l31 >= 16) ? 16 + ((l31 - 2) & 15) : l31;
     // per-lane LDS byte addresses of the fragments of call 0 / tap 0: pixel rows of the wave's two 32-pixel groups and
     // weight rows of its two 32-channel groups; lanes 32-63 take the second 16-byte unit of each 32-byte k-slice.
     // Everything else (tap, call, ring slot) is an immediate offset.
@@ -579,7 +625,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     const char* wrowp[2];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      const int p = wm * 64 + pt * 32 + l31;
+      const int p = wm * 64 + pt * 32 + lpx;
       xrow[pt] = smem + ((p / TW) * HP + (p % TW)) * ROWB + hi * 16;
     }
 #pragma unroll
@@ -630,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
               bias_r[ct][q] = *reinterpret_cast<const float4*>(L.bias + ttn * BN + wn * 64 + ct * 32 + 8 * q + 4 * hi);
         }
 #pragma unroll
-        for (int call = 0; call < 4; ++call) {
+        for (int call = 0; call < ((PRG_WS_EXP & 512) ? 0 : 4); ++call) {
           // set (call + 2) % 4 was consumed two calls ago: refill it for the call two ahead (this phase's calls 2,3
           // or the NEXT phase's calls 0,1 — its weight tile and halo are already visible in LDS)
           if (call < 2) {
@@ -674,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
                 w.x = pack_bf16(v[0], v[1]);
                 w.y = pack_bf16(v[2], v[3]);
                 // row = pixel, 16-byte unit = ct*4 + q (XOR-swizzled), half = hi
-                const int px = pt * 32 + l31;
+                const int px = pt * 32 + lpx;
                 *reinterpret_cast<uint2*>(stg + px * 128 + (((ct * 4 + q) ^ ((px >> 1) & 7)) << 4) + hi * 8) = w;
               }
               V[ct * 4 + q] = s;
@@ -746,6 +792,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     Producer<TH, TW, BN, PRO> Pv(L, smem, tid - 256, tmap, nsteps, nchunks, trace);
     Pv.prologue();
     phase_barrier(trace);
+    if constexpr ((PRG_WS_EXP & 256) != 0) {
+      for (int g = 0; g < nsteps; ++g)
+        for (int p = 0; p < 9; ++p) phase_barrier(trace);          // timing experiment: consumers alone
+      phase_barrier(trace);
+      return;
+    }
 #pragma unroll 1
     for (int g = 0; g < nsteps; g += 2) {
       Pv.template step<0, true>(g);
