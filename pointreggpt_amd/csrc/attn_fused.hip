@@ -10,8 +10,10 @@
 //   la_fin    slabs summed in fixed order, ctx / sum / N * 32^-1/2 -> bf16, stored in the k-slot order la_out's MFMA wants
 //   la_out    x -> LayerNorm -> q -> softmax_d -> out = ctx^T q -> y = Wout out + b -> LayerNorm -> + x     -> store
 //
-// Tiles are 64 pixels; a block of four waves keeps the projection weights in LDS (rows padded to C+8 / 136 bf16 so the
-// 16 lanes of a ds_read_b128 group hit distinct banks) and walks kTilesPerBlock tiles of one image.  Wave w owns head w.
+// Tiles are 64 pixels; a block of four waves walks kTilesPerBlock tiles of one image.  Wave w owns head w and keeps its
+// rows of the projection weights in registers as MFMA fragments (no LDS copy: 29-46 KB of LDS per block, several
+// blocks per CU); the LDS tiles have rows padded to C+8 / 136 / 72 bf16 so the 16 lanes of a ds_read_b128 group hit
+// distinct banks.
 // MFMA: v_mfma_f32_32x32x16_bf16, D[i][j] = sum_k A[i][k] B[k][j]; lane l supplies A[l&31][8(l>>5)..+7] and
 // B[8(l>>5)..+7][l&31] and receives D[(r&3) + 8(r>>2) + 4(l>>5)][l&31] in register r.
 // The LayerNorm gain of PreNorm is folded into the projection weights on the host (unet.hip).
@@ -113,6 +115,15 @@ __device__ inline bf16x8 frag(const __bf16* rows, int ld, int l31, int hi, int k
   return *reinterpret_cast<const bf16x8*>(rows + l31 * ld + kk * 16 + hi * 8);
 }
 
+// k-step fragments of 32 rows [r0, r0 + 32) of a row-major [.][COLS] bf16 matrix, straight from global memory into
+// registers (each wave keeps its own rows for the whole block: no LDS copy, so several blocks fit on a CU)
+template <int COLS>
+__device__ inline void load_wfrags(bf16x8 (&w)[COLS / 16], const bf16_t* mat, int r0, int l31, int hi) {
+#pragma unroll
+  for (int kk = 0; kk < COLS / 16; ++kk)
+    w[kk] = *reinterpret_cast<const bf16x8*>(mat + (size_t)(r0 + l31) * COLS + kk * 16 + hi * 8);
+}
+
 __device__ inline f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -128,13 +139,13 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
                                                             float* __restrict__ pmax, int N, int nslab) {
   using G = Geo<C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* Wl = reinterpret_cast<__bf16*>(smem);      // k rows of the projection: [128][LDW]
-  __bf16* xn = Wl + kHid * G::LDW;                   // [64][LDW]
+  __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int ntiles = (N + kTP - 1) / kTP;
   const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
-  stage_rows<C, G::LDW>(Wl, wqkv + (size_t)kHid * C, kHid);
+  bf16x8 wk[G::KK];                                    // k rows 32 wave .. + 32 of the projection
+  load_wfrags<C>(wk, wqkv, kHid + 32 * wave, l31, hi);
   float m = -INFINITY;                                 // column 32 wave + l31, this lane's pixel rows
   XTile<C> xt;
   if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
@@ -145,10 +156,9 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
     f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll
     for (int kk = 0; kk < G::KK; ++kk) {
-      const bf16x8 wf = frag(Wl + 32 * wave * G::LDW, G::LDW, l31, hi, kk);
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk), wf, acc[pt], 0, 0, 0);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk), wk[kk], acc[pt], 0, 0, 0);
     }
     const int valid = min(kTP, N - t * kTP);
 #pragma unroll
@@ -173,8 +183,7 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
                                                            float* __restrict__ sump, int N, int nslab) {
   using G = Geo<C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* Wl = reinterpret_cast<__bf16*>(smem);      // [256][LDW]: k rows then v rows
-  __bf16* xn = Wl + 2 * kHid * G::LDW;               // [64][LDW]
+  __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]
   __bf16* pv = xn + kTP * G::LDW;                    // per wave: pT [32][kLdP], vT [32][kLdP]
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -182,7 +191,9 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
   __bf16* vT = pT + 32 * kLdP;
   const int ntiles = (N + kTP - 1) / kTP;
   const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
-  stage_rows<C, G::LDW>(Wl, wqkv + (size_t)kHid * C, 2 * kHid);
+  bf16x8 wk[G::KK], wv[G::KK];                         // k and v rows of head `wave`
+  load_wfrags<C>(wk, wqkv, kHid + 32 * wave, l31, hi);
+  load_wfrags<C>(wv, wqkv, 2 * kHid + 32 * wave, l31, hi);
   float m = -INFINITY;                                 // global column maximum: fixed-order reduce of the slab maxima
   for (int s2 = 0; s2 < nslab; ++s2) m = fmaxf(m, pmax[((size_t)b * nslab + s2) * kHid + 32 * wave + l31]);
   f32x16 ctx = zero16();                               // rows d, column e = l31 of head `wave`
@@ -196,13 +207,11 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
     f32x16 ka[2] = {zero16(), zero16()}, va[2] = {zero16(), zero16()};
 #pragma unroll
     for (int kk = 0; kk < G::KK; ++kk) {
-      const bf16x8 wk = frag(Wl + 32 * wave * G::LDW, G::LDW, l31, hi, kk);
-      const bf16x8 wv = frag(Wl + (kHid + 32 * wave) * G::LDW, G::LDW, l31, hi, kk);
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
         const bf16x8 xf = frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk);
-        ka[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wk, ka[pt], 0, 0, 0);
-        va[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv, va[pt], 0, 0, 0);
+        ka[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wk[kk], ka[pt], 0, 0, 0);
+        va[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv[kk], va[pt], 0, 0, 0);
       }
     }
     const int valid = min(kTP, N - t * kTP);
@@ -272,17 +281,15 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   constexpr int RT = C / 32;                 // 32-channel row tiles of y
   constexpr int NA = RT / 2;                 // y accumulators per wave (RT x 2 pixel tiles over 4 waves)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* Wq = reinterpret_cast<__bf16*>(smem);      // [128][LDW]
-  __bf16* Wo = Wq + kHid * G::LDW;                   // [C][kLdO]
-  __bf16* xn = Wo + C * kLdO;                        // [64][LDW]   (later: the normalised y tile)
+  __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]   (later: the normalised y tile)
   __bf16* ot = xn + kTP * G::LDW;                    // [64][kLdO]  attention output, pixel-major
   float* lnb = reinterpret_cast<float*>(ot + kTP * kLdO);   // [64][4][2] LayerNorm partial sums
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int ntiles = (N + kTP - 1) / kTP;
   const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
-  stage_rows<C, G::LDW>(Wq, wqkv, kHid);
-  stage_rows<kHid, kLdO>(Wo, wout, C);
+  bf16x8 wq[G::KK];                                    // q rows of head `wave`
+  load_wfrags<C>(wq, wqkv, 32 * wave, l31, hi);
   // ctx^T rows e = l31 of head `wave`; k-slot s of half hi in k-step i is d = 16 i + 8 (s >> 2) + 4 hi + (s & 3):
   // exactly the d of q-accumulator register 8 i + s of a lane in half hi, so q feeds the MFMA without any shuffle
   bf16x8 ca[2];
@@ -296,6 +303,8 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
     if (RT == 2) { yrt[a] = wave & 1; ypt[a] = wave >> 1; }
     else { yrt[a] = wave; ypt[a] = a; }
   }
+  bf16x8 wo[kHid / 16];                                // to_out rows of this wave's y row tile (the same for all its accumulators)
+  load_wfrags<kHid>(wo, wout, yrt[0] * 32, l31, hi);
   XTile<C> xt;
   if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
   for (int t = t0; t < t1; ++t) {
@@ -308,10 +317,9 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
     f32x16 qa[2] = {zero16(), zero16()};
 #pragma unroll
     for (int kk = 0; kk < G::KK; ++kk) {
-      const bf16x8 wf = frag(Wq + 32 * wave * G::LDW, G::LDW, l31, hi, kk);
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
-        qa[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk), qa[pt], 0, 0, 0);
+        qa[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[kk], frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk), qa[pt], 0, 0, 0);
     }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
     for (int kk = 0; kk < kHid / 16; ++kk) {
 #pragma unroll
       for (int a = 0; a < NA; ++a)
-        ya[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Wo + yrt[a] * 32 * kLdO, kLdO, l31, hi, kk),
+        ya[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[kk],
                                                         frag(ot + ypt[a] * 32 * kLdO, kLdO, l31, hi, kk), ya[a], 0, 0, 0);
     }
 #pragma unroll
@@ -419,11 +427,11 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
 }
 
 template <int C>
-size_t lds_kmax() { return (size_t)(kHid + kTP) * Geo<C>::LDW * 2; }
+size_t lds_kmax() { return (size_t)kTP * Geo<C>::LDW * 2; }
 template <int C>
-size_t lds_ctx() { return (size_t)(2 * kHid + kTP) * Geo<C>::LDW * 2 + (size_t)4 * 2 * 32 * kLdP * 2; }
+size_t lds_ctx() { return (size_t)kTP * Geo<C>::LDW * 2 + (size_t)4 * 2 * 32 * kLdP * 2; }
 template <int C>
-size_t lds_out() { return (size_t)(kHid + kTP) * Geo<C>::LDW * 2 + (size_t)(C + kTP) * kLdO * 2 + (size_t)kTP * 4 * 2 * 4; }
+size_t lds_out() { return (size_t)kTP * Geo<C>::LDW * 2 + (size_t)kTP * kLdO * 2 + (size_t)kTP * 4 * 2 * 4; }
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
