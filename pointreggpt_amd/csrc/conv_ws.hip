@@ -79,24 +79,31 @@ __device__ inline float fast_silu(float x) {
 // arrives at and when it leaves every phase barrier of that launch (tools/ws_trace.py shows who the others wait for).
 // The record is stores only (device memory, count kept in a register): a load would put its latency into every phase
 // of the traced workgroup.  Stores raise vmcnt, which only makes the producers' counted waits stricter.
+// Compiled in only with -DPRG_WS_TRACE_BUILD=1 (`make trace` -> libprg_hip_trace.so): the checks alone are a dozen
+// instructions per phase and wave.
+#ifndef PRG_WS_TRACE_BUILD
+#define PRG_WS_TRACE_BUILD 0
+#endif
+constexpr bool kTrace = PRG_WS_TRACE_BUILD != 0;
 constexpr int kTraceStride = 4096;   // u64 slots per wave: [0] = count, then (arrive, leave) pairs
 
 struct TraceCtx {
   unsigned long long* p;   // this wave's slots, or nullptr
   int n;
   __device__ __forceinline__ TraceCtx(unsigned long long* base)
-      : p(base != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 ? base + (threadIdx.x >> 6) * kTraceStride : nullptr),
+      : p(kTrace && base != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 ? base + (threadIdx.x >> 6) * kTraceStride
+                                                                                   : nullptr),
         n(0) {}
   // two extra time stamps inside the phase that ends at barrier n (producers: after the weight wait, before the LDS drain)
   __device__ __forceinline__ void mark(int which) {
-    if (p != nullptr && n < 1000) p[kTraceStride / 2 + 2 * n + which] = clock64();
+    if (kTrace && p != nullptr && n < 1000) p[kTraceStride / 2 + 2 * n + which] = clock64();
   }
 };
 
 template <bool LDS_DONE = true>   // wait for this wave's own LDS operations first (writers always must)
 __device__ __forceinline__ void phase_barrier(TraceCtx& tr) {
   if constexpr (LDS_DONE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const bool rec = tr.p != nullptr && tr.n < (kTraceStride - 4) / 2;
+  const bool rec = kTrace && tr.p != nullptr && tr.n < (kTraceStride - 4) / 2;
   if (rec) tr.p[1 + 2 * tr.n] = clock64();
   if (!(PRG_WS_EXP & 4096)) __builtin_amdgcn_s_barrier();
   if (rec) {
@@ -268,6 +275,10 @@ struct Producer {
   StepInfo sA, sB, sC, dr;
   int gC;                    // step index of sC (clamped to the last step)
   bool drain_on;
+  const char* wptr;          // running address of the weight tile being issued (advances one tap per phase)
+  size_t w_tapb;             // bytes between consecutive taps of the packed weights
+  char* dr_base;             // output address of pixel (y0, x0), channel tn*BN of the tile being drained
+  size_t dr_rowb;            // output bytes per image row
   char* stage_rd;            // this thread's 16-byte unit of the consumers' output stage (row ptid >> 3 of a 32-row half)
   int dr_r0;                 // ... and its row
 
@@ -283,6 +294,10 @@ struct Producer {
     hvalid = hvalid_nxt = 0;
     ld_ca = ld_cb = nullptr;
     drain_on = false;
+    w_tapb = (size_t)d.kchunks * d.CoutPad * 64;
+    dr_rowb = (size_t)d.Wout * d.Cout * 2;
+    dr_base = nullptr;
+    wptr = nullptr;
     dr_r0 = ptid >> 3;
     stage_rd = smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES + G::RED_BYTES + dr_r0 * 128 + (((ptid & 7) ^ ((dr_r0 >> 1) & 7)) << 4);
     sA.chunk = 0;
@@ -323,11 +338,13 @@ struct Producer {
       }
     }
   }
+  __device__ __forceinline__ const char* w_tile(int tap, int chunk, int tn) const {
+    return reinterpret_cast<const char*>(L.w) +
+           ((PRG_WS_EXP & 1024) ? 0   // timing experiment: always the same (L1-resident) weight tile
+                                : ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tn * BN) * 64);
+  }
   template <int SET>
-  __device__ __forceinline__ void w_issue(int tap, int chunk, int tn) {
-    const char* base = reinterpret_cast<const char*>(L.w) +
-                       ((PRG_WS_EXP & 1024) ? 0   // timing experiment: always the same (L1-resident) weight tile
-                                            : ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tn * BN) * 64);
+  __device__ __forceinline__ void w_issue(const char* base) {
     // rows row + 32 j are 32 * 32 * 2 = 2048 bytes apart (immediate offsets reach 4095: second base for j >= 2)
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][0]) : "v"(w_voff), "s"(base) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wset[SET][1]) : "v"(w_voff), "s"(base) : "memory");
@@ -436,8 +453,7 @@ struct Producer {
     const u32x4 v = *reinterpret_cast<const u32x4*>(stage_rd + w * 8192 + (PH & 1) * 32 * 128);
     // pixels wm*64 + (PH&1)*32 + [0,32) of the tile: whole tile rows, so the row part is wave-uniform
     constexpr int prow = (wm * 64 + (PH & 1) * 32) / TW;
-    const int64_t m0 = ((int64_t)dr.b * Hl + dr.y0 + prow) * Wl + dr.x0;
-    char* base = reinterpret_cast<char*>(L.out) + (m0 * d.Cout + dr.tn * BN + wn * 64) * 2;
+    char* base = dr_base + prow * dr_rowb + wn * 128;
     asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(dr_voff), "v"(v), "s"(base) : "memory");
   }
   // phase PH handles units K = PH * UPH + J.  CSW = coefficient set of the halo being written
@@ -484,8 +500,11 @@ struct Producer {
       if constexpr (LIVE) trace.mark(0);
       w_write<SET>(SET);
     }
-    if constexpr (PH + 5 < 9) w_issue<SET>(PH + 5, chunk0, tn0);
-    else w_issue<SET>(PH + 5 - 9, chunk1, tn1);
+    // tile ph + 5: taps 5..8 of this step, then taps 0..4 of the next one (a new tile address only at tap 0)
+    if constexpr (!LIVE) wptr = PH + 5 < 9 ? w_tile(PH + 5, chunk0, tn0) : w_tile(PH + 5 - 9, chunk1, tn1);
+    else if constexpr (PH == 4) wptr = w_tile(0, chunk1, tn1);
+    else if (!(PRG_WS_EXP & 1024)) wptr += w_tapb;
+    w_issue<SET>(wptr);
     if constexpr (PH < 8) unit_pass<PH, (GP + 1) & 1, LIVE>(g, wr);
     if constexpr (LIVE && PH < 8) {
       if (drain_on) drain_unit<PH>();
@@ -502,17 +521,22 @@ struct Producer {
     if constexpr (LIVE) {
       const int c0 = sA.chunk, t0 = sA.tn, c1 = sB.chunk, t1 = sB.tn;
       drain_on = g > 0 && sA.chunk == 0;          // the previous step finished tile `dr`
-      issue_setup(sC);
-      issue_coeffs<GP>();
+      issue_coeffs<GP>();                         // halo g+2: its context was set up during the previous phase 8
       phase<GP, 0, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 1, LIVE>(g, wr, c0, t0, c1, t1);
       phase<GP, 2, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 3, LIVE>(g, wr, c0, t0, c1, t1);
       phase<GP, 4, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 5, LIVE>(g, wr, c0, t0, c1, t1);
       phase<GP, 6, LIVE>(g, wr, c0, t0, c1, t1); phase<GP, 7, LIVE>(g, wr, c0, t0, c1, t1);
-      phase<GP, 8, LIVE>(g, wr, c0, t0, c1, t1);
+      // Phase 8 has no halo units and no drain: it carries the step bookkeeping (all wave-uniform scalar work) so that
+      // phase 0 is not the one everybody waits for.
+      hvalid = hvalid_nxt;
       dr = sA;
+      dr_base = reinterpret_cast<char*>(L.out) +
+                ((((int64_t)dr.b * Hl + dr.y0) * Wl + dr.x0) * d.Cout + dr.tn * BN) * 2;
       sA = sB;
       sB = sC;
       advance(sC);
+      issue_setup(sC);
+      phase<GP, 8, LIVE>(g, wr, c0, t0, c1, t1);
     } else {
       // step -1: weights of step 0 (placeholders where the tile index is negative), halo of step 1
       const int c0 = sA.chunk, t0 = sA.tn;
@@ -523,8 +547,9 @@ struct Producer {
       phase<GP, 4, LIVE>(g, wr, c0, t0, c0, t0); phase<GP, 5, LIVE>(g, wr, c0, t0, c0, t0);
       phase<GP, 6, LIVE>(g, wr, c0, t0, c0, t0); phase<GP, 7, LIVE>(g, wr, c0, t0, c0, t0);
       phase<GP, 8, LIVE>(g, wr, c0, t0, c0, t0);
+      hvalid = hvalid_nxt;
+      issue_setup(sC);                            // context of halo 2, issued during step 0
     }
-    hvalid = hvalid_nxt;
   }
   template <int K>
   __device__ __forceinline__ void prologue_issue() {
@@ -827,7 +852,7 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
   static const int trace_at = [] { const char* e = std::getenv("PRG_WS_TRACE"); return e ? std::atoi(e) : -1; }();
   static int launch_no = 0;
   unsigned long long* tbuf = nullptr;
-  if (trace_at >= 0 && launch_no++ == trace_at) {
+  if (kTrace && trace_at >= 0 && launch_no++ == trace_at) {
     if (hipMalloc(reinterpret_cast<void**>(&tbuf), 8 * kTraceStride * sizeof(unsigned long long)) == hipSuccess) {
       (void)hipMemsetAsync(tbuf, 0, 8 * kTraceStride * sizeof(unsigned long long), s);
       (void)hipStreamSynchronize(s);
