@@ -447,14 +447,22 @@ struct Producer {
   // the next step's phases 0..7 every producer thread moves one 16-byte unit per phase to HBM (full 128-byte rows per
   // 8 lanes), so the tile's write burst overlaps the next tile's MFMAs instead of stalling the consumers.
   template <int PH>
-  __device__ __forceinline__ void drain_unit() {
+  __device__ __forceinline__ u32x4 drain_read() {
     constexpr int w = PH >> 1;                                   // consumer wave whose stage this phase drains
+    return *reinterpret_cast<const u32x4*>(stage_rd + w * 8192 + (PH & 1) * 32 * 128);
+  }
+  template <int PH>
+  __device__ __forceinline__ void drain_store(const u32x4& v) {
+    constexpr int w = PH >> 1;
     constexpr int wm = w / G::WAVES_N, wn = w % G::WAVES_N;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(stage_rd + w * 8192 + (PH & 1) * 32 * 128);
     // pixels wm*64 + (PH&1)*32 + [0,32) of the tile: whole tile rows, so the row part is wave-uniform
     constexpr int prow = (wm * 64 + (PH & 1) * 32) / TW;
     char* base = dr_base + prow * dr_rowb + wn * 128;
     asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(dr_voff), "v"(v), "s"(base) : "memory");
+  }
+  template <int PH>
+  __device__ __forceinline__ void drain_unit() {
+    drain_store<PH>(drain_read<PH>());
   }
   // phase PH handles units K = PH * UPH + J.  CSW = coefficient set of the halo being written
   // A phase's units are waited for together, transformed and written together (so the compiler can interleave
@@ -463,7 +471,7 @@ struct Producer {
   template <int PH, int J, int CSW>
   __device__ __forceinline__ void units_wait() {
     if constexpr (J < UPH && PH * UPH + J < KU) {
-      wait_unit<PH * UPH + J, CSW, U_YOUNGER - J>();
+      wait_unit<PH * UPH + J, CSW, U_YOUNGER - NWL - J>();   // this phase's weight tile is issued after the LDS work
       units_wait<PH, J + 1, CSW>();
     }
   }
@@ -481,33 +489,38 @@ struct Producer {
       units_issue<PH, J + 1>();
     }
   }
-  template <int PH, int CSW, bool LIVE>
-  __device__ __forceinline__ void unit_pass(int g, bool wr) {
-    if constexpr (LIVE) {
-      units_wait<PH, 0, CSW>();
-      units_write<PH, 0, CSW>(g, wr);
-    }
-    units_issue<PH, 0>();
-  }
   // tile ph + 5 lies in this step (PH + 5 < 9) or the next one: its (chunk, tn) are per-step values
   template <int GP, int PH, bool LIVE>
   __device__ __forceinline__ void phase(int g, bool wr, int chunk0, int tn0, int chunk1, int tn1) {
     constexpr int SET = (PH + 2) % 3;            // (9 g + PH + 2) % 3: register set == ring slot of tile ph + 2
     // the prologue's issue-only step: from phase 3 on the set holds an earlier (placeholder, then real) tile and the
     // three phases behind it are regular, so the steady-state wait + write applies (the consumers have not started)
+    // Order inside a phase: everything that touches LDS first (so its latency runs under the global issues and is
+    // gone by the barrier), the drain's stage read first of all; then the global issues in the periodic order
+    // [weight tile, halo units]; the drain store last.
+    u32x4 dv;
+    bool draining = false;
+    if constexpr (LIVE && PH < 8) {
+      draining = drain_on;
+      if (draining) dv = drain_read<PH>();
+    }
     if constexpr (LIVE || PH >= 3) {
       w_wait<SET, w_younger(PH)>();
       if constexpr (LIVE) trace.mark(0);
       w_write<SET>(SET);
+    }
+    if constexpr (LIVE && PH < 8) {
+      units_wait<PH, 0, (GP + 1) & 1>();
+      units_write<PH, 0, (GP + 1) & 1>(g, wr);
     }
     // tile ph + 5: taps 5..8 of this step, then taps 0..4 of the next one (a new tile address only at tap 0)
     if constexpr (!LIVE) wptr = PH + 5 < 9 ? w_tile(PH + 5, chunk0, tn0) : w_tile(PH + 5 - 9, chunk1, tn1);
     else if constexpr (PH == 4) wptr = w_tile(0, chunk1, tn1);
     else if (!(PRG_WS_EXP & 1024)) wptr += w_tapb;
     w_issue<SET>(wptr);
-    if constexpr (PH < 8) unit_pass<PH, (GP + 1) & 1, LIVE>(g, wr);
+    if constexpr (PH < 8) units_issue<PH, 0>();
     if constexpr (LIVE && PH < 8) {
-      if (drain_on) drain_unit<PH>();
+      if (draining) drain_store<PH>(dv);
     }
     if constexpr (LIVE) trace.mark(1);
     if constexpr (LIVE) phase_barrier(trace);
