@@ -442,6 +442,125 @@ int set_lds(K kernel, size_t bytes) {
 
 int la_slabs(int N) { return ceil_div(ceil_div(N, kTP), kTilesPerBlock); }
 
+// =====================================================================================================
+// ResnetBlock tail with the 1x1 res_conv folded in (sd:731-734):
+//   out = SiLU(h * A[b][c] + Bc[b][c]) + Wres . cat[s0, s1] + bres          (A, Bc: GroupNorm folded by gn_coeff)
+// Unfused this is a 1x1 conv launch (reads both sources, writes res) plus the flat pass (reads h and res, writes out);
+// fused, res never exists in HBM: -268 MB per level-0 block.  64-pixel tiles; the source tile and the h tile go
+// through LDS (coalesced 16-byte global accesses on both sides), Wres lives in registers as MFMA fragments, the
+// accumulator has pixels as columns so a lane owns four consecutive channels of one pixel.
+// =====================================================================================================
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void resblock_tail_fused_kernel(const bf16_t* __restrict__ h, const float* __restrict__ A,
+                                                                  const float* __restrict__ Bc, const bf16_t* __restrict__ s0,
+                                                                  int C0, const bf16_t* __restrict__ s1, int C1,
+                                                                  const bf16_t* __restrict__ wres, const float* __restrict__ bres,
+                                                                  bf16_t* __restrict__ out, int N) {
+  constexpr int LDX = CIN + 8, LDH = COUT + 8;
+  constexpr int RT = COUT / 32, NA = RT / 2;          // row tiles of 32 channels; accumulators per wave
+  constexpr int XV = CIN / 32, HV = COUT / 32;        // 16-byte vectors per thread of the source / h tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* xs = reinterpret_cast<__bf16*>(smem);       // [64][LDX]
+  __bf16* hs = xs + kTP * LDX;                        // [64][LDH]
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int ntiles = (N + kTP - 1) / kTP;
+  const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
+  const int yrt = RT == 2 ? (wave & 1) : wave;
+  int ypt[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) ypt[a] = RT == 2 ? (wave >> 1) : a;
+  bf16x8 wr[CIN / 16];
+  load_wfrags<CIN>(wr, wres, yrt * 32, l31, hi);
+  // this lane's 16 channels: yrt*32 + 8 g4 + 4 hi + {0..3}
+  float4 ca[4], cb[4], cr[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int c0 = yrt * 32 + 8 * g4 + 4 * hi;
+    ca[g4] = *reinterpret_cast<const float4*>(A + (size_t)b * COUT + c0);
+    cb[g4] = *reinterpret_cast<const float4*>(Bc + (size_t)b * COUT + c0);
+    cr[g4] = *reinterpret_cast<const float4*>(bres + c0);
+  }
+  uint4 xv[XV], hv[HV];
+  auto load_tile = [&](int t) {
+    const int valid = min(kTP, N - t * kTP);
+    const int64_t pix = (int64_t)b * N + (int64_t)t * kTP + row;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int c = (part + 4 * i) * 8;
+      xv[i] = row < valid ? (c < C0 ? *reinterpret_cast<const uint4*>(s0 + pix * C0 + c)
+                                    : *reinterpret_cast<const uint4*>(s1 + pix * C1 + (c - C0)))
+                          : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < HV; ++i)
+      hv[i] = row < valid ? *reinterpret_cast<const uint4*>(h + pix * COUT + (part + 4 * i) * 8) : make_uint4(0, 0, 0, 0);
+  };
+  if (t0 < t1) load_tile(t0);
+  for (int t = t0; t < t1; ++t) {
+    const int valid = min(kTP, N - t * kTP);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) *reinterpret_cast<uint4*>(xs + row * LDX + (part + 4 * i) * 8) = xv[i];
+#pragma unroll
+    for (int i = 0; i < HV; ++i) *reinterpret_cast<uint4*>(hs + row * LDH + (part + 4 * i) * 8) = hv[i];
+    __syncthreads();                                                                            // (1) tiles staged
+    if (t + 1 < t1) load_tile(t + 1);
+    f32x16 ya[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) ya[a] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < CIN / 16; ++kk)
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        ya[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[kk], frag(xs + ypt[a] * 32 * LDX, LDX, l31, hi, kk), ya[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int px = ypt[a] * 32 + l31;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        __bf16* hp = hs + px * LDH + yrt * 32 + 8 * g4 + 4 * hi;
+        const uint2 hw = *reinterpret_cast<const uint2*>(hp);
+        const float a4[4] = {ca[g4].x, ca[g4].y, ca[g4].z, ca[g4].w};
+        const float b4[4] = {cb[g4].x, cb[g4].y, cb[g4].z, cb[g4].w};
+        const float r4[4] = {cr[g4].x, cr[g4].y, cr[g4].z, cr[g4].w};
+        const float hx[4] = {bf_lo(hw.x), bf_hi(hw.x), bf_lo(hw.y), bf_hi(hw.y)};
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = Elem<bf16_t>::silu(fmaf(hx[j], a4[j], b4[j])) + (ya[a][4 * g4 + j] + r4[j]);
+        uint2 w;
+        w.x = pack2(y[0], y[1]);
+        w.y = pack2(y[2], y[3]);
+        *reinterpret_cast<uint2*>(hp) = w;            // each (pixel, channel quad) is owned by exactly one lane
+      }
+    }
+    __syncthreads();                                                                            // (2) out tile in hs
+    if (row < valid) {
+#pragma unroll
+      for (int i = 0; i < HV; ++i)
+        *reinterpret_cast<uint4*>(out + ((int64_t)b * N + (int64_t)t * kTP + row) * COUT + (part + 4 * i) * 8) =
+            *reinterpret_cast<const uint4*>(hs + row * LDH + (part + 4 * i) * 8);
+    }
+    __syncthreads();                                                                            // (3) tiles free
+  }
+}
+
+template <int CIN, int COUT>
+int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1, int C1,
+                const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, hipStream_t s) {
+  const size_t lds = (size_t)kTP * (CIN + 8 + COUT + 8) * 2;
+  static bool attr = false;
+  if (!attr) {
+    int rc = set_lds(&resblock_tail_fused_kernel<CIN, COUT>, lds);
+    if (rc) return rc;
+    attr = true;
+  }
+  resblock_tail_fused_kernel<CIN, COUT><<<dim3(la_slabs(N), B), 256, lds, s>>>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, N);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+
 template <int C>
 int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias, const float* out_g, bf16_t* out,
              float* ws, int B, int N, hipStream_t s) {
@@ -471,6 +590,20 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
 }
 
 }  // namespace
+
+bool resblock_tail_fused_supported(int C0, int C1, int Cout) {
+  const int cin = C0 + C1;
+  return C0 % 8 == 0 && C1 % 8 == 0 && ((cin == 128 && Cout == 64) || (cin == 256 && Cout == 128));
+}
+
+// out (B, N, Cout) <- SiLU(h * A + Bc) + wres [Cout][C0+C1] . cat[s0 (B,N,C0), s1 (B,N,C1)] + bres.  out may alias h.
+int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1,
+                               int C1, const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, int Cout,
+                               hipStream_t s) {
+  PRG_CHECK(resblock_tail_fused_supported(C0, C1, Cout) && bres, "fused resblock tail: unsupported shape");
+  if (Cout == 64) return launch_tail<128, 64>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
+  return launch_tail<256, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
+}
 
 bool linattn_fused_supported(int C) { return C == 64 || C == 128; }
 

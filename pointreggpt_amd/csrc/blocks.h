@@ -55,6 +55,12 @@ size_t linattn_fused_ws_floats(int B, int N);
 int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias,
                                   const float* out_g, bf16_t* out, float* ws, int B, int N, int C, hipStream_t s);
 
+// ResnetBlock tail with the 1x1 res_conv folded in (attn_fused.hip), bf16 path.  wres: [Cout][C0+C1] bf16.
+bool resblock_tail_fused_supported(int C0, int C1, int Cout);
+int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1,
+                               int C1, const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, int Cout,
+                               hipStream_t s);
+
 // Attention core (sd:789-795) on qkv NHWC (B, N, 384) -> out NHWC (B, N, 128).
 template <typename T>
 int launch_full_attention(const T* qkv, T* out, int B, int N, hipStream_t s);

@@ -72,6 +72,7 @@ struct ResP {
   int ss_off = 0;                  // column offset of this block's (scale|shift) in the conditioning row
   ConvP c1, c2, res;
   int64_t g1 = 0, b1 = 0, g2 = 0, b2 = 0;
+  int64_t fw_res = -1;             // bf16 element offset of the raw res_conv weight in the fused-kernel arena (-1: unfused)
   bool has_res = false;
 };
 struct AttnP {
@@ -344,7 +345,12 @@ struct UnetImpl : prg_unet {
     if ((rc = conv(r.c2, h1, r.cout, nullptr, 0, B, H, Wd, 1, 1, 0, o2, out, s))) return rc;
     if (!arena.dry && ns2 == 0 && (rc = launch_gn_stats<T>(out, part2, B, HW, r.cout, G, &ns2, s))) return rc;
     const T* skip = s0;
-    if (r.has_res) {
+    bool fused_tail = false;
+    if constexpr (std::is_same<T, bf16_t>::value)
+      fused_tail = r.has_res && r.fw_res >= 0 && d_attn && resblock_tail_fused_supported(C0, C1, r.cout);
+    if (fused_tail) {
+      // res_conv folded into the tail pass below: `res` is never materialised
+    } else if (r.has_res) {
       if ((rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, ConvOpt(), res, s))) return rc;
       skip = res;
     } else {
@@ -353,6 +359,14 @@ struct UnetImpl : prg_unet {
     if (!arena.dry) {
       // GroupNorm + SiLU + skip: fold the statistics into per-(image, channel) coefficients, then one flat pass
       if ((rc = launch_gn_coeff(part2, ns2, gn_params(r.g2, r.b2, nullptr, 0), coefA, coefB, B, HW, r.cout, G, s))) return rc;
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        if (fused_tail) {
+          rc = launch_resblock_tail_fused(out, coefA, coefB, s0, C0, s1, C1, d_attn + r.fw_res, F(r.res.b_off), out, B, HW,
+                                          r.cout, s);
+          arena.reset(m);
+          return rc;
+        }
+      }
       if ((rc = launch_affine_silu<T>(out, coefA, coefB, skip, out, B, HW, r.cout, s))) return rc;
     }
     arena.reset(m);
@@ -636,6 +650,15 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
     };
     for (auto& lv : u->lay.downs) add(lv.at);
     for (auto& lv : u->lay.ups) add(lv.at);
+    // fused ResnetBlock tail: raw res_conv weights [Cout][Cin] as bf16
+    auto add_res = [&](ResP& r) {
+      if (!r.has_res || r.res.b_off < 0 || !resblock_tail_fused_supported(r.cin / 2, r.cin - r.cin / 2, r.cout)) return;
+      aw.resize((aw.size() + 63) / 64 * 64);
+      r.fw_res = (int64_t)aw.size();
+      for (size_t i = 0; i < (size_t)r.cout * r.cin; ++i) aw.push_back(f32_to_bf16(weights[r.res.w_flat + i]));
+    };
+    for (auto& lv : u->lay.ups) { add_res(lv.r0); add_res(lv.r1); }
+    add_res(u->lay.fin);
     if (!aw.empty()) {
       if (hipMalloc(&u->d_attn, aw.size() * sizeof(bf16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(attention weights)");
       PRG_HIP(hipMemcpy(u->d_attn, aw.data(), aw.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
