@@ -260,7 +260,21 @@ __global__ __launch_bounds__(256) void la_fin_fused_kernel(const float* __restri
   for (int idx = threadIdx.x; idx < 1024; idx += 256) {
     const int d = idx >> 5, e = idx & 31;
     float c = 0.0f, s = 0.0f;
-    for (int s2 = 0; s2 < nslab; ++s2) {
+    int s2 = 0;
+    for (; s2 + 8 <= nslab; s2 += 8) {          // loads of a group issued together; the sums stay in slab order
+      float cv[8], sv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        cv[u] = ctxp[(ph + s2 + u) * 1024 + idx];
+        sv[u] = sump[(ph + s2 + u) * 32 + d];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        c += cv[u];
+        s += sv[u];
+      }
+    }
+    for (; s2 < nslab; ++s2) {
       c += ctxp[(ph + s2) * 1024 + idx];
       s += sump[(ph + s2) * 32 + d];
     }

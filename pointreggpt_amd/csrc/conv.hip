@@ -677,6 +677,124 @@ template int launch_stem_conv<bf16_t>(const float*, const float*, const float*, 
                                       hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
+// stem on MFMA (bf16 path, Cin = 1, Cout = 64): the direct kernel above is VALU-bound (3136 FMA per pixel: 192 us at
+// B = 64, 128 x 128); as a GEMM with K = 7 kernel rows x 8 columns (column 7 and row 7 are zero weights) it is
+// HBM-bound on its 134 MB output.  x and the weights are split into bf16 hi + lo parts (x_hi W_hi + x_lo W_hi +
+// x_hi W_lo: ~16 significant bits, the fp32 input is NOT rounded to bf16).  A block owns 32 x 8 pixels: the input
+// window goes to LDS once, is expanded to P[row][px] = the 8 consecutive columns px-3 .. px+4 as one 16-byte
+// fragment (hi and lo), and each wave runs 12 MFMAs per 32-pixel row against register-resident weight fragments.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 stem_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float stem_f32x16;
+__device__ inline uint32_t pack_bf16x2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wf,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
+                                                        int W) {
+  constexpr int ROWS = 8, PR = ROWS + 7, RC = 40, LDS_ST = 72;
+  __shared__ float raw[(ROWS + 6) * RC];
+  __shared__ __attribute__((aligned(16))) __bf16 Ph[PR * 32 * 8];
+  __shared__ __attribute__((aligned(16))) __bf16 Pl[PR * 32 * 8];
+  __shared__ __attribute__((aligned(16))) __bf16 stage[64 * LDS_ST];
+  const int b = blockIdx.z, y0 = blockIdx.y * ROWS, x0 = blockIdx.x * 32, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  for (int i = tid; i < (ROWS + 6) * RC; i += 256) {
+    const int r = i / RC, c = i - r * RC;
+    const int yy = y0 - 3 + r, xx = x0 - 4 + c;
+    raw[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[((size_t)b * H + yy) * W + xx] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < PR * 32; e += 256) {
+    const int r = e >> 5, p = e & 31;
+    stem_bf16x8 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = r < ROWS + 6 ? raw[r * RC + p + 1 + j] : 0.0f;      // row ROWS+6 only meets the zero weight row
+      const __bf16 h16 = (__bf16)v;
+      vh[j] = h16;
+      vl[j] = (__bf16)(v - (float)h16);
+    }
+    *reinterpret_cast<stem_bf16x8*>(Ph + e * 8) = vh;
+    *reinterpret_cast<stem_bf16x8*>(Pl + e * 8) = vl;
+  }
+  const int rt = wave & 1, prow = wave >> 1;     // 32-channel row tile; which row of the row pair
+  stem_bf16x8 whi[4], wlo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    whi[kk] = *reinterpret_cast<const stem_bf16x8*>(wf + ((((size_t)rt * 2 + 0) * 4 + kk) * 64 + lane) * 8);
+    wlo[kk] = *reinterpret_cast<const stem_bf16x8*>(wf + ((((size_t)rt * 2 + 1) * 4 + kk) * 64 + lane) * 8);
+  }
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = bias[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+  __syncthreads();
+  for (int ti = 0; ti < ROWS / 2; ++ti) {
+    const int row = 2 * ti + prow;
+    stem_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int pr = row + 2 * kk + hi;           // kernel row 2 kk + hi of output row `row`
+      const stem_bf16x8 bh = *reinterpret_cast<const stem_bf16x8*>(Ph + (pr * 32 + l31) * 8);
+      const stem_bf16x8 bl = *reinterpret_cast<const stem_bf16x8*>(Pl + (pr * 32 + l31) * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[kk], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[kk], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[kk], bh, acc, 0, 0, 0);
+    }
+    // lane: pixel l31 of row `row`, channels rt*32 + 8 g4 + 4 hi + {0..3}
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      uint2 w;
+      w.x = pack_bf16x2(acc[4 * g4] + bv[4 * g4], acc[4 * g4 + 1] + bv[4 * g4 + 1]);
+      w.y = pack_bf16x2(acc[4 * g4 + 2] + bv[4 * g4 + 2], acc[4 * g4 + 3] + bv[4 * g4 + 3]);
+      *reinterpret_cast<uint2*>(stage + (prow * 32 + l31) * LDS_ST + rt * 32 + 8 * g4 + 4 * hi) = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + 256 * i;                // 512 16-byte vectors: pixel v >> 3, unit v & 7
+      const int px = v >> 3, u = v & 7;
+      const int yy = y0 + 2 * ti + (px >> 5), xx = x0 + (px & 31);
+      *reinterpret_cast<uint4*>(out + (((size_t)b * H + yy) * W + xx) * 64 + u * 8) =
+          *reinterpret_cast<const uint4*>(stage + px * LDS_ST + u * 8);
+    }
+    __syncthreads();
+  }
+}
+
+bool stem_conv_mfma_supported(int Cin, int Cout, int H, int W) { return Cin == 1 && Cout == 64 && W % 32 == 0 && H % 8 == 0; }
+
+// wf: [2 row tiles][hi | lo][4 k-steps][64 lanes][8] bf16 = the A fragments of W[co][kh][kw] (pack_stem_mfma_weights)
+int launch_stem_conv_mfma(const float* x, const bf16_t* wf, const float* bias, bf16_t* out, int B, int H, int W,
+                          hipStream_t s) {
+  PRG_CHECK(stem_conv_mfma_supported(1, 64, H, W) && x && wf && bias && out, "stem conv (MFMA): bad arguments");
+  stem_mfma_kernel<<<dim3(W / 32, H / 8, B), 256, 0, s>>>(x, wf, bias, out, H, W);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+void pack_stem_mfma_weights(const float* w /* [64][1][7][7] */, std::vector<bf16_t>& outv) {
+  outv.assign((size_t)2 * 2 * 4 * 64 * 8, f32_to_bf16(0.0f));
+  for (int rt = 0; rt < 2; ++rt)
+    for (int kk = 0; kk < 4; ++kk)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = rt * 32 + (lane & 31), kh = 2 * kk + (lane >> 5);
+        for (int j = 0; j < 7 && kh < 7; ++j) {
+          const float v = w[(size_t)co * 49 + kh * 7 + j];
+          const bf16_t h16 = f32_to_bf16(v);
+          const bf16_t l16 = f32_to_bf16(v - bf16_to_f32(h16));
+          outv[((((size_t)rt * 2 + 0) * 4 + kk) * 64 + lane) * 8 + j] = h16;
+          outv[((((size_t)rt * 2 + 1) * 4 + kk) * 64 + lane) * 8 + j] = l16;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------------
 // head: 1x1 conv to one channel (+ sigmoid), T NHWC -> float32 (sd:918 / dc:868-869)
 // ---------------------------------------------------------------------------------------------
 template <typename T>

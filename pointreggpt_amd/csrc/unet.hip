@@ -223,6 +223,7 @@ struct prg_unet {
   float* d_flat = nullptr;      // the float32 state_dict on device (biases, norm gains, MLPs read in place)
   void* d_packed = nullptr;     // packed conv weights of T
   float* d_stem = nullptr;      // stem weights [49*Cin][dim]
+  bf16_t* d_stem_frag = nullptr; // stem weights as MFMA fragments (bf16 path, Cin 1 -> 64)
   bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
   Arena arena;
   int resB = 0, resS = 0;
@@ -428,7 +429,14 @@ struct UnetImpl : prg_unet {
     const int d0 = L.cfg.dim;
     T* x0 = alloc<T>((size_t)B * S * S * d0);
     PRG_CHECK(arena.dry || x0, "workspace exhausted (stem)");
-    if (!arena.dry &&
+    bool stem_done = false;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (!arena.dry && d_stem_frag && stem_conv_mfma_supported(L.cfg.in_channels, d0, S, S)) {
+        if ((rc = launch_stem_conv_mfma(x_nchw, d_stem_frag, F(L.stem_b), x0, B, S, S, s))) return rc;
+        stem_done = true;
+      }
+    }
+    if (!arena.dry && !stem_done &&
         (rc = launch_stem_conv<T>(x_nchw, d_stem, F(L.stem_b), x0, B, L.cfg.in_channels, S, S, d0, s)))
       return rc;
     tap("init_conv", x0, B, d0, S, S);
@@ -634,6 +642,12 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
   PRG_HIP(hipMemcpy(u->d_flat, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   PRG_HIP(hipMemcpy(u->d_packed, packed.data(), packed.size() * sizeof(T), hipMemcpyHostToDevice));
   PRG_HIP(hipMemcpy(u->d_stem, stem.data(), stem.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (std::is_same<T, bf16_t>::value && L.cfg.in_channels == 1 && L.cfg.dim == 64) {
+    std::vector<bf16_t> sf;
+    pack_stem_mfma_weights(weights + L.stem_w, sf);
+    if (hipMalloc(&u->d_stem_frag, sf.size() * sizeof(bf16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(stem fragments)");
+    PRG_HIP(hipMemcpy(u->d_stem_frag, sf.data(), sf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  }
   if (std::is_same<T, bf16_t>::value && fused_attention_enabled()) {
     // fused linear attention (attn_fused.hip): to_qkv with the PreNorm gain folded in, to_out as is, both [out][in] bf16
     std::vector<bf16_t> aw;
@@ -792,6 +806,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_packed) hipFree(h->d_packed);
   if (h->d_stem) hipFree(h->d_stem);
   if (h->d_attn) hipFree(h->d_attn);
+  if (h->d_stem_frag) hipFree(h->d_stem_frag);
   if (h->arena.base) hipFree(h->arena.base);
   delete h;
   return PRG_OK;
