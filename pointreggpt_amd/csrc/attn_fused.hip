@@ -440,6 +440,83 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   }
 }
 
+// =====================================================================================================
+// Bottleneck attention core (sd:789-795) on MFMA for N <= 256 tokens: one block per (image, head).
+//   S^T[key][query] = K q^T (keys as MFMA rows: a lane owns ONE query and sees all its keys in registers, so the
+//   softmax over keys is register-local plus one lane^32 exchange), P = exp(S/sqrt(32) - max), O^T = V^T P.
+// K goes to LDS row-major, V transposed with the keys of each 32-key tile stored in the order the S^T accumulator
+// registers supply them as the B operand (same trick as la_out): no shuffle between the two MFMAs.
+// =====================================================================================================
+template <int NT>   // key tiles of 32 (N = 32 NT)
+__global__ __launch_bounds__(256) void full_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out) {
+  constexpr int N = 32 * NT, LDK = 40, LDV = N + 8;
+  __shared__ __attribute__((aligned(16))) __bf16 Ks[N * LDK];
+  __shared__ __attribute__((aligned(16))) __bf16 Vt[32 * LDV];
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const bf16_t* base = qkv + (size_t)b * N * 384;
+  for (int i = tid; i < N * 4; i += 256) {
+    const int key = i >> 2, u = i & 3;
+    *reinterpret_cast<uint4*>(Ks + key * LDK + u * 8) =
+        *reinterpret_cast<const uint4*>(base + (size_t)key * 384 + 128 + h * 32 + u * 8);
+    const uint4 vv = *reinterpret_cast<const uint4*>(base + (size_t)key * 384 + 256 + h * 32 + u * 8);
+    const int d = key & 31;
+    const int pos = (key & ~31) + (d >> 4) * 16 + ((d >> 2) & 1) * 8 + ((d >> 3) & 1) * 4 + (d & 3);
+    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      reinterpret_cast<uint16_t*>(Vt)[(u * 8 + 2 * j) * LDV + pos] = (uint16_t)(w[j] & 0xffffu);
+      reinterpret_cast<uint16_t*>(Vt)[(u * 8 + 2 * j + 1) * LDV + pos] = (uint16_t)(w[j] >> 16);
+    }
+  }
+  __syncthreads();
+  for (int qt = wave; qt < NT; qt += 4) {
+    const bf16_t* qp = base + (size_t)(qt * 32 + l31) * 384 + h * 32 + hi * 8;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qp), q1 = *reinterpret_cast<const bf16x8*>(qp + 16);
+    f32x16 sacc[NT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      sacc[kt] = zero16();
+      sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Ks + kt * 32 * LDK, LDK, l31, hi, 0), q0, sacc[kt], 0, 0, 0);
+      sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Ks + kt * 32 * LDK, LDK, l31, hi, 1), q1, sacc[kt], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[kt][r] *= 0.17677669529663687f;
+        m = fmaxf(m, sacc[kt][r]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.0f;
+    f32x16 oacc = zero16();
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 pb;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const float pv = fast_exp(sacc[kt][8 * i + s2] - m);
+          l += pv;
+          pb[s2] = (__bf16)pv;
+        }
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            *reinterpret_cast<const bf16x8*>(Vt + l31 * LDV + kt * 32 + i * 16 + hi * 8), pb, oacc, 0, 0, 0);
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    bf16_t* op = out + ((size_t)b * N + qt * 32 + l31) * 128 + h * 32 + 4 * hi;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      uint2 w;
+      w.x = pack2(oacc[4 * g4] * inv, oacc[4 * g4 + 1] * inv);
+      w.y = pack2(oacc[4 * g4 + 2] * inv, oacc[4 * g4 + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 8 * g4) = w;
+    }
+  }
+}
+
 template <int C>
 size_t lds_kmax() { return (size_t)kTP * Geo<C>::LDW * 2; }
 template <int C>
@@ -604,6 +681,19 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
 }
 
 }  // namespace
+
+bool full_attention_mfma_supported(int N) { return N == 64 || N == 128 || N == 256; }
+
+// qkv (B, N, 384) bf16 -> out (B, N, 128) bf16
+int launch_full_attention_mfma(const bf16_t* qkv, bf16_t* out, int B, int N, hipStream_t s) {
+  PRG_CHECK(full_attention_mfma_supported(N) && qkv && out, "full attention (MFMA): unsupported token count");
+  const dim3 grid(4, B);
+  if (N == 64) full_attn_mfma_kernel<2><<<grid, 256, 0, s>>>(qkv, out);
+  else if (N == 128) full_attn_mfma_kernel<4><<<grid, 256, 0, s>>>(qkv, out);
+  else full_attn_mfma_kernel<8><<<grid, 256, 0, s>>>(qkv, out);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
 
 bool resblock_tail_fused_supported(int C0, int C1, int Cout) {
   const int cin = C0 + C1;

@@ -61,6 +61,10 @@ int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc,
                                int C1, const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, int Cout,
                                hipStream_t s);
 
+// Attention core on MFMA (bf16 path, N in {64, 128, 256} tokens) (attn_fused.hip)
+bool full_attention_mfma_supported(int N);
+int launch_full_attention_mfma(const bf16_t* qkv, bf16_t* out, int B, int N, hipStream_t s);
+
 // Attention core (sd:789-795) on qkv NHWC (B, N, 384) -> out NHWC (B, N, 128).
 template <typename T>
 int launch_full_attention(const T* qkv, T* out, int B, int N, hipStream_t s);

@@ -405,7 +405,14 @@ struct UnetImpl : prg_unet {
       if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, ConvOpt(), y, s))) return rc;
       if (!arena.dry && (rc = launch_layernorm<T>(y, F(a.out_g), x, out, (int64_t)M, a.C, s))) return rc;
     } else {
-      if (!arena.dry && (rc = launch_full_attention<T>(qkv, o, B, N, s))) return rc;
+      bool done = false;
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        if (!arena.dry && full_attention_mfma_supported(N)) {
+          if ((rc = launch_full_attention_mfma(qkv, o, B, N, s))) return rc;
+          done = true;
+        }
+      }
+      if (!arena.dry && !done && (rc = launch_full_attention<T>(qkv, o, B, N, s))) return rc;
       { ConvOpt ro; ro.residual = x;
         if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, ro, out, s))) return rc; }
     }
