@@ -240,10 +240,16 @@ struct Producer {
     return hi > lo ? hi - lo : 0;
   }
   static constexpr int n_coef(int p) { return ((p % 9) + 9) % 9 == 0 ? NCO : 0; }
-  // weight tile ph+2 was issued first thing (after the coefficients) in phase ph-3; everything after it is younger
+  // Weight tiles are prefetched WD phases ahead in WD register sets (tile t lives in set t % WD).  Three sets made the
+  // producers latency-bound: alone (consumers idle) they needed a phase of (load latency / 3) ~ 700 clk.
+  static constexpr int WD = 6;
+  // weight tile ph+2 was issued (after the coefficients, before the units) in phase ph-WD; everything after it is younger
   static constexpr int w_younger(int ph) {
-    return n_units(ph - 3) + n_coef(ph - 2) + NWL + n_units(ph - 2) + n_coef(ph - 1) + NWL + n_units(ph - 1) + n_coef(ph);
+    int n = n_units(ph - WD) + n_coef(ph);
+    for (int j = 1; j < WD; ++j) n += n_coef(ph - j) + NWL + n_units(ph - j);
+    return n;
   }
+  static_assert(9 % 3 == 0 && 18 % WD == 0, "set index must be a compile-time function of (g & 1, phase)");
 
   const ConvLaunch<bf16_t>& L;
   const ConvDesc& d;
@@ -251,7 +257,7 @@ struct Producer {
   char* Ah0;
   char* Bw0;
   TraceCtx& trace;
-  u32x4 wset[3][NWL];
+  u32x4 wset[WD][NWL];
   u32x4 hreg[KU];
   u32x4 cf[2][4];            // [halo parity][a0..3, a4..7, b0..3, b4..7] as raw bits
   // Every global access is "wave-uniform SGPR base + per-thread 32-bit VGPR offset (+ immediate)": the bases come from
@@ -492,9 +498,10 @@ struct Producer {
   // tile ph + 5 lies in this step (PH + 5 < 9) or the next one: its (chunk, tn) are per-step values
   template <int GP, int PH, bool LIVE>
   __device__ __forceinline__ void phase(int g, bool wr, int chunk0, int tn0, int chunk1, int tn1) {
-    constexpr int SET = (PH + 2) % 3;            // (9 g + PH + 2) % 3: register set == ring slot of tile ph + 2
-    // the prologue's issue-only step: from phase 3 on the set holds an earlier (placeholder, then real) tile and the
-    // three phases behind it are regular, so the steady-state wait + write applies (the consumers have not started)
+    constexpr int SET = (3 * GP + PH + 2) % WD;  // (9 g + PH + 2) % WD, g & 1 == GP: register set of tile ph + 2
+    constexpr int RING = (PH + 2) % 3;           // (9 g + PH + 2) % 3: its LDS ring slot
+    // the prologue's issue-only step: from phase WD on the set holds an earlier (placeholder, then real) tile and the
+    // WD phases behind it are regular, so the steady-state wait + write applies (the consumers have not started)
     // Order inside a phase: everything that touches LDS first (so its latency runs under the global issues and is
     // gone by the barrier), the drain's stage read first of all; then the global issues in the periodic order
     // [weight tile, halo units]; the drain store last.
@@ -504,18 +511,20 @@ struct Producer {
       draining = drain_on;
       if (draining) dv = drain_read<PH>();
     }
-    if constexpr (LIVE || PH >= 3) {
+    if constexpr (LIVE || PH >= WD) {
       w_wait<SET, w_younger(PH)>();
       if constexpr (LIVE) trace.mark(0);
-      w_write<SET>(SET);
+      w_write<SET>(RING);
     }
     if constexpr (LIVE && PH < 8) {
       units_wait<PH, 0, (GP + 1) & 1>();
       units_write<PH, 0, (GP + 1) & 1>(g, wr);
     }
-    // tile ph + 5: taps 5..8 of this step, then taps 0..4 of the next one (a new tile address only at tap 0)
-    if constexpr (!LIVE) wptr = PH + 5 < 9 ? w_tile(PH + 5, chunk0, tn0) : w_tile(PH + 5 - 9, chunk1, tn1);
-    else if constexpr (PH == 4) wptr = w_tile(0, chunk1, tn1);
+    // tile ph + 2 + WD: the remaining taps of this step, then taps of the next one (a new tile address only at tap 0)
+    constexpr int TAPN = PH + 2 + WD;
+    static_assert(TAPN < 18, "weight prefetch reaches at most into the next step");
+    if constexpr (!LIVE) wptr = TAPN < 9 ? w_tile(TAPN, chunk0, tn0) : w_tile(TAPN - 9, chunk1, tn1);
+    else if constexpr (TAPN == 9) wptr = w_tile(0, chunk1, tn1);
     else if (!(PRG_WS_EXP & 1024)) wptr += w_tapb;
     w_issue<SET>(wptr);
     if constexpr (PH < 8) units_issue<PH, 0>();
@@ -600,13 +609,15 @@ struct Producer {
       keep_units<K + 1>();
     }
   }
-  __device__ __forceinline__ void finish() {
+  __device__ __forceinline__ void finish(bool drain = true) {
     // the last step always ends a tile: `dr` is that tile (consumers passed the last phase barrier: stage complete)
-    drain_unit<0>(); drain_unit<1>(); drain_unit<2>(); drain_unit<3>();
-    drain_unit<4>(); drain_unit<5>(); drain_unit<6>(); drain_unit<7>();
+    if (drain) {
+      drain_unit<0>(); drain_unit<1>(); drain_unit<2>(); drain_unit<3>();
+      drain_unit<4>(); drain_unit<5>(); drain_unit<6>(); drain_unit<7>();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int sidx = 0; sidx < 3; ++sidx)
+    for (int sidx = 0; sidx < WD; ++sidx)
 #pragma unroll
       for (int j = 0; j < NWL; ++j) asm volatile("" : "+v"(wset[sidx][j])::"memory");
     keep_units<0>();
@@ -831,9 +842,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     Pv.prologue();
     phase_barrier(trace);
     if constexpr ((PRG_WS_EXP & 256) != 0) {
+      // timing experiment: consumers alone.  The loads of the prologue stay owned until they have landed.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (int g = 0; g < nsteps; ++g)
-        for (int p = 0; p < 9; ++p) phase_barrier(trace);          // timing experiment: consumers alone
-      phase_barrier(trace);
+        for (int p = 0; p < 9; ++p) phase_barrier(trace);
+      Pv.finish(false);
       return;
     }
 #pragma unroll 1
