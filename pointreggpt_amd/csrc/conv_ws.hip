@@ -130,7 +130,8 @@ struct WsGeom {
   static constexpr size_t BW_BYTES = (size_t)BN * ROWB;
   static constexpr size_t RED_BYTES = 0;
   static constexpr size_t STG_BYTES = 4 * 64 * 128;                   // per consumer wave: 64 pixels x 64 channels bf16
-  static constexpr size_t LDS = 2 * AH_BYTES + 3 * BW_BYTES + RED_BYTES + STG_BYTES;
+  static constexpr size_t BIAS_BYTES = BN * sizeof(float);            // bias of the workgroup's (fixed) channel tile
+  static constexpr size_t LDS = 2 * AH_BYTES + 3 * BW_BYTES + RED_BYTES + STG_BYTES + BIAS_BYTES;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(BM / WAVES_M == 64, "consumer wave tile is 64 pixels x 64 channels");
 };
@@ -354,7 +355,7 @@ struct Producer {
     // rows row + 32 j are 32 * 32 * 2 = 2048 bytes apart (immediate offsets reach 4095: second base for j >= 2)
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][0]) : "v"(w_voff), "s"(base) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wset[SET][1]) : "v"(w_voff), "s"(base) : "memory");
-    if constexpr (NWL == 4) {
+    if constexpr (NWL == 4 && !(PRG_WS_EXP & 8192)) {   // 8192: timing experiment, half the producer work per wave
       const char* base2 = base + 4096;
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][NWL - 2]) : "v"(w_voff), "s"(base2) : "memory");
       asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wset[SET][NWL - 1]) : "v"(w_voff), "s"(base2) : "memory");
@@ -371,7 +372,7 @@ struct Producer {
   template <int SET>
   __device__ __forceinline__ void w_write(int ring) {
 #pragma unroll
-    for (int j = 0; j < NWL; ++j)      // weight row `row + 32 j`
+    for (int j = 0; j < ((PRG_WS_EXP & 8192) ? NWL / 2 : NWL); ++j)      // weight row `row + 32 j`
       if (!kExpNoLdsWrite) *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 32 * G::ROWB) = wset[SET][j];
   }
 
@@ -477,21 +478,22 @@ struct Producer {
   template <int PH, int J, int CSW>
   __device__ __forceinline__ void units_wait() {
     if constexpr (J < UPH && PH * UPH + J < KU) {
-      wait_unit<PH * UPH + J, CSW, U_YOUNGER - NWL - J>();   // this phase's weight tile is issued after the LDS work
+      if constexpr (!((PRG_WS_EXP & 8192) && (J & 1)))
+        wait_unit<PH * UPH + J, CSW, U_YOUNGER - NWL - J>();   // this phase's weight tile is issued after the LDS work
       units_wait<PH, J + 1, CSW>();
     }
   }
   template <int PH, int J, int CSW>
   __device__ __forceinline__ void units_write(int g, bool wr) {
     if constexpr (J < UPH && PH * UPH + J < KU) {
-      write_unit<PH * UPH + J, CSW>(g + 1, wr);
+      if constexpr (!((PRG_WS_EXP & 8192) && (J & 1))) write_unit<PH * UPH + J, CSW>(g + 1, wr);
       units_write<PH, J + 1, CSW>(g, wr);
     }
   }
   template <int PH, int J>
   __device__ __forceinline__ void units_issue() {
     if constexpr (J < UPH && PH * UPH + J < KU) {
-      issue_unit<PH * UPH + J>();
+      if constexpr (!((PRG_WS_EXP & 8192) && (J & 1))) issue_unit<PH * UPH + J>();
       units_issue<PH, J + 1>();
     }
   }
@@ -643,6 +645,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWB = G::ROWB;
   char* const stage = smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES + G::RED_BYTES;
+  float* const bias_lds = reinterpret_cast<float*>(stage + G::STG_BYTES);
   TraceCtx trace(trace_buf);
 
   const ConvDesc& d = L.d;
@@ -690,8 +693,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     // Consumers never wait for their own LDS reads at a barrier: every fragment of phase p is consumed by an MFMA of
     // phase p (which cannot issue before the data is back), and the fragments prefetched for phase p+1 come from a
     // ring slot / halo buffer that no producer touches before phase p+2.
-    phase_barrier<false>(trace);   // prologue barrier: first halo + weight tiles 0,1 are in LDS
-    bf16x8 fw[4][2], fx[4][2];   // one fragment set per call of a phase; loads run TWO calls (256 MFMA cycles) ahead
+    // the workgroup's channel tile never changes (one Cout tile, or pinned to one): its bias lives in LDS
+    if (tid < BN) bias_lds[tid] = L.bias[(tmap.pinned ? tmap.tn_fixed : 0) * BN + tid];
+    phase_barrier<true>(trace);    // prologue barrier: first halo + weight tiles 0,1 are in LDS
+    // three fragment sets: the one being multiplied, the next call's, and the one being loaded two calls (256 MFMA
+    // cycles) ahead; set of global call c is c % 3 (36 calls per step: the same code serves every step)
+    bf16x8 fw[3][2], fx[3][2];
     const char* xa[2] = {xrow[0], xrow[1]};                                 // halo buffer of this step
     const char* xn[2] = {xrow[0] + G::AH_BYTES, xrow[1] + G::AH_BYTES};     // ... of the next one
 #define PRG_LW(SET, CT, RING, CALL) fw[SET][CT] = *reinterpret_cast<const bf16x8*>(wrowp[CT] + (RING) * (int)G::BW_BYTES + (CALL) * 32)
@@ -704,7 +711,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
     int tb = 0, ty0 = 0, tx0 = 0, ttn = 0; // tile `it`
     TileCur tcur = tmap.c0;
     tmap.fill(tcur, tb, ty0, tx0, ttn);
-    float4 bias_r[2][4];
     for (int g = 0; g < nsteps; ++g) {
       const bool tile_end = chunk == nchunks - 1;
       // The nine taps are fully unrolled: tap offsets, the weight ring slot (9 g + p) % 3 == p % 3 and the fragment
@@ -716,33 +722,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
         const int toff = (p / 3) * HP + (p % 3);
         const int pn = p == 8 ? 0 : p + 1;
         const int toffN = (pn / 3) * HP + (pn % 3);
-        if (p == 0 && tile_end) {
-          // bias of this lane's channels, needed eight phases from now
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              bias_r[ct][q] = *reinterpret_cast<const float4*>(L.bias + ttn * BN + wn * 64 + ct * 32 + 8 * q + 4 * hi);
-        }
 #pragma unroll
         for (int call = 0; call < ((PRG_WS_EXP & 512) ? 0 : 4); ++call) {
           // set (call + 2) % 4 was consumed two calls ago: refill it for the call two ahead (this phase's calls 2,3
           // or the NEXT phase's calls 0,1 — its weight tile and halo are already visible in LDS)
+          const int sl = (4 * p + call + 2) % 3, sm = (4 * p + call) % 3;   // set being loaded / multiplied
           if (call < 2) {
-            PRG_LW(call + 2, 0, p % 3, call + 2); PRG_MM(call, 0, 0); PRG_SB();
-            PRG_LX(call + 2, 0, xa, toff, call + 2); PRG_MM(call, 0, 1); PRG_SB();
-            PRG_LX(call + 2, 1, xa, toff, call + 2); PRG_MM(call, 1, 0); PRG_SB();
-            PRG_LW(call + 2, 1, p % 3, call + 2); PRG_MM(call, 1, 1); PRG_SB();
+            PRG_LW(sl, 0, p % 3, call + 2); PRG_MM(sm, 0, 0); PRG_SB();
+            PRG_LX(sl, 0, xa, toff, call + 2); PRG_MM(sm, 0, 1); PRG_SB();
+            PRG_LX(sl, 1, xa, toff, call + 2); PRG_MM(sm, 1, 0); PRG_SB();
+            PRG_LW(sl, 1, p % 3, call + 2); PRG_MM(sm, 1, 1); PRG_SB();
           } else if (p == 8) {
-            PRG_LW(call - 2, 0, (p + 1) % 3, call - 2); PRG_MM(call, 0, 0); PRG_SB();
-            PRG_LX(call - 2, 0, xn, toffN, call - 2); PRG_MM(call, 0, 1); PRG_SB();
-            PRG_LX(call - 2, 1, xn, toffN, call - 2); PRG_MM(call, 1, 0); PRG_SB();
-            PRG_LW(call - 2, 1, (p + 1) % 3, call - 2); PRG_MM(call, 1, 1); PRG_SB();
+            PRG_LW(sl, 0, (p + 1) % 3, call - 2); PRG_MM(sm, 0, 0); PRG_SB();
+            PRG_LX(sl, 0, xn, toffN, call - 2); PRG_MM(sm, 0, 1); PRG_SB();
+            PRG_LX(sl, 1, xn, toffN, call - 2); PRG_MM(sm, 1, 0); PRG_SB();
+            PRG_LW(sl, 1, (p + 1) % 3, call - 2); PRG_MM(sm, 1, 1); PRG_SB();
           } else {
-            PRG_LW(call - 2, 0, (p + 1) % 3, call - 2); PRG_MM(call, 0, 0); PRG_SB();
-            PRG_LX(call - 2, 0, xa, toffN, call - 2); PRG_MM(call, 0, 1); PRG_SB();
-            PRG_LX(call - 2, 1, xa, toffN, call - 2); PRG_MM(call, 1, 0); PRG_SB();
-            PRG_LW(call - 2, 1, (p + 1) % 3, call - 2); PRG_MM(call, 1, 1); PRG_SB();
+            PRG_LW(sl, 0, (p + 1) % 3, call - 2); PRG_MM(sm, 0, 0); PRG_SB();
+            PRG_LX(sl, 0, xa, toffN, call - 2); PRG_MM(sm, 0, 1); PRG_SB();
+            PRG_LX(sl, 1, xa, toffN, call - 2); PRG_MM(sm, 1, 0); PRG_SB();
+            PRG_LW(sl, 1, (p + 1) % 3, call - 2); PRG_MM(sm, 1, 1); PRG_SB();
           }
         }
         if (p == 8 && tile_end && !kExpNoEpilogue) {
@@ -754,7 +753,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float bv[4] = {bias_r[ct][q].x, bias_r[ct][q].y, bias_r[ct][q].z, bias_r[ct][q].w};
+              const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + wn * 64 + ct * 32 + 8 * q + 4 * hi);
+              const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
               float s = 0.0f, sq = 0.0f;
 #pragma unroll
               for (int pt = 0; pt < 2; ++pt) {
@@ -858,6 +858,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf1
   }
 }
 
+constexpr int kWsUnsupported = 100;   // launch_ws_cfg: shape not covered, caller falls back
+
 template <int TH, int TW, int BN, bool PRO>
 int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, int* nsplit, int num_cus) {
   using G = WsGeom<TH, TW, BN>;
@@ -867,6 +869,7 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
   int grid = num_cus;
   if (grid > total) grid = total;
   if (grid >= 8) grid &= ~7;                     // multiple of 8: XCD-contiguous runs inside a round
+  if (tiles_n > 1 && (grid & 7) != 0) return kWsUnsupported;   // a workgroup must own one channel tile (bias in LDS)
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<TH, TW, BN, PRO>),
@@ -922,6 +925,10 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
   if (d.C0 % kCH || d.C1 % kCH || d.Cout % 64) return 0;
   if (L.residual || !L.bias) return 0;
+  {
+    const int tn128 = d.Cout % 128 == 0 ? d.Cout / 128 : d.Cout / 64;   // Cout tiles of the configuration chosen below
+    if (tn128 != 1 && tn128 != 2 && tn128 != 4 && tn128 != 8) return 0;  // every workgroup must own ONE channel tile
+  }
   static int num_cus = 0;
   if (!num_cus) {
     int dev = 0;
@@ -948,6 +955,7 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
     if (W % 32 == 0 && H % 8 == 0) rc = launch_ws_cfg<8, 32, 64>(L, s, fuse_for(8, 32, 64), gn_nsplit_out, num_cus);
     else return 0;
   }
+  if (rc == kWsUnsupported) return 0;
   return rc == PRG_OK ? 1 : rc;
 }
 
