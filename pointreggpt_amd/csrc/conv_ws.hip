@@ -222,8 +222,13 @@ template <int TH, int TW, int BN, bool PRO>
 struct Producer {
   using G = WsGeom<TH, TW, BN>;
   static constexpr int HP = G::HP, HALO = G::HALO;
-  static constexpr int NWL = BN / 32;                  // weight units per thread per tap (BN rows x 8 units / 256)
-  static constexpr int RPP = 32;                       // halo rows per pass (8 lanes per 128-byte row)
+  // EIGHT producer waves (two per SIMD next to one consumer wave: 768 threads, <= 168 VGPRs): a producer's phase is a
+  // dependent chain (wait -> LDS write -> address -> issue) that runs at 16-35 clk per instruction with one wave per
+  // SIMD; two waves with half the work each overlap their chains.
+  static constexpr int NPT = 512;                      // producer threads
+  static constexpr int NWL = BN * 8 / NPT;             // weight units per thread per tap (BN rows x 8 units / 512)
+  static constexpr int RPP = NPT / 8;                  // halo rows per pass (8 lanes per 128-byte row)
+  static constexpr int DRAIN_PHASES = 2048 / NPT;      // 16-byte units of a finished tile per thread
   static constexpr int KU = (HALO + RPP - 1) / RPP;    // halo units per thread
   // units handled per phase (phases 0..7), at least two: the fused prologue of ONE unit is a latency-bound dependent
   // chain (~840 clk measured, tools/micro/coissue.hip); two units interleave to about the VALU throughput bound
@@ -295,7 +300,7 @@ struct Producer {
     Ah0 = smem + (ptid >> 3) * G::ROWB + (ptid & 7) * 16;            // this thread's unit of halo row `row`
     Bw0 = smem + 2 * G::AH_BYTES + (ptid >> 3) * G::ROWB + (ptid & 7) * 16;
     slot = ptid & 7;
-    row = ptid >> 3;            // 0..31
+    row = ptid >> 3;            // 0..63
     Hl = d.Hout;
     Wl = d.Wout;
     hvalid = hvalid_nxt = 0;
@@ -352,28 +357,26 @@ struct Producer {
   }
   template <int SET>
   __device__ __forceinline__ void w_issue(const char* base) {
-    // rows row + 32 j are 32 * 32 * 2 = 2048 bytes apart (immediate offsets reach 4095: second base for j >= 2)
+    // rows row + 64 j are 64 * 32 * 2 = 4096 bytes apart (immediate offsets reach 4095: second base)
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][0]) : "v"(w_voff), "s"(base) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wset[SET][1]) : "v"(w_voff), "s"(base) : "memory");
-    if constexpr (NWL == 4 && !(PRG_WS_EXP & 8192)) {   // 8192: timing experiment, half the producer work per wave
+    if constexpr (NWL == 2) {
       const char* base2 = base + 4096;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][NWL - 2]) : "v"(w_voff), "s"(base2) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wset[SET][NWL - 1]) : "v"(w_voff), "s"(base2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wset[SET][NWL - 1]) : "v"(w_voff), "s"(base2) : "memory");
     }
   }
   template <int SET, int N>                                // N younger loads may stay in flight
   __device__ __forceinline__ void w_wait() {
-    if constexpr (NWL == 4)
-      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]), "+v"(wset[SET][2]), "+v"(wset[SET][3]) : [n] "i"(kExpNoWaitW ? 63 : N) : "memory");
-    else
+    if constexpr (NWL == 2)
       asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]), "+v"(wset[SET][1]) : [n] "i"(kExpNoWaitW ? 63 : N) : "memory");
-    static_assert(NWL == 4 || NWL == 2, "weight units per thread");
+    else
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(wset[SET][0]) : [n] "i"(kExpNoWaitW ? 63 : N) : "memory");
+    static_assert(NWL == 2 || NWL == 1, "weight units per thread");
   }
   template <int SET>
   __device__ __forceinline__ void w_write(int ring) {
 #pragma unroll
-    for (int j = 0; j < ((PRG_WS_EXP & 8192) ? NWL / 2 : NWL); ++j)      // weight row `row + 32 j`
-      if (!kExpNoLdsWrite) *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 32 * G::ROWB) = wset[SET][j];
+    for (int j = 0; j < NWL; ++j)      // weight row `row + 64 j`
+      if (!kExpNoLdsWrite) *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 64 * G::ROWB) = wset[SET][j];
   }
 
   // ---- halo ----
@@ -455,15 +458,13 @@ struct Producer {
   // 8 lanes), so the tile's write burst overlaps the next tile's MFMAs instead of stalling the consumers.
   template <int PH>
   __device__ __forceinline__ u32x4 drain_read() {
-    constexpr int w = PH >> 1;                                   // consumer wave whose stage this phase drains
-    return *reinterpret_cast<const u32x4*>(stage_rd + w * 8192 + (PH & 1) * 32 * 128);
+    return *reinterpret_cast<const u32x4*>(stage_rd + PH * 8192);   // phase PH drains consumer wave PH's 64 x 64 tile
   }
   template <int PH>
   __device__ __forceinline__ void drain_store(const u32x4& v) {
-    constexpr int w = PH >> 1;
-    constexpr int wm = w / G::WAVES_N, wn = w % G::WAVES_N;
-    // pixels wm*64 + (PH&1)*32 + [0,32) of the tile: whole tile rows, so the row part is wave-uniform
-    constexpr int prow = (wm * 64 + (PH & 1) * 32) / TW;
+    constexpr int wm = PH / G::WAVES_N, wn = PH % G::WAVES_N;
+    // pixels wm*64 + [0,64) of the tile start on a tile row: that part of the address is wave-uniform
+    constexpr int prow = (wm * 64) / TW;
     char* base = dr_base + prow * dr_rowb + wn * 128;
     asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(dr_voff), "v"(v), "s"(base) : "memory");
   }
@@ -509,7 +510,7 @@ struct Producer {
     // [weight tile, halo units]; the drain store last.
     u32x4 dv;
     bool draining = false;
-    if constexpr (LIVE && PH < 8) {
+    if constexpr (LIVE && PH < DRAIN_PHASES) {
       draining = drain_on;
       if (draining) dv = drain_read<PH>();
     }
@@ -530,7 +531,7 @@ struct Producer {
     else if (!(PRG_WS_EXP & 1024)) wptr += w_tapb;
     w_issue<SET>(wptr);
     if constexpr (PH < 8) units_issue<PH, 0>();
-    if constexpr (LIVE && PH < 8) {
+    if constexpr (LIVE && PH < DRAIN_PHASES) {
       if (draining) drain_store<PH>(dv);
     }
     if constexpr (LIVE) trace.mark(1);
@@ -615,7 +616,7 @@ struct Producer {
     // the last step always ends a tile: `dr` is that tile (consumers passed the last phase barrier: stage complete)
     if (drain) {
       drain_unit<0>(); drain_unit<1>(); drain_unit<2>(); drain_unit<3>();
-      drain_unit<4>(); drain_unit<5>(); drain_unit<6>(); drain_unit<7>();
+      static_assert(DRAIN_PHASES == 4, "one consumer wave's stage per drain phase");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -637,7 +638,7 @@ struct Producer {
 // kernel
 // =====================================================================================================
 template <int TH, int TW, int BN, bool PRO>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvLaunch<bf16_t> L, const int tiles_x,
+__global__ __launch_bounds__(768) void conv3x3_ws_kernel(const ConvLaunch<bf16_t> L, const int tiles_x,
                                                             const int tiles_y, const int tiles_n, const int fuse_stats,
                                                             unsigned long long* const trace_buf) {
   using G = WsGeom<TH, TW, BN>;
@@ -882,12 +883,12 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
   static int launch_no = 0;
   unsigned long long* tbuf = nullptr;
   if (kTrace && trace_at >= 0 && launch_no++ == trace_at) {
-    if (hipMalloc(reinterpret_cast<void**>(&tbuf), 8 * kTraceStride * sizeof(unsigned long long)) == hipSuccess) {
-      (void)hipMemsetAsync(tbuf, 0, 8 * kTraceStride * sizeof(unsigned long long), s);
+    if (hipMalloc(reinterpret_cast<void**>(&tbuf), 12 * kTraceStride * sizeof(unsigned long long)) == hipSuccess) {
+      (void)hipMemsetAsync(tbuf, 0, 12 * kTraceStride * sizeof(unsigned long long), s);
       (void)hipStreamSynchronize(s);
     }
   }
-  conv3x3_ws_kernel<TH, TW, BN, PRO><<<dim3(grid), 512, G::LDS, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats, tbuf);
+  conv3x3_ws_kernel<TH, TW, BN, PRO><<<dim3(grid), 768, G::LDS, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats, tbuf);
   PRG_LAUNCH_CHECK();
   if (tbuf) {
     (void)hipStreamSynchronize(s);
@@ -895,7 +896,7 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
     std::snprintf(path, sizeof(path), "%s/ws_trace_%d_%d_%d_cin%d_pro%d.bin",
                   std::getenv("PRG_WS_TRACE_DIR") ? std::getenv("PRG_WS_TRACE_DIR") : "/tmp", TH, TW, BN, d.C0 + d.C1,
                   (int)PRO);
-    std::vector<unsigned long long> host(8 * kTraceStride);
+    std::vector<unsigned long long> host(12 * kTraceStride);
     (void)hipMemcpy(host.data(), tbuf, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     if (FILE* f = std::fopen(path, "wb")) {
       std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
