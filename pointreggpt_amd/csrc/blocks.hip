@@ -263,9 +263,18 @@ __global__ __launch_bounds__(256) void gn_coeff_kernel(const float* __restrict__
   if (g < G) {
     double ss = 0, qq = 0;
     const float* pp = partials + ((size_t)b * nsplit * G + g) * 2;
-    for (int k = j; k < nsplit; k += LPG) {
-      ss += (double)pp[(size_t)k * G * 2 + 0];
-      qq += (double)pp[(size_t)k * G * 2 + 1];
+    for (int k0 = j; k0 < nsplit; k0 += 8 * LPG) {   // eight loads in flight per lane, summed in index order
+      float2 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = k0 + i * LPG;
+        v[i] = k < nsplit ? *reinterpret_cast<const float2*>(pp + (size_t)k * G * 2) : make_float2(0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ss += (double)v[i].x;
+        qq += (double)v[i].y;
+      }
     }
     for (int o = LPG >> 1; o > 0; o >>= 1) {
       ss += __shfl_xor(ss, o, 64);
