@@ -374,9 +374,18 @@ struct Producer {
   }
   template <int SET>
   __device__ __forceinline__ void w_write(int ring) {
+    if constexpr ((PRG_WS_EXP >> 16) != 0) {                       // timing experiment: stagger the weight writes
+      if (row & 32) __builtin_amdgcn_s_sleep(PRG_WS_EXP >> 16);    // odd producer waves start N * 64 clk later
+    }
 #pragma unroll
-    for (int j = 0; j < NWL; ++j)      // weight row `row + 64 j`
-      if (!kExpNoLdsWrite) *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 64 * G::ROWB) = wset[SET][j];
+    for (int j = 0; j < NWL; ++j) {    // weight row `row + 64 j`
+      // 16384: timing experiment, only half of the weight tile is written to LDS (what a 256-pixel tile would stage per MFMA)
+      const bool skip = (PRG_WS_EXP & 16384) && (NWL == 2 ? j == 1 : (row & 32) != 0);
+      if (!kExpNoLdsWrite && !skip) *reinterpret_cast<u32x4*>(Bw0 + ring * G::BW_BYTES + j * 64 * G::ROWB) = wset[SET][j];
+      if constexpr ((PRG_WS_EXP & 32768) != 0) {                 // timing experiment: gap between a wave's two stores
+        if (j + 1 < NWL) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      }
+    }
   }
 
   // ---- halo ----
@@ -946,6 +955,16 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
   };
   static const int cfg_mask = [] { const char* e = std::getenv("PRG_WS_CFGS"); return e ? std::atoi(e) : 7; }();   // debugging aid
   int rc = 0;
+  // PRG_WS_PREFER64: route wide convs through the 256-pixel x 64-channel tile where it fits (half the weight bytes
+  // staged per MFMA, the halo staged once per 64 output channels)
+  static const int prefer64 = [] { const char* e = std::getenv("PRG_WS_PREFER64"); return e ? std::atoi(e) : 0; }();
+  const int tn64 = d.Cout / 64;
+  if (prefer64 && d.Cout % 128 == 0 && W % 32 == 0 && H % 8 == 0 && (tn64 == 2 || tn64 == 4 || tn64 == 8) &&
+      (prefer64 >= 2 || tn64 == 2)) {
+    rc = launch_ws_cfg<8, 32, 64>(L, s, fuse_for(8, 32, 64), gn_nsplit_out, num_cus);
+    if (rc == kWsUnsupported) return 0;
+    return rc == PRG_OK ? 1 : rc;
+  }
   if (d.Cout % 128 == 0) {
     if (!(cfg_mask & (W % 32 == 0 && H % 4 == 0 ? 1 : 2))) return 0;
     if (W % 32 == 0 && H % 4 == 0) rc = launch_ws_cfg<4, 32, 128>(L, s, fuse_for(4, 32, 128), gn_nsplit_out, num_cus);
