@@ -208,6 +208,8 @@ def main():
             "bound": "mfma", "achieved": ach,
             "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype],
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE*2 + WRITE_SIZE)", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": pr.get("conv_bytes", 0.0) / max(1, pr["conv_launches"]),
+            "peak_measured_random_operands": 1670.0 if a.dtype == "bf16" else None,   # tools/micro/mfma_power.hip, power-limited
             "launches": pr["conv_launches"], "avg_launch_us": pr["conv_ms"] * 1e3 / max(1, pr["conv_launches"]),
             "flop_per_launch": pr["conv_flops"] / max(1, pr["conv_launches"]),
             "share_of_step_time": pr["conv_ms"] / pr["total_ms"],

@@ -178,6 +178,9 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
 int prg_sampler_set_profile(prg_sampler* h, int enable);
 int prg_sampler_get_profile(prg_sampler* h, double* conv_ms, int64_t* conv_launches, double* conv_flops,
                             double* total_ms);
+/* Algorithmic bytes of the same launches (each input and output element once, plus the weights): what the PMC-measured
+ * HBM traffic of bench.py's `roofline.traffic` is compared with. */
+int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes);
 
 #ifdef __cplusplus
 }

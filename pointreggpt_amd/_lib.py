@@ -57,6 +57,7 @@ PROTOTYPES = {
     "prg_sampler_set_profile": (C.c_int, [_P, _I]),
     "prg_sampler_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]),
+    "prg_sampler_get_profile_bytes": (C.c_int, [_P, C.POINTER(C.c_double)]),
 }
 
 _lib = None

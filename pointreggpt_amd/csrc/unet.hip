@@ -52,7 +52,7 @@ struct ProfileSink {  // per-launch conv timing (bench roofline)
   bool on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
   size_t used = 0;
-  double conv_ms = 0, conv_flops = 0;
+  double conv_ms = 0, conv_flops = 0, conv_bytes = 0;   // conv_bytes: algorithmic input + output + weight bytes
   int64_t launches = 0;
 };
 
@@ -287,6 +287,8 @@ struct UnetImpl : prg_unet {
       int rc = launch_conv<T>(L, s, o.gn_nsplit);
       PRG_HIP(hipEventRecord(ev.second, s));
       prof->conv_flops += conv_flops(L.d);
+      prof->conv_bytes += ((double)L.d.B * L.d.Hin * L.d.Win * (L.d.C0 + L.d.C1) + (double)L.d.B * L.d.Hout * L.d.Wout * L.d.Cout +
+                           (double)L.d.Cout * (L.d.C0 + L.d.C1) * L.d.KH * L.d.KW) * sizeof(T);
       prof->launches += 1;
       return rc;
     }
@@ -950,6 +952,12 @@ int prg_sampler_set_profile(prg_sampler* h, int enable) {
   return PRG_OK;
 }
 
+int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes) {
+  PRG_CHECK(h && conv_bytes, "prg_sampler_get_profile_bytes: null argument");
+  *conv_bytes = h->prof.conv_bytes;
+  return PRG_OK;
+}
+
 int prg_sampler_get_profile(prg_sampler* h, double* conv_ms, int64_t* conv_launches, double* conv_flops,
                             double* total_ms) {
   PRG_CHECK(h, "prg_sampler_get_profile: null handle");
@@ -1000,7 +1008,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
 
   const bool profiling = h->prof.on;
   u->prof = profiling ? &h->prof : nullptr;
-  h->prof.conv_ms = 0; h->prof.conv_flops = 0; h->prof.launches = 0; h->prof.used = 0;
+  h->prof.conv_ms = 0; h->prof.conv_flops = 0; h->prof.conv_bytes = 0; h->prof.launches = 0; h->prof.used = 0;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   if (profiling) {
     PRG_HIP(hipEventCreate(&t0));

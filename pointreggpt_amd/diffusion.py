@@ -180,4 +180,7 @@ class GaussianDiffusion:
         h = self._sampler(batch)
         ms, n, fl, tot = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(lib.prg_sampler_get_profile(h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(tot)))
-        return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value, "total_ms": tot.value}
+        by = C.c_double()
+        _lib.check(lib.prg_sampler_get_profile_bytes(h, C.byref(by)))
+        return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value, "conv_bytes": by.value,
+                "total_ms": tot.value}

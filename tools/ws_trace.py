@@ -1,6 +1,6 @@
 """Print a barrier trace written by conv_ws.hip under PRG_WS_TRACE (see phase_barrier).
 
-For every wave (0-3 consumers, 4-7 producers) and phase-in-step p: mean work time (barrier leave -> next arrive) and
+For every wave (0-3 consumers, 4-11 producers) and phase-in-step p: mean work time (barrier leave -> next arrive) and
 the barrier period.  Usage: python tools/ws_trace.py <trace.bin> ...
 """
 import sys
@@ -9,9 +9,10 @@ import numpy as np
 
 S = 4096
 for path in sys.argv[1:]:
-    a = np.fromfile(path, dtype=np.uint64).reshape(8, S)
+    a = np.fromfile(path, dtype=np.uint64).reshape(-1, S)
     n = int(a[:, 0].min())
-    arr = a[:, 1:1 + 2 * n].reshape(8, n, 2).astype(np.int64)
+    NW = a.shape[0]
+    arr = a[:, 1:1 + 2 * n].reshape(NW, n, 2).astype(np.int64)
     arrive, leave = arr[..., 0], arr[..., 1]
     work = arrive[:, 1:] - leave[:, :-1]            # work[:, k-1] = work before barrier k
     period = np.diff(leave.max(axis=0))
