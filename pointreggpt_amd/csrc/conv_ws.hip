@@ -1,24 +1,27 @@
 // conv_ws.hip — wave-specialised persistent 3x3 convolution for the bf16 throughput path (MFMA roofline).
 //
-// One 512-thread workgroup per CU, resident for the whole launch, walks a strided list of output tiles
-// (TH x TW pixels of one image x BN output channels).  Its eight waves have fixed roles:
+// One 768-thread workgroup per CU, resident for the whole launch, walks a strided list of output tiles
+// (TH x TW pixels of one image x BN output channels).  A step = one 64-channel chunk of Cin for one tile, a phase = one
+// tap of a step (nine phases, one raw s_barrier each).  Its twelve waves (three per SIMD, <= 168 VGPRs) have fixed roles:
 //
-//   waves 0-3   CONSUMERS, one per SIMD, raised issue priority.  Per phase (= one tap of one 128-byte channel chunk)
-//               16 ds_read_b128 fragment loads and 16 v_mfma_f32_32x32x16_bf16, the nine taps fully unrolled
-//               (offsets, ring slots and fragment sets are compile-time constants) and the fragment loads issued
-//               two calls (256 MFMA cycles) ahead of their use, across the phase barrier included.  The operands
-//               are swapped — weights are the MFMA "A" rows, pixels the "B" columns — so a lane ends up with four
-//               consecutive channels of one pixel: at the end of a tile it adds the bias, rounds to bf16, stores
-//               8 bytes per (pixel, channel quad) straight to HBM and folds the GroupNorm partial sums of the
-//               output with wave shuffles (fixed order: deterministic).
-//   wave 4 (+5) WEIGHTS.  Three register sets hold the weight tiles of phases ph+2..ph+4; phase ph writes tile ph+2
-//               into ring slot (ph+2) % 3 and re-issues that set for tile ph+5 (9 % 3 == 0: set == slot == a
-//               compile-time constant of the unrolled step).
-//   waves 5/6-7 HALO.  "Write, then re-issue": during step s the units of halo s+1 are written to LDS (after the fused
-//               GroupNorm + (scale+1, shift) + SiLU of the previous Block, sd:690-696 — each halo pixel once, not
-//               nine times) from registers loaded one full step earlier, and each register is immediately re-issued
-//               for the same unit of halo s+2: nine phases of MFMAs between an HBM load and its use, work spread
-//               evenly over phases 0..7.
+//   waves 0-3   CONSUMERS, one per SIMD.  Per phase 16 ds_read_b128 fragment loads and 16 v_mfma_f32_32x32x16_bf16, the
+//               nine taps fully unrolled (tap offsets, ring slots and fragment sets are compile-time constants, every
+//               LDS offset an immediate) with a sched_barrier-pinned one-load-one-MFMA interleave; the fragments of
+//               call c+2 are loaded while call c multiplies, across the phase barrier included, and a consumer never
+//               waits for its own LDS reads at a barrier.  The operands are swapped — weights are the MFMA "A" rows,
+//               pixels the "B" columns — so a lane ends up with four consecutive channels of one pixel: at the end of
+//               a tile it adds the bias (kept in LDS: a workgroup owns one channel tile), rounds to bf16, transposes
+//               through a per-wave LDS stage, and folds the GroupNorm partial sums of the output with a 17-exchange
+//               halving butterfly (DPP / ds_swizzle; fixed order: deterministic) straight to global.
+//   waves 4-11  PRODUCERS, each stages an eighth of every weight tile and of every halo and drains finished tiles:
+//               * weights: six register sets hold the tiles of phases ph+2..ph+7; phase ph writes tile ph+2 into LDS ring
+//                 slot (ph+2) % 3 and re-issues that set for tile ph+8;
+//               * halo, "write, then re-issue": during step s the units of halo s+1 are written to LDS (after the fused
+//                 GroupNorm + (scale+1, shift) + SiLU of the previous Block, sd:690-696 — each halo pixel once, not
+//                 nine times) from registers loaded one full step earlier, and each register is immediately re-issued
+//                 for the same unit of halo s+2: nine phases of MFMAs between an HBM load and its use;
+//               * drain: the tile the consumers left in the LDS stage goes to HBM in full 128-byte rows during the
+//                 first four phases of the next step, under that tile's MFMAs.
 //
 // All producer loads are inline asm with hand-counted `s_waitcnt vmcnt(N)`: every producer wave issues loads only,
 // in a fixed periodic order, so "N younger loads may stay in flight" is an exact constant.  (hipcc's own waitcnt
