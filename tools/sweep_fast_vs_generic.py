@@ -7,7 +7,7 @@ from pointreggpt_amd import weights as W
 from pointreggpt_amd.unet import Unet, MaskUnet
 out = sys.argv[1]
 res = {}
-for (B, S) in [(1, 64), (3, 128), (5, 96), (1, 256), (2, 192)]:
+for (B, S) in [(2, 40), (3, 72), (1, 64), (3, 128), (5, 96), (1, 256), (2, 192)]:
     sd = W.synth_state_dict(W.unet_config(64), 8)
     net = Unet(64, dtype="bf16").load_state_dict(sd)
     g = torch.Generator().manual_seed(B * 1000 + S)
