@@ -49,7 +49,7 @@ def parse():
 
 def cpu_baseline(size, dim):
     """The reference's arithmetic on the host cores: the oracle's p_sample (torch-CPU / oneDNN, fp32) on a bounded
-    sample — 1 warm-up + 3 timed transitions at batch 4 — extrapolated to pairs/s for the full chain."""
+    sample — a thread-count sweep, then 12 timed transitions at batch 4 — extrapolated to pairs/s for the full chain."""
     from oracle import diffusion as OD
     from oracle import unet as OU
     from pointreggpt_amd import weights as W
@@ -81,7 +81,7 @@ def cpu_baseline(size, dim):
         if d > 2.5 * best:
             break
     torch.set_num_threads(used)
-    n = 3
+    n = 12                       # ~6 s of timed CPU work after the ~10 s thread sweep
     dt = sum(transition(2 + i) for i in range(n)) / n
     cores = used
     pairs_per_s = B / (dt * T)
