@@ -9,6 +9,7 @@ hard-coded literals, generate_dataset.py:32-55):
   --image_size 256  --timesteps 1000  --sampling_timesteps 250  --batch_size 4  --dim 64  --dtype bf16
   --data_root /path/to/3DMatch-RGBD/train
   --synthetic SEED    synthetic scenes instead of 3DMatch frames (no dataset needed)
+  --noise_seed N      seed of the diffusion noise (default: fresh entropy, printed; synthetic runs default to SEED)
   --resume synthetic[:SEED]   deterministic synthetic weights instead of ./successive_ddnm_diffusion_results/model-<resume>.pt
 Under `torchrun --nproc-per-node N` every rank takes a contiguous block of [-start, -stop) (no collectives).
 """
@@ -34,6 +35,9 @@ def main():
     p.add_argument("--data_root", default="/path/to/3DMatch-RGBD/train", type=str)
     p.add_argument("--synthetic", default=None, type=int, help="seed of the synthetic scene generator")
     p.add_argument("--mask_threshold", default=0.99, type=float)
+    p.add_argument("--noise_seed", default=None, type=int,
+                   help="seed of the diffusion noise (and, with real data, of the pose stream); default: fresh entropy, "
+                        "logged, like the reference's unseeded torch.randn")
     args = p.parse_args()
 
     from pointreggpt_amd import sharding
@@ -62,10 +66,17 @@ def main():
         generator.load(args.resume)
         ckpt = torch.load("./depth_correction_results/model-best.pt", map_location="cpu")
         depth_correction.load_state_dict(maskunet_state_from_checkpoint(ckpt, depth_correction.cfg))
+    if args.noise_seed is None:
+        import secrets
+        args.noise_seed = secrets.randbits(63) if args.synthetic is None else int(args.synthetic)
+    print("noise seed: {}".format(args.noise_seed))
+    if args.synthetic is None:
+        import numpy as np
+        np.random.seed((args.noise_seed + start) % (2 ** 32))   # the reference's global pose stream (sd:417-443), per shard
     if stop > start:
         generator.generate(start_scene_index=start, stop_scene_index=stop, num_samples=args.num_samples,
                            has_refine_step=False, depth_correction=depth_correction,
-                           mask_threshold=args.mask_threshold)
+                           mask_threshold=args.mask_threshold, noise_seed=args.noise_seed)
     torch.cuda.synchronize()
 
 

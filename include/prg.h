@@ -138,9 +138,11 @@ int prg_unet_get_tap(prg_unet* h, const char* name, float* out, int64_t out_capa
 typedef struct prg_sampler prg_sampler;
 
 /* One denoising transition.  With u = Unet(x, t, param_cond):
- *     x0p = clip_pred ? clamp(u,-1,1) : u                                    (sd:1199-1201)
+ *     x0p = (clip_pred & 1) ? clamp(u,-1,1) : u                              (ddim_sample, sd:1199-1201)
  *     eps = (sqrt_recip * x - x0p) / sqrt_recipm1                            (sd:1158-1162; used iff c_eps != 0)
- *     x0  = known ? cond_depth : x0p ;  x0 = clamp(x0,-1,1)                  (sd:1210-1218, sd:1250-1251)
+ *     x0  = known ? cond_depth : x0p                                         (DDNM replacement, sd:1210-1218)
+ *     x0  = (clip_pred & 2) ? clamp(x0,-1,1) : x0                            (p_mean_variance, sd:1250-1251: the ancestral
+ *           sampler clamps AFTER the replacement; ddim_sample does not, so known pixels > 1 enter the state as they are)
  *     x'  = c_x0 * x0 + c_x * x + c_eps * eps + sigma * noise                (sd:1173-1180,1280 / sd:1369-1373)
  * Ancestral step t: c_x0 = posterior_mean_coef1[t], c_x = coef2[t], c_eps = 0, sigma = exp(0.5 logvar[t])
  * (0 at t = 0).  DDIM pair (t, t'): c_x0 = sqrt(ac[t']), c_x = 0, c_eps = c, sigma = sigma; last pair:
@@ -148,7 +150,8 @@ typedef struct prg_sampler prg_sampler;
  * schedule exactly as the reference computes it.                                                            */
 typedef struct prg_step {
   int32_t t;            /* timestep fed to the U-Net */
-  int32_t clip_pred;    /* clamp the network output before deriving eps (ddim: clip_denoised=True) */
+  int32_t clip_pred;    /* bit 0: clamp the network output before deriving eps (DDIM rows = 1);
+                           bit 1: clamp x0 after the DDNM replacement (ancestral rows = 2) */
   float c_x0, c_x, c_eps, sigma;
   float sqrt_recip, sqrt_recipm1;
 } prg_step;

@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(SamplerStepArgs a) {
     float r[4], f[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float x0p = st.clip_pred ? clamp1(us[e]) : us[e];
+      const float x0p = (st.clip_pred & 1) ? clamp1(us[e]) : us[e];
       const bool known = a.cond && ((cms[e] + 1.0f) * 0.5f > 0.5f);  // get_mask_from_img_cond (sd:507-508)
       float x0 = known ? cds[e] : x0p;
-      x0 = clamp1(x0);
+      if (st.clip_pred & 2) x0 = clamp1(x0);   // p_mean_variance clip_denoised (sd:1250); ddim_sample has no such clamp
       float v = st.c_x0 * x0;
       if (st.c_x != 0.0f) v = v + st.c_x * xs[e];
       if (st.c_eps != 0.0f) {
@@ -87,9 +87,17 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(SamplerStepArgs a) {
     *reinterpret_cast<float4*>(a.x + o) = make_float4(r[0], r[1], r[2], r[3]);
     if (last) *reinterpret_cast<float4*>(a.final_out + o) = make_float4(f[0], f[1], f[2], f[3]);
   }
+  // Every workgroup read the step counter at its first instruction; the last one to arrive here advances it for the
+  // next launch and re-arms the ticket (kernel boundaries order this against the neighbouring launches).
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nwg = gridDim.x * gridDim.y;
+    if (atomicAdd(a.ticket, 1) == nwg - 1) {
+      *a.ticket = 0;
+      *a.step_idx = k + 1;
+    }
+  }
 }
-
-__global__ void advance_step_kernel(int* step_idx) { *step_idx = *step_idx + 1; }
 
 __global__ void sampler_init_kernel(float* __restrict__ x, const float* __restrict__ noise,
                                     const uint64_t* __restrict__ seeds, int HW) {
@@ -115,11 +123,6 @@ static inline dim3 step_grid(int HW, int B) {
 int launch_sampler_step(const SamplerStepArgs& a, hipStream_t s) {
   PRG_CHECK(a.HW % 4 == 0, "sampler: H*W must be a multiple of 4");
   sampler_step_kernel<<<step_grid(a.HW, a.B), 256, 0, s>>>(a);
-  PRG_LAUNCH_CHECK();
-  return PRG_OK;
-}
-int launch_advance_step(int* step_idx, hipStream_t s) {
-  advance_step_kernel<<<1, 1, 0, s>>>(step_idx);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }

@@ -226,6 +226,7 @@ struct prg_unet {
   bf16_t* d_stem_frag = nullptr; // stem weights as MFMA fragments (bf16 path, Cin 1 -> 64)
   bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
   Arena arena;
+  uint64_t arena_gen = 0;       // bumped whenever the workspace is reallocated: captured graphs bake its pointers in
   int resB = 0, resS = 0;
   bool taps_on = false;
   std::map<std::string, Tap> taps;
@@ -706,6 +707,7 @@ static int reserve(prg_unet* h, int B, int S) {
     return fail(PRG_E_NOMEM, "hipMalloc(workspace " + std::to_string(bytes >> 20) + " MiB)");
   }
   h->arena.cap = bytes;
+  ++h->arena_gen;
   h->resB = nb;
   h->resS = ns;
   return PRG_OK;
@@ -735,6 +737,7 @@ struct prg_sampler {
   const float* g_noise = nullptr;
   float* g_out = nullptr;
   hipStream_t g_stream = nullptr;
+  uint64_t g_arena_gen = 0;        // workspace generation the graph was captured against
   bool use_graph = true;
   ProfileSink prof;
   double last_total_ms = 0;
@@ -762,8 +765,8 @@ static int sampler_one_step(prg_sampler* h, const float* cond, const float* nois
   SamplerStepArgs a;
   a.x = h->d_x; a.u = h->d_u; a.cond = cond; a.noise = noise; a.steps = h->d_steps; a.step_idx = h->d_step;
   a.seeds = h->d_seeds; a.final_out = out; a.B = h->B; a.HW = h->S * h->S; a.n_steps = h->n_steps;
-  if ((rc = launch_sampler_step(a, s))) return rc;
-  return launch_advance_step(h->d_step, s);
+  a.ticket = h->d_step + 1;
+  return launch_sampler_step(a, s);   // its last workgroup advances the step counter
 }
 
 }  // namespace prg
@@ -895,7 +898,7 @@ int prg_sampler_create(prg_unet* unet, const prg_step* steps, int n_steps, int B
       hipMalloc(&h->d_ppart, sizeof(float) * (size_t)B * W) != hipSuccess ||
       hipMalloc(&h->d_scratch, sizeof(float) * (size_t)R * (d0 + 2 * e) + sizeof(int32_t) * n_steps) != hipSuccess ||
       hipMalloc(&h->d_x, sizeof(float) * B * HW) != hipSuccess || hipMalloc(&h->d_u, sizeof(float) * B * HW) != hipSuccess ||
-      hipMalloc(&h->d_step, sizeof(int)) != hipSuccess || hipMalloc(&h->d_seeds, sizeof(uint64_t) * B) != hipSuccess)
+      hipMalloc(&h->d_step, 2 * sizeof(int)) != hipSuccess || hipMalloc(&h->d_seeds, sizeof(uint64_t) * B) != hipSuccess)
     return fail(PRG_E_NOMEM, "prg_sampler_create: hipMalloc failed");
   PRG_HIP(hipMemcpy(h->d_steps, steps, sizeof(prg_step) * n_steps, hipMemcpyHostToDevice));
   PRG_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault));
@@ -985,7 +988,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
   const int e = L.emb, W = L.ss_total, B = h->B;
   int rc;
   if (seeds) PRG_HIP(hipMemcpyAsync(h->d_seeds, seeds, sizeof(uint64_t) * B, hipMemcpyHostToDevice, s));
-  PRG_HIP(hipMemsetAsync(h->d_step, 0, sizeof(int), s));
+  PRG_HIP(hipMemsetAsync(h->d_step, 0, 2 * sizeof(int), s));   // [step counter, arrival ticket]
   // camera half of the conditioning: Ppart[b] = W_p . SiLU(param_mlp(K_b))
   {
     float* h2 = h->d_scratch;
@@ -1016,7 +1019,8 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
     PRG_HIP(hipEventRecord(t0, s));
   }
   if (h->use_graph && !profiling && !u->taps_on) {
-    const bool stale = !h->exec || h->g_cond != img_cond || h->g_noise != noise || h->g_out != out || h->g_stream != s;
+    const bool stale = !h->exec || h->g_cond != img_cond || h->g_noise != noise || h->g_out != out || h->g_stream != s ||
+                       h->g_arena_gen != u->arena_gen;
     if (stale) {
       sampler_free(h);
       PRG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1027,7 +1031,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
       if (ce != hipSuccess) return fail(PRG_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
       h->graph = g;
       PRG_HIP(hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0));
-      h->g_cond = img_cond; h->g_noise = noise; h->g_out = out; h->g_stream = s;
+      h->g_cond = img_cond; h->g_noise = noise; h->g_out = out; h->g_stream = s; h->g_arena_gen = u->arena_gen;
     }
     for (int k = 0; k < h->n_steps; ++k) PRG_HIP(hipGraphLaunch(h->exec, s));
   } else {

@@ -74,6 +74,9 @@ class GaussianDiffusion:
         for k, v in make_schedule(self.num_timesteps).items():
             setattr(self, k, v)
         self._samplers = {}
+        dep = getattr(model, "_dependents", None)
+        if dep is not None:
+            dep.add(self)               # reloading / closing the network drops the samplers built on its old handle
 
     # -- transition table -------------------------------------------------------------------------
     def step_table(self) -> List[dict]:
@@ -82,7 +85,7 @@ class GaussianDiffusion:
         if not self.is_ddim_sampling:                                   # p_sample_loop (sd:1283-1317)
             for t in reversed(range(self.num_timesteps)):
                 sig = (0.5 * self.posterior_log_variance_clipped[t]).exp() if t > 0 else torch.tensor(0.0)
-                rows.append(dict(t=t, clip_pred=0, c_x0=self.posterior_mean_coef1[t], c_x=self.posterior_mean_coef2[t],
+                rows.append(dict(t=t, clip_pred=2, c_x0=self.posterior_mean_coef1[t], c_x=self.posterior_mean_coef2[t],
                                  c_eps=0.0, sigma=sig, sqrt_recip=self.sqrt_recip_alphas_cumprod[t],
                                  sqrt_recipm1=self.sqrt_recipm1_alphas_cumprod[t]))
         else:                                                           # ddim_sample (sd:1319-1392)

@@ -145,7 +145,7 @@ class Generator:
                 rpj_host = rpj.cpu().numpy()
                 prob = depth_correction(rpj)
                 rpj_c, hit_c, cond = G.apply_mask(prob, rpj, hit, mask_threshold)
-                seeds = [synthetic.noise_seed(noise_seed, i * 4096 + sample_idx) for i in idxs]
+                seeds = [synthetic.noise_seed(noise_seed, i, sample_idx) for i in idxs]
                 images = self.model.sample(param_cond=param_cond, img_cond=cond, seeds=seeds)
                 prob2 = depth_correction(images)
                 images, _, _ = G.apply_mask(prob2, images, None, mask_threshold, want_cond=False)

@@ -73,6 +73,10 @@ def synth_batch(base_seed: int, scene_indices, S: int):
     return np.stack(ds)[:, None], np.stack(ks), np.stack(ps)
 
 
-def noise_seed(base_seed: int, scene_index: int) -> int:
-    """64-bit Philox key for a scene's diffusion noise: shard-invariant (depends only on seed and index)."""
-    return int(np.random.SeedSequence([int(base_seed), int(scene_index), 0x6E6F6973]).generate_state(1, np.uint64)[0])
+def noise_seed(base_seed: int, scene_index: int, sample_index: int = 0) -> int:
+    """64-bit Philox key for the diffusion noise of (scene, sample): shard-invariant (depends only on the run's seed and
+    the two indices; no aliasing between scenes and samples)."""
+    words = [int(base_seed) & 0xFFFFFFFFFFFFFFFF, int(scene_index), 0x6E6F6973]
+    if sample_index:
+        words.append(int(sample_index))
+    return int(np.random.SeedSequence(words).generate_state(1, np.uint64)[0])

@@ -11,6 +11,7 @@ parity mode).  sd / dc = the reference's successive_ddnm_diffusion.py / depth_co
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -52,6 +53,9 @@ class _HipNet:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}")
         self.cfg, self.dtype = cfg, dtype
         self._h: Optional[C.c_void_p] = None
+        # objects holding library handles that point INTO this network's handle (samplers: captured graphs bake in its
+        # weight and workspace pointers); they are closed before the handle is destroyed
+        self._dependents: "weakref.WeakSet" = weakref.WeakSet()
         self.channels = cfg.in_channels if cfg.conditional else 1
         self.out_dim = cfg.out_channels
         self.random_or_learned_sinusoidal_cond = False   # asserted off by GaussianDiffusion (sd:1034)
@@ -76,6 +80,8 @@ class _HipNet:
         return self.load_state_dict(synth_state_dict(self.cfg, seed, **kw))
 
     def close(self):
+        for dep in list(self._dependents):
+            dep.close()
         if self._h is not None:
             _lib.load().prg_unet_destroy(self._h)
             self._h = None

@@ -89,6 +89,7 @@ def test_schedule_and_step_table_against_reference_goldens(golden):
     assert len(rows) == 1000 and [r["t"] for r in rows] == list(range(999, -1, -1)) and d.n_draws == 1000
     assert rows[-1]["sigma"] == 0.0 and rows[-1]["c_x0"] == 1.0 and rows[-1]["c_x"] == 0.0     # t = 0
     assert rows[0]["c_x0"] == float(g["posterior_mean_coef1"][999]) and rows[0]["c_eps"] == 0.0
+    assert all(r["clip_pred"] == 2 for r in rows)          # ancestral: clamp x0 after the DDNM replacement (sd:1250)
     assert rows[3]["sigma"] == float(np.exp(np.float32(0.5) * g["posterior_log_variance_clipped"][996]))
     d = GaussianDiffusion(_FakeNet(), image_size=32, timesteps=1000, sampling_timesteps=250)
     rows = d.step_table()
@@ -108,6 +109,8 @@ def test_synthetic_scenes_are_index_keyed():
     assert d1.dtype == np.float32 and d1.shape == (2, 1, 64, 64) and 0.0 <= d1.min() and d1.max() <= 0.35
     assert 0.02 < (d1 == 0).mean() < 0.1
     assert synthetic.noise_seed(0, 5) != synthetic.noise_seed(0, 6) and synthetic.noise_seed(0, 5) == synthetic.noise_seed(0, 5)
+    keys = {synthetic.noise_seed(3, i, s) for i in range(50) for s in range(50)}
+    assert len(keys) == 2500 and synthetic.noise_seed(3, 1, 0) == synthetic.noise_seed(3, 1)   # no scene/sample aliasing
 
 
 def test_flatten_state_dict_and_checkpoint_layouts():

@@ -5,7 +5,8 @@ Run:  python tools/make_goldens.py            (needs /root/reference; takes ~1-2
 Every fixture stores the inputs and the reference's outputs.  Network weights are NOT stored: they come from
 the build's deterministic initialiser (pointreggpt_amd.weights.synth_state_dict(cfg, seed)), loaded into the
 reference modules with load_state_dict, and are regenerated bit-identically by the tests.
-Fixture ids follow SURVEY.md §8c (G1..G12).
+Fixture ids follow SURVEY.md §8c (G1..G12); G12b..G17 were added in round 2 (benchmarked 128x128 configuration,
+the reference's shipped 256x256 resolution, float64 "exact arithmetic" envelopes, DDIM with known pixels > 1).
 """
 import os
 import sys
@@ -305,6 +306,159 @@ def g12_end_to_end():
          depth_out=out_img, cloud=cloud)
 
 
+# ------------------------------------------------------------------------------------------------
+# Round-2 fixtures: the BENCHMARKED configuration (dim 64, 128x128) and the reference's shipped setting (256x256),
+# each with the oracle evaluated in float64 on the same fp32 weights ("exact arithmetic": the oracle is pinned
+# bit-exactly to the reference in fp32, so its fp64 evaluation is the reference's function without roundoff) — the
+# distance |reference fp32 - exact| is the noise floor any fp32 implementation with another summation order sits in.
+# ------------------------------------------------------------------------------------------------
+from oracle import diffusion as OD  # noqa: E402  (tools may use the oracle; the product never does)
+from oracle import geometry as OG  # noqa: E402
+from oracle import unet as OU  # noqa: E402
+
+TAP_NAMES = ("init_conv", "down0_block0", "down0_attn", "down0_out", "mid_attn", "up0_out", "final_res")
+N_TAP_SAMPLES = 8192
+
+
+def f64(sdict):
+    return {k: v.double() for k, v in sdict.items()}
+
+
+def tap_index(name, numel, seed):
+    """Fixed pseudo-random flat indices into a (B,C,H,W) tap (full taps at 128x128 would be 8 MB each)."""
+    rng = np.random.default_rng([seed, sum(map(ord, name))])
+    return np.sort(rng.choice(numel, size=min(N_TAP_SAMPLES, numel), replace=False)).astype(np.int64)
+
+
+def unet_fixture(prefix, dim, wseed, S, B, xseed, t, out):
+    """Reference U-Net forward + subsampled taps, and the same from the float64 oracle."""
+    m = ref_unet(dim, wseed)
+    taps = hook_taps(m, {"init_conv": m.init_conv, "down0_block0": m.downs[0][0], "down0_attn": m.downs[0][2],
+                         "down0_out": m.downs[0][3], "mid_attn": m.mid_attn, "up0_out": m.ups[0][3],
+                         "final_res": m.final_res_block})
+    g = torch.Generator().manual_seed(xseed)
+    x = torch.randn((B, 1, S, S), generator=g)
+    tt = torch.tensor(t)
+    pc = (torch.tensor([[75.7486, 76.0456, 32.5, 32.0], [73.1, 73.4, 32.5, 32.0]]) * (S / 64))[:B]
+    y = m(x, tt, pc)
+    sdict = weights.synth_state_dict(weights.unet_config(dim), wseed)
+    taps64 = {}
+    y64 = OU.unet_forward(f64(sdict), x.double(), tt.double(), pc.double(), taps=taps64)
+    taps32 = {}
+    y32 = OU.unet_forward(sdict, x, tt, pc, taps=taps32)
+    assert torch.equal(y32, y), "oracle fp32 must reproduce the reference bit-exactly"
+    out.update({f"{prefix}x": x, f"{prefix}t": tt, f"{prefix}pc": pc, f"{prefix}y": y, f"{prefix}y64": y64})
+    for k in TAP_NAMES:
+        assert torch.equal(taps32[k], taps[k]), k
+        idx = tap_index(k, taps[k].numel(), wseed)
+        out[f"{prefix}tap_{k}_idx"] = idx
+        out[f"{prefix}tap_{k}"] = taps[k].reshape(-1)[idx]
+        out[f"{prefix}tap_{k}_64"] = taps64[k].reshape(-1)[idx]
+    e = (y.double() - y64).abs().max().item()
+    print(f"  {prefix or 'unet'} S={S}: |ref32 - exact|max = {e:.3e} on |y|max {y.abs().max().item():.2f}")
+
+
+def g13_unet_128():
+    out = {}
+    unet_fixture("", 64, 13, 128, 2, 13, [3, 900], out)
+    save("G13_unet_dim64_128", **out)
+
+
+def g14_chain_128():
+    """dim-64 ancestral chain (timesteps=8) at 128x128, B=2, mixed DDNM mask, stored noise; + the float64 oracle chain."""
+    S, B = 128, 2
+    m = ref_unet(64, 14)
+    pc = torch.tensor([[151.5, 152.1, 64.5, 64.0], [146.2, 146.8, 64.5, 64.0]])
+    cond = mixed_cond(B, S, 14)
+    d8 = ref_diffusion(m, S, T=8)
+    img, nz = recorded_noise(lambda: d8.sample(param_cond=pc, img_cond=cond, disable_tqdm=True), 1414)
+    sdict = weights.synth_state_dict(weights.unet_config(64), 14)
+    sch8 = OD.schedule(8)
+    den32 = lambda x, t, c: OU.unet_forward(sdict, x, t, c)
+    o32 = OD.sample(sch8, den32, pc, cond, S, OD.stored_noise(nz))
+    assert torch.equal(o32, img), "oracle fp32 chain must reproduce the reference bit-exactly"
+    s64 = f64(sdict)
+    den64 = lambda x, t, c: OU.unet_forward(s64, x.double(), t.double(), c.double())
+    o64 = OD.sample(sch8, den64, pc, cond.double(), S, lambda k: nz[k].double())
+    print(f"  chain8@128: |ref32 - exact|max = {(img.double() - o64).abs().max().item():.3e}")
+    save("G14_chain8_dim64_128", pc=pc, cond=cond, noise=nz, out=img, out64=o64)
+
+
+def g15_maskunet_128():
+    S, B = 128, 2
+    depth, _, _ = synthetic.synth_batch(15, range(B), S)
+    x = torch.tensor(depth)
+    m = ref_maskunet(64, 15, final_bias=6.0)
+    prob = m(x)
+    sdict = weights.synth_state_dict(weights.maskunet_config(64), 15, final_bias=6.0)
+    logit64 = OU.maskunet_forward(f64(sdict), x.double(), return_logits=True)
+    assert torch.equal(OU.maskunet_forward(sdict, x), prob)
+    save("G15_maskunet_dim64_128", depth=x, prob=prob, prob64=torch.sigmoid(logit64))
+
+
+def g16_unet_256():
+    """The reference's shipped resolution (generate_dataset.py:34-49): one dim-64 U-Net forward at 256x256, B=1."""
+    out = {}
+    unet_fixture("", 64, 16, 256, 1, 16, [417], out)
+    save("G16_unet_dim64_256", **out)
+
+
+def g17_ddim_cond_gt1():
+    """DDIM transitions whose known pixels exceed 1 after normalisation (a memory point farther than 10 m): ddim_sample
+    clamps only the raw network output (sd:1197-1201), the replaced values enter the state unclamped (sd:1218, 1371)."""
+    S, B, dim = 32, 2, 16
+    m = ref_unet(dim, 9)
+    pc = torch.tensor([[37.87, 38.02, 16.25, 16.0], [36.5, 36.7, 16.25, 16.0]])
+    cond = mixed_cond(B, S, 17)
+    g = torch.Generator().manual_seed(171)
+    far = (torch.rand((B, 1, S, S), generator=g) < 0.2) & (cond[:, 1:2] > 0)
+    cond[:, 0:1][far] = 1.0 + torch.rand((int(far.sum()),), generator=g)          # depth in (1, 2]: 10-15 m
+    d5 = ref_diffusion(m, S, T=1000, steps=5)
+    img, nz = recorded_noise(lambda: d5.sample(param_cond=pc, img_cond=cond, disable_tqdm=True), 1717)
+    d8 = ref_diffusion(m, S, T=8)
+    img8, nz8 = recorded_noise(lambda: d8.sample(param_cond=pc, img_cond=cond, disable_tqdm=True), 1718)
+    save("G17_ddim_cond_gt1", pc=pc, cond=cond, ddim5_noise=nz, ddim5_out=img, chain8_noise=nz8, chain8_out=img8)
+
+
+def g12b_envelope():
+    """Noise floor of the parity metric on the G12 chain (64x64, 50-step DDIM, dim 64): the reference against (a) itself
+    with one thread instead of eight (another oneDNN blocking: another summation order) and (b) exact arithmetic."""
+    g = np.load(os.path.join(OUT, "G12_end_to_end_64.npz"))
+    sdict = weights.synth_state_dict(weights.unet_config(64), 12)
+    mask_sd = weights.synth_state_dict(weights.maskunet_config(64), 13, final_bias=6.0)
+    sch = OD.schedule(1000)
+    K, pose = g["K"], g["pose"]
+    pc = OG.param_vector(torch.tensor(K))
+    cond, noise, ref = torch.tensor(g["img_cond"]), torch.tensor(g["noise"]), torch.tensor(g["sampled"])
+
+    def cloud_of(img, thr2, msd):
+        prob2 = OU.maskunet_forward(msd, img)
+        o = torch.where(prob2 > thr2, img, torch.zeros_like(img))
+        c = OG.point_cloud(o[0, 0].numpy() * 10, K[0], (0.5, 10.0))
+        return OG.inverse_pose_apply(c, pose[0]), (o > 0)
+
+    den = lambda x, t, c: OU.unet_forward(sdict, x, t, c)
+    torch.set_num_threads(1)
+    s1 = OD.sample(sch, den, pc, cond, 64, OD.stored_noise(noise), sampling_steps=50)
+    torch.set_num_threads(8)
+    s8 = OD.sample(sch, den, pc, cond, 64, OD.stored_noise(noise), sampling_steps=50)
+    assert torch.equal(s8, ref)
+    s64d = f64(sdict)
+    den64 = lambda x, t, c: OU.unet_forward(s64d, x.double(), t.double(), c.double())
+    s64 = OD.sample(sch, den64, pc, cond.double(), 64, lambda k: noise[k].double(), sampling_steps=50)
+    thr2 = float(g["thr2"])
+    c_ref, m_ref = cloud_of(ref, thr2, mask_sd)
+    assert np.array_equal(c_ref, g["cloud"])
+    c1, m1 = cloud_of(s1, thr2, mask_sd)
+    c64, m64 = cloud_of(s64.float(), thr2, mask_sd)
+    rep = {"depth_1thread": (s1 - ref).abs().max().item(), "depth_exact": (s64 - ref.double()).abs().max().item()}
+    for name, c, mk in (("xyz_1thread", c1, m1), ("xyz_exact", c64, m64)):
+        rep[name] = float(np.abs(c - c_ref).max()) if torch.equal(mk, m_ref) else float("nan")
+    print("  G12 envelope:", rep)
+    save("G12b_envelope", sampled_1thread=s1, sampled_exact=s64,
+         **{k: np.float64(v) for k, v in rep.items()})
+
+
 def spec_fixture():
     import json
     spec = {"unet64": [[k, list(v.shape)] for k, v in sd.Unet(dim=64, param_cond_dim=4).state_dict().items()],
@@ -320,7 +474,8 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])
     jobs = [("g1", g1_schedule), ("g2", g2_intrinsics), ("g3", g3_pose), ("g4", g4_pc2depth), ("g5", g5_g6_reproject),
             ("g7", g7_unet_taps), ("g8", g8_unet_full), ("g9", g9_g10_sampler), ("g11", g11_maskunet),
-            ("g12", g12_end_to_end), ("spec", spec_fixture)]
+            ("g12", g12_end_to_end), ("g12b", g12b_envelope), ("g13", g13_unet_128), ("g14", g14_chain_128),
+            ("g15", g15_maskunet_128), ("g16", g16_unet_256), ("g17", g17_ddim_cond_gt1), ("spec", spec_fixture)]
     for name, fn in jobs:
         if not only or name in only:
             fn()
