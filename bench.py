@@ -28,6 +28,14 @@ MASK_GFLOP = {64: 14.787, 128: 59.173, 256: 237.096}
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}        # dense, MI355X_MICROARCH.md chip table
 
 
+def conv_sources_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("conv_ws.hip", "conv.hip", "conv.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "pointreggpt_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -44,6 +52,10 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--profile-transitions", type=int, default=40)
+    p.add_argument("--no-e2e-files", action="store_true", help="skip the generate_dataset leg (files on disk)")
+    p.add_argument("--e2e-batches", type=int, default=2)
+    p.add_argument("--no-drift", action="store_true", help="skip the bf16-vs-fp32 end-to-end drift measurement")
+    p.add_argument("--drift-scenes", type=int, default=4)
     return p.parse_args()
 
 
@@ -89,6 +101,110 @@ def cpu_baseline(size, dim):
             "sample": f"oracle p_sample (torch-CPU fp32, {used} threads = fastest of a sweep on a {os.cpu_count()}-core host), "
                       f"batch {B}, {size}x{size}, {n} timed transitions = {dt:.3f} s/transition, extrapolated x{T} "
                       f"transitions; MaskUnet/geometry (0.2% of the work) omitted"}
+
+
+def mem_rooflines(G, bt, mask_net, S, B, pr):
+    """HIP-event bandwidth of the memory-bound kernels of one pair (north_star: 'coalesced HBM loads ... evidenced by
+    HBM-GB/s'): algorithmic bytes per pixel (fp32 images, float64 points) / average launch time over
+    `reps` back-to-back launches on torch's current stream (the stream these kernels are launched on)."""
+    reps = 50
+    npx = B * S * S
+    rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+    prob = torch.rand_like(rpj)
+    cases = {
+        "reproject_zbuffer (unproject + SE(3) + atomicMin z-buffer + resolve)":
+            (9, lambda: G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)),
+        "unproject_f64 (+ inverse pose)": (4 + 24 + 1, lambda: G.unproject_f64(rpj, bt["K"], bt["pose"])),
+        "depth_augment": (4 + 12, lambda: G.depth_augment(rpj)),
+        "apply_mask (+ condition assembly)": (4 + 4 + 1 + 4 + 1 + 8, lambda: G.apply_mask(prob, rpj, hit, 0.5)),
+    }
+    out = {}
+    for name, (bpp, fn) in cases.items():
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out[name] = {"bytes_per_px": bpp, "avg_us": us, "GBps": bpp * npx / (us * 1e-6) / 1e9,
+                     "note": "includes the wrapper's output allocations (torch caching allocator, no sync)"}
+    if pr.get("step_launches"):
+        us = pr["step_ms"] * 1e3 / pr["step_launches"]
+        out["sampler_step (x0, DDNM replace, posterior/DDIM, Philox noise)"] = {
+            "bytes_per_px": 20, "avg_us": us, "GBps": 20 * npx / (us * 1e-6) / 1e9,
+            "note": "HIP events inside the library around every launch of the profiled transitions"}
+    for v in out.values():
+        v["frac_of_8TBps"] = v["GBps"] / 8000.0
+    return {"bound": "hbm", "peak_GBps": 8000.0, "pixels_per_launch": npx, "kernels": out,
+            "reading": "1 Mpx per launch = 9-30 MB: these launches last 4-12 us and are latency-bound, not bandwidth-bound"}
+
+
+def e2e_files(a, unet, mask, diff, rank, world, B, S):
+    """generate_dataset.py's own loop (Generator.generate, synthetic scenes) for `e2e_batches` batches INCLUDING every file
+    of the reference's layout (2 PLY + 5 PNG + 2 text files per pair): host post-processing runs on the library's C++
+    writer pool while the GPU samples the next batch.  Returns pairs on disk / wall time of this rank."""
+    import shutil
+    import tempfile
+    from pointreggpt_amd.generator import Generator
+    root = tempfile.mkdtemp(prefix=f"prg_e2e_r{rank}_")
+    try:
+        gen = Generator(diff, None, batch_size=B, samples_folder=os.path.join(root, "data"), synthetic_seed=a.seed)
+        first = 10_000_000 + rank * (a.e2e_batches + 1) * B
+        st = {}
+        gen.generate(first, first + B, 1, depth_correction=mask, stats=st)          # warm-up batch (graph capture, pool start)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gen.generate(first + B, first + (a.e2e_batches + 1) * B, 1, depth_correction=mask, stats=st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nfiles = sum(len(f) for _d, _s, f in os.walk(os.path.join(root, "data")))
+        nbytes = sum(os.path.getsize(os.path.join(d, f)) for d, _s, fs in os.walk(os.path.join(root, "data")) for f in fs)
+        return {"pairs": a.e2e_batches * B, "seconds": dt, "files_written": nfiles, "bytes_written": nbytes,
+                "writer_threads": st.get("writer_threads"), "dir": "tmpfs/tmp (deleted)"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def bf16_drift(a, G, synthetic, S, n_trans_rows):
+    """How far the throughput mode (bf16) lands from the parity mode (fp32 HIP, pinned to the reference by the golden
+    tests) on the SAME scenes, Philox keys and full transition table: depth in metres over in-painted pixels and the
+    point-XYZ difference of the pixels both runs keep."""
+    from pointreggpt_amd.diffusion import GaussianDiffusion
+    from pointreggpt_amd.unet import MaskUnet, Unet
+    n = a.drift_scenes
+    idx = list(range(20_000_000, 20_000_000 + n))
+    depth, K, pose = synthetic.synth_batch(a.seed, idx, S)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_depth, d_K, d_pose = (torch.from_numpy(x).to(dev) for x in (depth, K, pose))
+    seeds = [synthetic.noise_seed(a.seed, j) for j in idx]
+    res = {}
+    for dt in ("fp32", "bf16"):
+        unet = Unet(a.dim, dtype=dt).init_synthetic(seed=1)
+        mask = MaskUnet(a.dim, dtype=dt).init_synthetic(seed=2, final_bias=6.0)
+        diff = GaussianDiffusion(unet, image_size=S, timesteps=a.timesteps, sampling_timesteps=a.sampling_steps)
+        rpj, hit = G.reproject_tensor(d_depth, d_K, d_pose, clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+        _, hit_c, cond = G.apply_mask(mask(rpj), rpj, hit, 0.99)
+        img = diff.sample(param_cond=G.param_vector(d_K), img_cond=cond, seeds=seeds)
+        out, _, _ = G.apply_mask(mask(img), img, None, 0.99, want_cond=False)
+        xyz, valid = G.unproject_f64(out, d_K, d_pose)
+        res[dt] = (img.cpu(), hit_c.cpu(), xyz.cpu(), valid.cpu())
+        diff.close(); unet.close(); mask.close()
+    (i32, k32, x32, v32), (i16, k16, x16, v16) = res["fp32"], res["bf16"]
+    same_known = bool(torch.equal(k32, k16))
+    free = ~(k32 | k16)
+    dd = (i32 - i16).abs()[free] * 10.0
+    both = v32 & v16
+    dx = (x32 - x16).abs().max(dim=-1).values[both]
+    return {"scenes": n, "image_size": S, "transitions": n_trans_rows, "reference": "this library's fp32 parity mode, same Philox keys",
+            "known_mask_identical": same_known, "inpainted_fraction": float(free.float().mean()),
+            "inpainted_depth_m": {"max": float(dd.max()) if dd.numel() else 0.0, "mean": float(dd.mean()) if dd.numel() else 0.0,
+                                  "median": float(dd.median()) if dd.numel() else 0.0},
+            "xyz_m_points_kept_by_both": {"max": float(dx.max()) if dx.numel() else 0.0, "mean": float(dx.mean()) if dx.numel() else 0.0},
+            "kept_by_only_one_fraction": float((v32 ^ v16).float().mean()),
+            "known_pixels": "bit-identical to the condition in both modes (DDNM replacement)"}
 
 
 def main():
@@ -167,7 +283,8 @@ def main():
                   (0 if a.sampler_only else 2 * MASK_GFLOP.get(S, 59.173 * (S / 128) ** 2))) / 1e3
 
     res = {
-        "metric": "generated point-cloud pairs/sec (node), 128x128 depth, 1000-step DDNM",
+        "metric": "generated point-cloud pairs/sec (node), {0}x{0} depth, {1}-step {2}".format(
+            S, n_trans, "DDNM" if not diff.is_ddim_sampling else "DDIM (DDNM replacement, eta=1)"),
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
@@ -176,7 +293,8 @@ def main():
                    "batch_per_gpu": B, "image_size": S, "transitions": n_trans,
                    "sampler": "ddim" if diff.is_ddim_sampling else "ancestral-ddnm", "unet_dim": a.dim,
                    "noise": "on-device Philox4x32-10 keyed per scene", "weights": "synthetic (deterministic initialiser)",
-                   "parallelism": f"scene-sharded x{world}, no collectives", "hipgraph": True,
+                   "parallelism": f"scene-sharded x{world}, no collectives",
+                   "hipgraph": "one captured transition (U-Net + update), replayed per step",
                    "tflop_per_pair": tflop_pair},
         "end_to_end_mfma_frac": value / world * tflop_pair / MFMA_PEAK_TFLOPS[a.dtype],
     }
@@ -197,12 +315,16 @@ def main():
         pr = pdiff.last_profile(B)
         ach = pr["conv_flops"] / (pr["conv_ms"] * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
         if os.path.exists(tpath) and B == 64 and S == 128 and a.dtype == "bf16":
             # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same workload (bench.py cannot
-            # run the profiler on itself); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
+            # run the profiler on itself); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  The file
+            # records the hash of the conv kernel sources it was measured on: a stale measurement is refused (null).
             tj = json.load(open(tpath))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_conv_hbm_traffic.json"
+            if tj.get("kernel_sources_sha256") == conv_sources_hash():
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/conv_hbm_traffic.json (sources hash matches)"
+            else:
+                traffic_src = "profiles/conv_hbm_traffic.json is stale (conv kernel sources changed since the PMC passes): not reported"
         res["roofline"] = {
             "kernel": "MFMA convolutions: conv3x3_ws_kernel (3x3, wave-specialised persistent) + conv_igemm_kernel (1x1 / 4x4s2)",
             "bound": "mfma", "achieved": ach,
@@ -215,7 +337,24 @@ def main():
             "share_of_step_time": pr["conv_ms"] / pr["total_ms"],
             "measured": f"HIP events around every conv launch, {nprof} transitions, batch {B}",
         }
+        if not a.sampler_only:
+            res["roofline_mem"] = mem_rooflines(G, bt, mask, S, B, pr)
         pdiff.close()
+    if not a.no_e2e_files and not a.sampler_only:
+        # every rank runs its own shard of the generate_dataset loop; aggregate like the headline metric
+        e2e = e2e_files(a, unet, mask, diff, rank, world, B, S)
+        dt_e = e2e["seconds"]
+        if dist is not None:
+            tt = torch.tensor([dt_e], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_e = float(tt.item())
+        e2e.update(value=world * e2e["pairs"] / dt_e, unit="pairs/s on disk (whole job)", seconds_max_over_ranks=dt_e,
+                   vs_device_only=world * e2e["pairs"] / dt_e / value,
+                   what="Generator.generate --synthetic: memory-cloud z-buffer + MaskUnet + sampler + MaskUnet + unprojection + "
+                        "crop / 0.025 voxel grid / PLY + PNG + text files through the C++ writer pool, overlapped with the next batch")
+        res["e2e_files"] = e2e
+    if rank == 0 and not a.no_drift and a.dtype == "bf16" and not a.sampler_only:
+        res["bf16_drift"] = bf16_drift(a, G, synthetic, S, n_trans)
     if rank == 0 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(S, a.dim)
 

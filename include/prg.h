@@ -88,6 +88,18 @@ int prg_depth_augment(const float* depth, float* out, int B, int H, int W, void*
 int prg_apply_mask(const float* prob, const float* depth, const uint8_t* hit, float thr, float* depth_out,
                    uint8_t* hit_out, float* img_cond, int B, int H, int W, void* stream);
 
+/* occlusion_filter of Tester.sample (sd:446-463): depth (B,1,H,W) [metres], mask (B,1,H,W) bytes -> out: every pixel
+ * more than `threshold` (0.0375) behind the nearest VALID depth of its 3x3 window takes that depth.  out != depth.   */
+int prg_occlusion_filter(const float* depth, const uint8_t* mask, float* out, int B, int H, int W, float threshold,
+                         void* stream);
+
+/* compute_overlap_ratio of generate_gt.py:68-102 for a batch of cloud pairs, after the caller's voxel down-sampling:
+ * pts (total,3) float64 DEVICE, offsets (2*n_pairs+1) int64 DEVICE — pair p is clouds [off[2p],off[2p+1]) and
+ * [off[2p+1],off[2p+2]) — counts (n_pairs,2) int32 DEVICE: points of the first / second cloud that have a point of
+ * the other strictly within `radius` (float64 squared distances, exact all-pairs test).  max_cloud = largest cloud.  */
+int prg_overlap_counts(const double* pts, const int64_t* offsets, int n_pairs, int64_t max_cloud, double radius,
+                       int32_t* counts, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * U-Nets (MFMA kernels)
  * ---------------------------------------------------------------------------------------------------- */
@@ -151,7 +163,9 @@ typedef struct prg_sampler prg_sampler;
 typedef struct prg_step {
   int32_t t;            /* timestep fed to the U-Net */
   int32_t clip_pred;    /* bit 0: clamp the network output before deriving eps (DDIM rows = 1);
-                           bit 1: clamp x0 after the DDNM replacement (ancestral rows = 2) */
+                           bit 1: clamp x0 after the DDNM replacement (ancestral rows = 2);
+                           bit 2 (= 4, alone): refine row of has_refine_step (sd:1307-1314, 1374-1388):
+                                  x' = known ? clamp(u,-1,1) : x, no replacement, coefficients ignored */
   float c_x0, c_x, c_eps, sigma;
   float sqrt_recip, sqrt_recipm1;
 } prg_step;
@@ -184,6 +198,42 @@ int prg_sampler_get_profile(prg_sampler* h, double* conv_ms, int64_t* conv_launc
 /* Algorithmic bytes of the same launches (each input and output element once, plus the weights): what the PMC-measured
  * HBM traffic of bench.py's `roofline.traffic` is compared with. */
 int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes);
+/* The same for the per-transition update kernel (x0 / DDNM replace / posterior / noise: HBM-bound, 20 B per pixel). */
+int prg_sampler_get_profile_step(prg_sampler* h, double* step_ms, int64_t* step_launches);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Host post-processing of the generated views (HOST pointers; plain C++ threads, no device work)
+ *
+ * Replaces what Generator.generate delegates to open3d / torchvision / cv2 after every batch (sd:2484-2500,
+ * 2586-2685): compaction, rigid moves, PointCloud.crop(AxisAlignedBoundingBox), voxel_down_sample, io.write_point_cloud,
+ * utils.save_image, cv2.imwrite, np.savetxt.  The pool runs them on worker threads while the GPU samples the next
+ * batch.  Semantics = pointreggpt_amd/postprocess.py (Open3D 0.17 as recalled: parity-unpinned).
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* pts (n,3) float64 -> out (<= n,3), *n_out; keep lo <= p <= hi (inclusive).                                     */
+int prg_host_crop_aabb(const double* pts, int64_t n, const double* lo, const double* hi, double* out, int64_t* n_out);
+/* Voxel-grid mean: voxel = floor((p - (min - voxel/2)) / voxel); out (<= n,3) in ascending voxel order.         */
+int prg_host_voxel_down_sample(const double* pts, int64_t n, double voxel, double* out, int64_t* n_out);
+/* binary_little_endian PLY with `double x y z` vertices (what the example dataloaders read).                    */
+int prg_host_write_ply(const char* path, const double* pts, int64_t n);
+
+typedef struct prg_pool prg_pool;
+int prg_pool_create(int n_threads, prg_pool** out);
+int prg_pool_destroy(prg_pool* p);              /* finishes queued jobs first */
+/* Block until every submitted job has finished; returns the first job error (message via prg_last_error).       */
+int prg_pool_wait(prg_pool* p, int64_t* jobs_done);
+/* One cloud file (inputs are copied; the call returns immediately): xyz (n,3) float64 rows with valid[i] != 0 (NULL =
+ * all) -> T_pre (4x4 row-major or NULL) -> crop to [lo,hi] (if crop) -> voxel mean (if voxel > 0) -> T_post -> PLY.
+ * sample-000000: (valid, NULL, crop, 0.025, NULL) (sd:2484-2500); sample-000001: (valid, pose0, crop, 0.025,
+ * pose0^-1) (sd:2641-2658).                                                                                    */
+int prg_pool_submit_cloud(prg_pool* p, const char* path, const double* xyz, int64_t n, const uint8_t* valid,
+                          const double* T_pre, int crop, const double* lo, const double* hi, double voxel,
+                          const double* T_post);
+/* img (H,W) float32 in [0,1]: kind 0 = utils.save_image (8-bit RGB, x*255+0.5 clamped; sd:2588-2612),
+ * kind 1 = cv2.imwrite of uint16(img * 1e4) (sd:2618-2620).                                                     */
+int prg_pool_submit_image(prg_pool* p, const char* path, const float* img, int H, int W, int kind);
+/* np.savetxt(path, values (rows, cols)) with the default "%.18e" format (sd:2462-2467, 2555-2561).              */
+int prg_pool_submit_text(prg_pool* p, const char* path, const double* values, int rows, int cols);
 
 #ifdef __cplusplus
 }

@@ -99,20 +99,33 @@ def p_sample(sch, denoise, x, t: int, param_cond, img_cond, noise: Optional[torc
     return mean + 0.0, x0
 
 
-def p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn, T: Optional[int] = None):
-    """T-step DDNM ancestral chain (sd:1283-1317, has_refine_step=False).  noise_fn(0) is the start
-    image; noise_fn(k) for k = 1..T-1 feeds the step at t = T-k; t = 0 draws nothing."""
+def refine(sch, denoise, img, param_cond, img_cond):
+    """has_refine_step (sd:1307-1314 ancestral, sd:1374-1388 DDIM; same arithmetic): one more evaluation at t = 0 with
+    the DDNM replacement banned; the KNOWN pixels take its clamped output (posterior mean at t = 0 is x0 itself:
+    coef1[0] = 1, coef2[0] = 0), the in-painted ones keep their value."""
+    tt = torch.zeros((img.shape[0],), dtype=torch.long)
+    x0 = denoise(img, tt, param_cond).clamp(-1.0, 1.0)
+    mean = sch["posterior_mean_coef1"][0] * x0 + sch["posterior_mean_coef2"][0] * img
+    return torch.where(cond_mask(img_cond), mean, img)
+
+
+def p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn, T: Optional[int] = None,
+                  has_refine_step: bool = False):
+    """T-step DDNM ancestral chain (sd:1283-1317).  noise_fn(0) is the start image; noise_fn(k) for k = 1..T-1 feeds
+    the step at t = T-k; t = 0 draws nothing."""
     T = T or sch["betas"].shape[0]
     img = noise_fn(0)
     assert tuple(img.shape) == tuple(shape)
     for k, t in enumerate(range(T - 1, -1, -1)):
         img, _ = p_sample(sch, denoise, img, t, param_cond, img_cond, noise_fn(k + 1) if t > 0 else None)
+    if has_refine_step:
+        img = refine(sch, denoise, img, param_cond, img_cond)
     return (img + 1) * 0.5
 
 
 def ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps: int, eta: float = 1.0,
-                T: Optional[int] = None):
-    """DDIM with eta (sd:1319-1392, has_refine_step=False): clamped x_start, no draw on the last pair."""
+                T: Optional[int] = None, has_refine_step: bool = False):
+    """DDIM with eta (sd:1319-1392): clamped x_start, no draw on the last pair."""
     T = T or sch["betas"].shape[0]
     ac = sch["alphas_cumprod"]
     img = noise_fn(0)
@@ -126,18 +139,20 @@ def ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps: int,
         sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
         c = (1 - an - sigma ** 2).sqrt()
         img = x0 * an.sqrt() + c * eps + sigma * noise_fn(k + 1)
+    if has_refine_step:
+        img = refine(sch, denoise, img, param_cond, img_cond)
     return (img + 1) * 0.5
 
 
 def sample(sch, denoise, param_cond, img_cond, image_size: int, noise_fn, sampling_steps: Optional[int] = None,
-           eta: float = 1.0):
+           eta: float = 1.0, has_refine_step: bool = False):
     """Dispatch exactly like sd:1394-1409: ancestral iff sampling_steps == T."""
     T = sch["betas"].shape[0]
     steps = sampling_steps or T
     shape = (param_cond.shape[0], 1, image_size, image_size)
     if steps < T:
-        return ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps, eta)
-    return p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn)
+        return ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps, eta, has_refine_step=has_refine_step)
+    return p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn, has_refine_step=has_refine_step)
 
 
 def torch_stream_noise(shape, generator: Optional[torch.Generator] = None):

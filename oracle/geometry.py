@@ -149,3 +149,33 @@ def project_cloud(cloud: np.ndarray, pose: np.ndarray, K: np.ndarray, S: int):
     moved = cloud @ pose[:3, :3].T + pose[:3, 3]
     pc = torch.tensor(moved[None])
     return pc2depth_tensor(pc, torch.ones(pc.shape[:2], dtype=torch.bool), torch.tensor(K[None]), (S, S))
+
+
+def occlusion_filter(depth_rpj: torch.Tensor, mask_rpj: torch.Tensor):
+    """3x3 min over valid neighbours; pixels >= 0.0375 m behind it take that minimum (sd:446-463)."""
+    import torch.nn.functional as F
+    pre = depth_rpj.clone()
+    pre[~mask_rpj] = float("inf")
+    mn = -F.max_pool2d(-pre, kernel_size=3, stride=1, padding=1)
+    keep = (depth_rpj - mn) < 0.0375
+    return torch.where(keep, depth_rpj, mn), mask_rpj
+
+
+def random_sample_transform(K: np.ndarray, image_size: int = 256) -> np.ndarray:
+    """Frustum-bounded random rotation, zero translation (sd:377-415).  Draw order on the legacy numpy stream:
+    rand(B) theta, rand(B) phi, rand(B) psi, randn(B,3) (multiplied by 0)."""
+    from scipy.spatial.transform import Rotation
+    B = K.shape[0]
+    fx, fy, cx, cy = K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2]
+    h = w = image_size
+    th0, th1 = -np.arctan((h - cy) / fy), np.arctan(cy / fy)
+    ph0, ph1 = -np.arctan(cx / fx), np.arctan((w - cx) / fx)
+    theta = np.random.rand(B) * (th1 - th0) + th0
+    phi = np.random.rand(B) * (ph1 - ph0) + ph0
+    psi = np.random.rand(B) * 2 * np.pi - np.pi
+    R = Rotation.from_euler("XYZ", np.stack((theta, phi, psi), -1)).as_matrix()
+    t = np.random.randn(B, 3) / 3 * 0
+    T = np.stack([np.eye(4) for _ in range(B)])
+    T[..., :3, :3] = R
+    T[..., :3, 3] = t
+    return T.astype(np.float32)

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "prg_unproject_f64": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P]),
     "prg_depth_augment": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "prg_apply_mask": (C.c_int, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "prg_occlusion_filter": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "prg_overlap_counts": (C.c_int, [_P, _P, _I, _L, C.c_double, _P, _P]),
     "prg_unet_param_count": (_L, [C.POINTER(UnetConfigC)]),
     "prg_unet_create": (C.c_int, [C.POINTER(UnetConfigC), _P, _L, _I, C.POINTER(_P)]),
     "prg_unet_destroy": (C.c_int, [_P]),
@@ -58,6 +60,16 @@ PROTOTYPES = {
     "prg_sampler_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]),
     "prg_sampler_get_profile_bytes": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "prg_sampler_get_profile_step": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
+    "prg_host_crop_aabb": (C.c_int, [_P, _L, _P, _P, _P, C.POINTER(_L)]),
+    "prg_host_voxel_down_sample": (C.c_int, [_P, _L, C.c_double, _P, C.POINTER(_L)]),
+    "prg_host_write_ply": (C.c_int, [C.c_char_p, _P, _L]),
+    "prg_pool_create": (C.c_int, [_I, C.POINTER(_P)]),
+    "prg_pool_destroy": (C.c_int, [_P]),
+    "prg_pool_wait": (C.c_int, [_P, C.POINTER(_L)]),
+    "prg_pool_submit_cloud": (C.c_int, [_P, C.c_char_p, _P, _L, _P, _P, _I, _P, _P, C.c_double, _P]),
+    "prg_pool_submit_image": (C.c_int, [_P, C.c_char_p, _P, _I, _I, _I]),
+    "prg_pool_submit_text": (C.c_int, [_P, C.c_char_p, _P, _I, _I]),
 }
 
 _lib = None
@@ -68,6 +80,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch's wheel carries its own libamdhip64: import it FIRST so this library binds to the HIP runtime torch already
+    # initialised (loading /opt/rocm's copy first leaves the process with two runtimes, one of which sees no device)
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise PrgError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"or `make -C pointreggpt_amd/csrc` (there is no CPU fallback)")

@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
 // =====================================================================================================
 template <int C>
 __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
-                                                           const float* __restrict__ pmax, float* __restrict__ ctxp,
-                                                           float* __restrict__ sump, int N, int nslab) {
+                                                           const float* __restrict__ pmax, const float* __restrict__ kshift,
+                                                           float* __restrict__ ctxp, float* __restrict__ sump, int N, int nslab) {
   using G = Geo<C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]
@@ -194,8 +194,17 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
   bf16x8 wk[G::KK], wv[G::KK];                         // k and v rows of head `wave`
   load_wfrags<C>(wk, wqkv, kHid + 32 * wave, l31, hi);
   load_wfrags<C>(wv, wqkv, 2 * kHid + 32 * wave, l31, hi);
-  float m = -INFINITY;                                 // global column maximum: fixed-order reduce of the slab maxima
-  for (int s2 = 0; s2 < nslab; ++s2) m = fmaxf(m, pmax[((size_t)b * nslab + s2) * kHid + 32 * wave + l31]);
+  // Shift of the softmax over pixels (any shift gives the same softmax): either the static bound of this column,
+  // |k[n][d]| <= ||w_d|| sqrt(C) because a LayerNorm output has norm <= sqrt(C) (computed once at weight load; used when
+  // it is small enough that exp(k - bound) cannot underflow: no extra pass over x), or the measured column maximum
+  // (fixed-order reduce of la_kmax's slab maxima).
+  float m;
+  if (kshift) {
+    m = kshift[32 * wave + l31];
+  } else {
+    m = -INFINITY;
+    for (int s2 = 0; s2 < nslab; ++s2) m = fmaxf(m, pmax[((size_t)b * nslab + s2) * kHid + 32 * wave + l31]);
+  }
   f32x16 ctx = zero16();                               // rows d, column e = l31 of head `wave`
   float ssum = 0.0f;
   XTile<C> xt;
@@ -517,6 +526,82 @@ __global__ __launch_bounds__(256) void full_attn_mfma_kernel(const bf16_t* __res
   }
 }
 
+
+// Same contraction for N up to 1024 tokens (the 256x256 bottleneck, 32 x 32): the score tile of a (query tile, key tile)
+// pair no longer stays in registers for all key tiles, so the keys are walked twice — pass 1 the row maxima (2 MFMAs per
+// key tile), pass 2 the scores again, exp, row sums and V^T P (4 MFMAs) — the reference's two-pass softmax order.  K and
+// V^T of one (image, head) fill the LDS (146 KB at N = 1024: one block per CU); QS blocks share a head, each takes every
+// QS-th query tile so the grid covers the chip at B = 16.
+template <int NT, int QS>
+__global__ __launch_bounds__(256) void full_attn_mfma_big_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out) {
+  constexpr int N = 32 * NT, LDK = 40, LDV = N + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  __bf16* Ks = reinterpret_cast<__bf16*>(smem_attn);          // [N][LDK]
+  __bf16* Vt = Ks + N * LDK;                                    // [32][LDV]
+  const int h = blockIdx.x, b = blockIdx.y, qs = blockIdx.z, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const bf16_t* base = qkv + (size_t)b * N * 384;
+  for (int i = tid; i < N * 4; i += 256) {
+    const int key = i >> 2, u = i & 3;
+    *reinterpret_cast<uint4*>(Ks + key * LDK + u * 8) =
+        *reinterpret_cast<const uint4*>(base + (size_t)key * 384 + 128 + h * 32 + u * 8);
+    const uint4 vv = *reinterpret_cast<const uint4*>(base + (size_t)key * 384 + 256 + h * 32 + u * 8);
+    const int d = key & 31;
+    const int pos = (key & ~31) + (d >> 4) * 16 + ((d >> 2) & 1) * 8 + ((d >> 3) & 1) * 4 + (d & 3);
+    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      reinterpret_cast<uint16_t*>(Vt)[(u * 8 + 2 * j) * LDV + pos] = (uint16_t)(w[j] & 0xffffu);
+      reinterpret_cast<uint16_t*>(Vt)[(u * 8 + 2 * j + 1) * LDV + pos] = (uint16_t)(w[j] >> 16);
+    }
+  }
+  __syncthreads();
+  for (int qt = qs * 4 + wave; qt < NT; qt += 4 * QS) {
+    const bf16_t* qp = base + (size_t)(qt * 32 + l31) * 384 + h * 32 + hi * 8;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qp), q1 = *reinterpret_cast<const bf16x8*>(qp + 16);
+    float m = -INFINITY;
+#pragma unroll 2
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x16 sa = zero16();
+      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Ks + kt * 32 * LDK, LDK, l31, hi, 0), q0, sa, 0, 0, 0);
+      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Ks + kt * 32 * LDK, LDK, l31, hi, 1), q1, sa, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sa[r] * 0.17677669529663687f);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.0f;
+    f32x16 oacc = zero16();
+#pragma unroll 2
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x16 sa = zero16();
+      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Ks + kt * 32 * LDK, LDK, l31, hi, 0), q0, sa, 0, 0, 0);
+      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Ks + kt * 32 * LDK, LDK, l31, hi, 1), q1, sa, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 pb;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const float pv = fast_exp(sa[8 * i + s2] * 0.17677669529663687f - m);
+          l += pv;
+          pb[s2] = (__bf16)pv;
+        }
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            *reinterpret_cast<const bf16x8*>(Vt + l31 * LDV + kt * 32 + i * 16 + hi * 8), pb, oacc, 0, 0, 0);
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    bf16_t* op = out + ((size_t)b * N + qt * 32 + l31) * 128 + h * 32 + 4 * hi;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      uint2 w;
+      w.x = pack2(oacc[4 * g4] * inv, oacc[4 * g4 + 1] * inv);
+      w.y = pack2(oacc[4 * g4 + 2] * inv, oacc[4 * g4 + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 8 * g4) = w;
+    }
+  }
+}
+
 template <int C>
 size_t lds_kmax() { return (size_t)kTP * Geo<C>::LDW * 2; }
 template <int C>
@@ -654,7 +739,7 @@ int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* 
 
 template <int C>
 int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias, const float* out_g, bf16_t* out,
-             float* ws, int B, int N, hipStream_t s) {
+             float* ws, int B, int N, const float* kshift, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     int rc;
@@ -669,9 +754,11 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
   float* sump = ctxp + (size_t)B * 4 * nslab * 1024;
   bf16_t* ctxT = reinterpret_cast<bf16_t*>(sump + (size_t)B * 4 * nslab * 32);
   const dim3 grid(nslab, B);
-  la_kmax_fused_kernel<C><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, N, nslab);
-  PRG_LAUNCH_CHECK();
-  la_ctx_fused_kernel<C><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, ctxp, sump, N, nslab);
+  if (!kshift) {
+    la_kmax_fused_kernel<C><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, N, nslab);
+    PRG_LAUNCH_CHECK();
+  }
+  la_ctx_fused_kernel<C><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
   PRG_LAUNCH_CHECK();
   la_fin_fused_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctxT, N, nslab);
   PRG_LAUNCH_CHECK();
@@ -682,12 +769,29 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
 
 }  // namespace
 
-bool full_attention_mfma_supported(int N) { return N == 64 || N == 128 || N == 256; }
+bool full_attention_mfma_supported(int N) { return N == 64 || N == 128 || N == 256 || N == 512 || N == 1024; }
+
+template <int NT, int QS>
+static int launch_attn_big(const bf16_t* qkv, bf16_t* out, int B, hipStream_t s) {
+  constexpr int N = 32 * NT;
+  constexpr size_t lds = ((size_t)N * 40 + (size_t)32 * (N + 8)) * 2;
+  static bool attr = false;
+  if (!attr) {
+    int rc = set_lds(&full_attn_mfma_big_kernel<NT, QS>, lds);
+    if (rc) return rc;
+    attr = true;
+  }
+  full_attn_mfma_big_kernel<NT, QS><<<dim3(4, B, QS), 256, lds, s>>>(qkv, out);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
 
 // qkv (B, N, 384) bf16 -> out (B, N, 128) bf16
 int launch_full_attention_mfma(const bf16_t* qkv, bf16_t* out, int B, int N, hipStream_t s) {
   PRG_CHECK(full_attention_mfma_supported(N) && qkv && out, "full attention (MFMA): unsupported token count");
   const dim3 grid(4, B);
+  if (N == 1024) return B >= 32 ? launch_attn_big<32, 2>(qkv, out, B, s) : launch_attn_big<32, 4>(qkv, out, B, s);
+  if (N == 512) return launch_attn_big<16, 2>(qkv, out, B, s);
   if (N == 64) full_attn_mfma_kernel<2><<<grid, 256, 0, s>>>(qkv, out);
   else if (N == 128) full_attn_mfma_kernel<4><<<grid, 256, 0, s>>>(qkv, out);
   else full_attn_mfma_kernel<8><<<grid, 256, 0, s>>>(qkv, out);
@@ -718,11 +822,12 @@ size_t linattn_fused_ws_floats(int B, int N) {
 
 // x, out: (B, N, C) bf16.  wqkv: [384][C] with the PreNorm gain folded in (q | k | v rows, head-major); wout: [C][128].
 int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias,
-                                  const float* out_g, bf16_t* out, float* ws, int B, int N, int C, hipStream_t s) {
+                                  const float* out_g, bf16_t* out, float* ws, int B, int N, int C, const float* kshift,
+                                  hipStream_t s) {
   PRG_CHECK(linattn_fused_supported(C), "fused linear attention: unsupported width");
   PRG_CHECK(la_slabs(N) <= 4096, "fused linear attention: too many slabs");
-  if (C == 64) return launch_c<64>(x, wqkv, wout, bias, out_g, out, ws, B, N, s);
-  return launch_c<128>(x, wqkv, wout, bias, out_g, out, ws, B, N, s);
+  if (C == 64) return launch_c<64>(x, wqkv, wout, bias, out_g, out, ws, B, N, kshift, s);
+  return launch_c<128>(x, wqkv, wout, bias, out_g, out, ws, B, N, kshift, s);
 }
 
 }  // namespace prg

@@ -52,8 +52,10 @@ int launch_linear_attention(const T* qkv, T* out, float* ws, int B, int N, hipSt
 // the PreNorm gain folded in, wout [C][128] bf16.  ws: at least linattn_fused_ws_floats(B, N) floats.
 bool linattn_fused_supported(int C);
 size_t linattn_fused_ws_floats(int B, int N);
+// kshift: [128] static per-column softmax shift (a bound on |k|; see unet.hip) or null = measure the column maxima.
 int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias,
-                                  const float* out_g, bf16_t* out, float* ws, int B, int N, int C, hipStream_t s);
+                                  const float* out_g, bf16_t* out, float* ws, int B, int N, int C, const float* kshift,
+                                  hipStream_t s);
 
 // ResnetBlock tail with the 1x1 res_conv folded in (attn_fused.hip), bf16 path.  wres: [Cout][C0+C1] bf16.
 bool resblock_tail_fused_supported(int C0, int C1, int Cout);

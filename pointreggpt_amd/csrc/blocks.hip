@@ -479,7 +479,8 @@ __global__ __launch_bounds__(256) void la_ctx_kernel(const T* __restrict__ qkv, 
   float km[VEC];
 #pragma unroll
   for (int u = 0; u < VEC; ++u) km[u] = kmax[(size_t)b * 128 + h * 32 + sv * VEC + u];
-  float acc[4] = {0, 0, 0, 0}, ssum = 0.0f;
+  using A = typename Acc<T>::type;            // parity mode: float64 sums over the slab's pixels
+  A acc[4] = {0, 0, 0, 0}, ssum = 0;
   const T* base = qkv + (size_t)b * N * 384 + h * 32 + sv * VEC;
   for (int t0 = p0; t0 < p1; t0 += P) {
     const int n = t0 + spx;
@@ -499,17 +500,17 @@ __global__ __launch_bounds__(256) void la_ctx_kernel(const T* __restrict__ qkv, 
     for (int pp = 0; pp < P; ++pp) {
       const float a = ek[pp][d];
       const float4 w = *reinterpret_cast<const float4*>(&vv[pp][e0]);
-      ssum += a;
-      acc[0] = fmaf(a, w.x, acc[0]);
-      acc[1] = fmaf(a, w.y, acc[1]);
-      acc[2] = fmaf(a, w.z, acc[2]);
-      acc[3] = fmaf(a, w.w, acc[3]);
+      ssum += (A)a;
+      acc[0] += (A)a * (A)w.x;
+      acc[1] += (A)a * (A)w.y;
+      acc[2] += (A)a * (A)w.z;
+      acc[3] += (A)a * (A)w.w;
     }
     __syncthreads();
   }
   float* o = ctxp + (((size_t)b * 4 + h) * ns + sp) * 1024 + d * 32 + e0;
-  o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
-  if ((tid & 7) == 0) sump[(((size_t)b * 4 + h) * ns + sp) * 32 + d] = ssum;
+  o[0] = (float)acc[0]; o[1] = (float)acc[1]; o[2] = (float)acc[2]; o[3] = (float)acc[3];
+  if ((tid & 7) == 0) sump[(((size_t)b * 4 + h) * ns + sp) * 32 + d] = (float)ssum;
 }
 
 // grid (4, B), 256 threads x 4 entries: ctx = (sum_split ctxp) / (sum_split sump[d]) / N
@@ -521,12 +522,12 @@ __global__ __launch_bounds__(256) void la_fin_kernel(const float* __restrict__ c
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + i * 256, d = idx >> 5;
-    float s = 0.0f, a = 0.0f;
+    double s = 0.0, a = 0.0;
     for (int k = 0; k < ns; ++k) {
-      a += ctxp[(bh * ns + k) * 1024 + idx];
-      s += sump[(bh * ns + k) * 32 + d];
+      a += (double)ctxp[(bh * ns + k) * 1024 + idx];
+      s += (double)sump[(bh * ns + k) * 32 + d];
     }
-    ctx[bh * 1024 + idx] = a / s * invN;
+    ctx[bh * 1024 + idx] = (float)a / (float)s * invN;
   }
 }
 
@@ -640,9 +641,11 @@ __global__ __launch_bounds__(256) void full_attn_kernel(const T* __restrict__ qk
       for (int u = 0; u < VEC; ++u) q[k * VEC + u] = Elem<T>::load(t.e[u]) * 0.17677669529663687f;
     }
   }
-  float m = -INFINITY, l = 0.0f, acc[32];
+  using A = typename Acc<T>::type;            // parity mode: float64 sums over the keys
+  float m = -INFINITY;
+  A l = 0, acc[32];
 #pragma unroll
-  for (int e = 0; e < 32; ++e) acc[e] = 0.0f;
+  for (int e = 0; e < 32; ++e) acc[e] = 0;
   for (int pass = 0; pass < 2; ++pass) {
     for (int j0 = 0; j0 < N; j0 += KC) {
       const int cnt = min(KC, N - j0);
@@ -666,21 +669,21 @@ __global__ __launch_bounds__(256) void full_attn_kernel(const T* __restrict__ qk
           m = fmaxf(m, sdot);
         } else {
           const float pj = expf(sdot - m);
-          l += pj;
+          l += (A)pj;
 #pragma unroll
-          for (int e = 0; e < 32; ++e) acc[e] = fmaf(pj, Vs[j][e], acc[e]);
+          for (int e = 0; e < 32; ++e) acc[e] += (A)pj * (A)Vs[j][e];
         }
       }
     }
   }
   if (i < N) {
-    const float inv = 1.0f / l;
+    const float lf = (float)l;
     T* op = out + ((size_t)b * N + i) * 128 + h * 32;
 #pragma unroll
     for (int k = 0; k < 32 / VEC; ++k) {
       Vec16<T> w;
 #pragma unroll
-      for (int u = 0; u < VEC; ++u) w.e[u] = Elem<T>::store(acc[k * VEC + u] * inv);
+      for (int u = 0; u < VEC; ++u) w.e[u] = Elem<T>::store((float)acc[k * VEC + u] / lf);
       vec_store(op + k * VEC, w);
     }
   }
@@ -713,8 +716,9 @@ __global__ void linear_kernel(const float* __restrict__ x, int ldx, int xoff, co
   const int r = (int)(idx / O), o = (int)(idx - (int64_t)r * O);
   const float* xr = x + (size_t)r * ldx + xoff;
   const float* wr = W + (size_t)o * ldw + woff;
-  float acc = 0.0f;
-  for (int i = 0; i < I; ++i) acc = fmaf(act_apply(xr[i], act_in), wr[i], acc);
+  double accd = 0.0;                         // tiny conditioning MLPs: float64 sum, one rounding
+  for (int i = 0; i < I; ++i) accd += (double)act_apply(xr[i], act_in) * (double)wr[i];
+  float acc = (float)accd;
   if (bias) acc += bias[o];
   y[(size_t)r * ldy + o] = act_apply(acc, act_out);
 }

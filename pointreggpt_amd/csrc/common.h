@@ -138,7 +138,7 @@ __device__ inline double wave_sum_d(double v) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-constexpr int kGnMaxSplit = 256;   // max GroupNorm (sum, sumsq) partial slabs per image
+constexpr int kGnMaxSplit = 1024;  // max GroupNorm (sum, sumsq) partial slabs per image (256x256: 8x32 tiles x 4 wave rows)
 
 // ---------------------------------------------------------------------------------------------
 // activations

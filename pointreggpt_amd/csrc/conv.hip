@@ -19,9 +19,17 @@
 // Shared epilogue: accumulators are transposed through LDS so every lane stores 16 contiguous bytes (full 128-byte
 // lines per 8 lanes) instead of 2-byte pieces, bias / residual are added on the way, and the per-(image, tile,
 // group) GroupNorm partial sums of the output are emitted in a fixed order (deterministic) for the consumer.
+#include <type_traits>
+
 #include "conv.h"
 
 namespace prg {
+
+// GroupNorm partial sums of a conv output: float in the bf16 path; the parity mode (T = float) sums in float64 — the
+// variance is E[x^2] - mean^2, and fp32 sums of squares alone put ~3e-6 of error into every normalised activation
+// (the reference's group_norm computes its moments to ~1e-7).
+template <typename T>
+using StatAcc = std::conditional_t<std::is_same<T, float>::value, double, float>;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -61,6 +69,56 @@ struct Mma<float> {
   }
 };
 
+
+// Parity mode (T = float): the reference's oneDNN kernels sum a convolution's K = 9 Cin products in short vector blocks;
+// one K-long fp32 chain per output sits 2-3x further from exact arithmetic than that (measured per tap against a float64
+// evaluation of the reference, tests/golden/G13).  So the exact-f32 MFMA chain is cut at every main-loop iteration (16 or 32
+// terms) and the partials are summed in float64: the result is within 1 ulp of the correctly rounded fp32 value.
+template <int TM>
+__device__ inline void clear_acc(f32x16 (&acc)[TM][2]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+}
+template <typename T, int TM = 1>
+struct Wide {                      // bf16 path: nothing
+  static constexpr bool on = false;
+  __device__ inline void add(const f32x16 (&)[TM][2]) {}
+  __device__ inline void finish(f32x16 (&)[TM][2]) {}
+};
+template <int TM>
+struct Wide<float, TM> {
+  static constexpr bool on = true;
+  double tot[TM][2][16];
+  __device__ inline Wide() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[i][j][e] = 0.0;
+  }
+  __device__ inline void add(const f32x16 (&acc)[TM][2]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[i][j][e] += (double)acc[i][j][e];
+  }
+  __device__ inline void finish(f32x16 (&acc)[TM][2]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (float)tot[i][j][e];
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // shared epilogue
 // ---------------------------------------------------------------------------------------------
@@ -69,7 +127,8 @@ struct Mma<float> {
 // (sum, sumsq) over the 8 consecutive channels it stored (cols (lane & 7) * 8 .. + 7 of the wave tile).
 template <typename T, int TM, typename RowMap>
 __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][2], float* stage, int lane,
-                                      int col0, RowMap row_to_m, float& gs, float& gq) {
+                                      int col0, RowMap row_to_m, StatAcc<T>& gs, StatAcc<T>& gq) {
+  using SA = StatAcc<T>;
   constexpr int P = 68;  // stage pitch (floats): 64 + 4 keeps rows 16-byte aligned and off one bank
   constexpr int VEC = Elem<T>::kVec;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -79,8 +138,8 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
   float bias[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) bias[u] = (L.bias && col_ok) ? L.bias[col + u] : 0.0f;
-  gs = 0.0f;
-  gq = 0.0f;
+  gs = 0;
+  gq = 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     __syncthreads();  // previous pass fully read (and, first time, the main loop's LDS reads are done)
@@ -101,7 +160,10 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] += bias[u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { gs += v[u]; gq = fmaf(v[u], v[u], gq); }
+        for (int u = 0; u < 8; ++u) {
+          if constexpr (std::is_same<SA, double>::value) { gs += (double)v[u]; gq += (double)v[u] * (double)v[u]; }
+          else { gs += v[u]; gq = fmaf(v[u], v[u], gq); }
+        }
         if (L.residual) {
 #pragma unroll
           for (int h = 0; h < 8 / VEC; ++h) {
@@ -124,8 +186,8 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
 
 // Block-level, fixed-order reduction of the lanes' (gs, gq) into per-group partials and one global store per group.
 // red = LDS scratch of 4 waves x 8 column chunks x 2 floats.  Wave layout WAVES_M x WAVES_N, wave tile 64 columns.
-template <int WAVES_M, int WAVES_N>
-__device__ inline void epilogue_stats(float* red, float gs, float gq, int wave, int lane, int tn_col0, int Cout,
+template <int WAVES_M, int WAVES_N, typename SA>
+__device__ inline void epilogue_stats(SA* red, SA gs, SA gq, int wave, int lane, int tn_col0, int Cout,
                                       int groups, float* dst /* partials + (image*nsplit + slab) * groups * 2 */) {
   // lanes with equal (lane & 7) stored the same 8-channel column chunk: fold the 8 row-lanes together
 #pragma unroll
@@ -145,7 +207,7 @@ __device__ inline void epilogue_stats(float* red, float gs, float gq, int wave, 
   if (t < ngrp_blk) {
     const int g = tn_col0 / cpg + t;
     if (g < groups) {
-      float ss = 0.0f, qq = 0.0f;
+      SA ss = 0, qq = 0;
       for (int ch = 0; ch < cpg / 8; ++ch) {
         const int cblk = t * (cpg / 8) + ch;     // 8-channel chunk index within the workgroup's columns
         const int wn = cblk / 8, c8 = cblk % 8;
@@ -154,8 +216,8 @@ __device__ inline void epilogue_stats(float* red, float gs, float gq, int wave, 
           qq += red[((wm * WAVES_N + wn) * 8 + c8) * 2 + 1];
         }
       }
-      dst[g * 2 + 0] = ss;
-      dst[g * 2 + 1] = qq;
+      dst[g * 2 + 0] = (float)ss;
+      dst[g * 2 + 1] = (float)qq;
     }
   }
 }
@@ -171,7 +233,7 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 // 3x3 halo kernel
 // ---------------------------------------------------------------------------------------------
 template <typename T, int TH, int TW, int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvLaunch<T> L, const int tiles_x,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv3x3_halo_kernel(const ConvLaunch<T> L, const int tiles_x,
                                                            const int tiles_y, const int tiles_n, const int fuse_stats) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int CH = 8 * VEC;                 // channels per 128-byte pixel row (bf16 64, f32 32)
@@ -257,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvLaunch<T
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+  Wide<T, TM> wacc;
   const int niter = nchunks * 9;
   gload_halo(0);
   gload_b(0, 0);
@@ -300,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvLaunch<T
 
     const int kh = tap / 3, kw = tap - kh * 3;
     const int toff = kh * HP + kw;
+    if constexpr (Wide<T>::on) clear_acc<TM>(acc);   // parity mode: this (tap, chunk)'s 32-term partial, then summed in float64
 #pragma unroll
     for (int call = 0; call < CALLS; ++call) {
       const int unit = Mma<T>::unit_of(call, hi);
@@ -319,11 +383,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvLaunch<T
 #pragma unroll
         for (int j = 0; j < 2; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j], hi);
     }
+    wacc.add(acc);
     tap = ntap;
     chunk = nchunk;
   }
+  wacc.finish(acc);
 
-  float gs, gq;
+  StatAcc<T> gs, gq;
   auto row_to_m = [&](int r) -> int64_t {
     const int p = wm * WM + r;
     return ((int64_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
@@ -332,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvLaunch<T
   if (fuse_stats) {
     const int nsplit = tiles_x * tiles_y;
     float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
-    epilogue_stats<WAVES_M, WAVES_N>(stage + 4 * 32 * 68, gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
+    epilogue_stats<WAVES_M, WAVES_N>(reinterpret_cast<StatAcc<T>*>(stage + 4 * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout,
+                                     L.gn_groups, dst);
   }
 }
 
@@ -340,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvLaunch<T
 // generic gather kernel (1x1, 4x4 s2, ragged shapes)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvLaunch<T> L, const int M, const int tiles_m,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel(const ConvLaunch<T> L, const int M, const int tiles_m,
                                                          const int tiles_n, const int fuse_stats, const int wide) {
   constexpr int BK = ConvTile<T>::BK;
   constexpr int VEC = Elem<T>::kVec;
@@ -418,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvLaunch<T> 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+  Wide<T, TM> wacc;
   int tap = 0, kc = 0;
   gload(0, 0);
   for (int it = 0; it < niter; ++it) {
@@ -430,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvLaunch<T> 
     __syncthreads();
     if (++kc == d.kchunks) { kc = 0; ++tap; }
     if (it + 1 < niter) gload(tap, kc);
+    if constexpr (Wide<T>::on) clear_acc<TM>(acc);   // parity mode: 16-term partials summed in float64
 #pragma unroll
     for (int call = 0; call < CALLS; ++call) {
       const int unit = Mma<T>::unit_of(call, hi);
@@ -443,10 +512,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvLaunch<T> 
 #pragma unroll
         for (int j = 0; j < 2; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j], hi);
     }
+    wacc.add(acc);
   }
+  wacc.finish(acc);
 
   if (wide) {
-    float gs, gq;
+    StatAcc<T> gs, gq;
     auto row_to_m = [&](int r) -> int64_t {
       const int m = tm * BM + wm * WM + r;
       return m < M ? (int64_t)m : (int64_t)-1;
@@ -456,7 +527,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvLaunch<T> 
       const int nsplit = HWo / BM;
       const int bimg = (tm * BM) / HWo, slab = tm - bimg * nsplit;
       float* dst = L.gn_partials + ((size_t)bimg * nsplit + slab) * L.gn_groups * 2;
-      epilogue_stats<WAVES_M, WAVES_N>(stage + 4 * 32 * 68, gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
+      epilogue_stats<WAVES_M, WAVES_N>(reinterpret_cast<StatAcc<T>*>(stage + 4 * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout,
+                                       L.gn_groups, dst);
     }
   } else {
     // narrow fallback (Cout not a multiple of 8): C/D layout col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -484,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvLaunch<T> 
 // ---------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------
-constexpr size_t kEpilogueLds = (size_t)4 * 32 * 68 * sizeof(float) + 4 * 8 * 2 * sizeof(float);  // 35,072 B
+constexpr size_t kEpilogueLds = (size_t)4 * 32 * 68 * sizeof(float) + 4 * 8 * 2 * sizeof(double);  // 35,328 B
 
 template <typename T>
 struct HaloPick {

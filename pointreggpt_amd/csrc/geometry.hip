@@ -191,6 +191,70 @@ __global__ void depth_augment_kernel(const float* __restrict__ depth, float* __r
   }
 }
 
+// ---- occlusion filter of the successive multi-view path (sd:446-463) -----------------------------
+// min over the VALID pixels of the 3x3 window (the pool pads with -inf of -x: out-of-frame neighbours never win);
+// a pixel more than `thr` behind that minimum is replaced by it.  (depth - min) < thr keeps the pixel; invalid pixels
+// hold 0 and compare as 0 - min (or 0 - inf): always kept, exactly like the reference's expression.
+__global__ void occlusion_filter_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                        float* __restrict__ out, int H, int W, float thr) {
+  const int b = blockIdx.y, HW = H * W;
+  const float* d = depth + (size_t)b * HW;
+  const uint8_t* m = mask + (size_t)b * HW;
+  const float inf = __uint_as_float(0x7f800000u);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const int r = i / W, col = i - r * W;
+    float mn = inf;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int rr = r + dy;
+      if (rr < 0 || rr >= H) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int cc = col + dx;
+        if (cc < 0 || cc >= W) continue;
+        if (m[rr * W + cc]) mn = fminf(mn, d[rr * W + cc]);
+      }
+    }
+    const float c0 = d[i];
+    out[(size_t)b * HW + i] = (c0 - mn) < thr ? c0 : mn;
+  }
+}
+
+// ---- overlap ratio of generate_gt.py:68-102 ---------------------------------------------------------
+// For every point of cloud A of a pair: is some point of cloud B strictly within `radius` (squared distance in
+// float64, < r^2 like the KD-tree radius search)?  Clouds are a few thousand points after the 0.025 voxel grid, so
+// the exact all-pairs test with B streamed through LDS is microseconds per pair on one CU and needs no grid or tree;
+// one workgroup per (pair, direction, 256-query slab), a count per (pair, direction) by atomicAdd of integers (exact).
+__global__ __launch_bounds__(256) void overlap_count_kernel(const double* __restrict__ pts, const int64_t* __restrict__ offs,
+                                                            double r2, int32_t* __restrict__ counts) {
+  __shared__ double tile[256 * 3];
+  const int pair = blockIdx.y, dir = blockIdx.z;
+  const int64_t a0 = offs[2 * pair + dir], a1 = offs[2 * pair + dir + 1];
+  const int64_t b0 = dir == 0 ? offs[2 * pair + 1] : offs[2 * pair], b1 = dir == 0 ? offs[2 * pair + 2] : offs[2 * pair + 1];
+  const int64_t q = a0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a0 + (int64_t)blockIdx.x * 256 >= a1) return;            // whole slab beyond this cloud (uniform exit)
+  const bool live = q < a1;
+  double qx = 0, qy = 0, qz = 0;
+  if (live) { qx = pts[3 * q]; qy = pts[3 * q + 1]; qz = pts[3 * q + 2]; }
+  bool found = false;
+  for (int64_t t0 = b0; t0 < b1; t0 += 256) {
+    const int64_t n = min((int64_t)256, b1 - t0);
+    __syncthreads();
+    if (threadIdx.x < n) {
+      tile[threadIdx.x] = pts[3 * (t0 + threadIdx.x)];
+      tile[256 + threadIdx.x] = pts[3 * (t0 + threadIdx.x) + 1];
+      tile[512 + threadIdx.x] = pts[3 * (t0 + threadIdx.x) + 2];
+    }
+    __syncthreads();
+    if (!found) {
+      for (int j = 0; j < (int)n; ++j) {
+        const double dx = tile[j] - qx, dy = tile[256 + j] - qy, dz = tile[512 + j] - qz;
+        if (dx * dx + dy * dy + dz * dz < r2) found = true;
+      }
+    }
+  }
+  const unsigned long long hits = __ballot(live && found);
+  if ((threadIdx.x & 63) == 0 && hits) atomicAdd(counts + 2 * pair + dir, (int32_t)__popcll(hits));
+}
+
 // ---- mask application + condition assembly (sd:2564-2570, sd:2579-2581) --------------------------
 __global__ void apply_mask_kernel(const float* __restrict__ prob, const float* __restrict__ depth,
                                   const uint8_t* __restrict__ hit, float thr, float* __restrict__ depth_out,
@@ -309,6 +373,26 @@ int prg_apply_mask(const float* prob, const float* depth, const uint8_t* hit, fl
   PRG_CHECK(B > 0 && H > 0 && W > 0, "prg_apply_mask: bad shape");
   apply_mask_kernel<<<grid_for(H * W, B), 256, 0, (hipStream_t)stream>>>(prob, depth, hit, thr, depth_out, hit_out,
                                                                         img_cond, H * W);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+int prg_occlusion_filter(const float* depth, const uint8_t* mask, float* out, int B, int H, int W, float threshold,
+                         void* stream) {
+  PRG_CHECK(depth && mask && out && depth != out, "prg_occlusion_filter: null or aliased pointer");
+  PRG_CHECK(B > 0 && H > 0 && W > 0, "prg_occlusion_filter: bad shape");
+  occlusion_filter_kernel<<<grid_for(H * W, B), 256, 0, (hipStream_t)stream>>>(depth, mask, out, H, W, threshold);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+int prg_overlap_counts(const double* pts, const int64_t* offsets, int n_pairs, int64_t max_cloud, double radius,
+                       int32_t* counts, void* stream) {
+  PRG_CHECK(pts && offsets && counts, "prg_overlap_counts: null pointer");
+  PRG_CHECK(n_pairs > 0 && n_pairs <= 65535 && max_cloud > 0 && radius > 0, "prg_overlap_counts: bad arguments");
+  PRG_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * (size_t)n_pairs, (hipStream_t)stream));
+  const dim3 grid((unsigned)((max_cloud + 255) / 256), (unsigned)n_pairs, 2);
+  overlap_count_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(pts, offsets, radius * radius, counts);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }

@@ -75,6 +75,13 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(SamplerStepArgs a) {
       float x0 = known ? cds[e] : x0p;
       if (st.clip_pred & 2) x0 = clamp1(x0);   // p_mean_variance clip_denoised (sd:1250); ddim_sample has no such clamp
       float v = st.c_x0 * x0;
+      if (st.clip_pred & 4) {
+        // refine row (has_refine_step, sd:1307-1314 / 1374-1388): evaluation without the replacement; only the KNOWN
+        // pixels take the clamped network output (posterior mean at t = 0 is exactly x0: coef1 = 1, coef2 = 0)
+        r[e] = known ? clamp1(us[e]) : xs[e];
+        f[e] = (r[e] + 1.0f) * 0.5f;
+        continue;
+      }
       if (st.c_x != 0.0f) v = v + st.c_x * xs[e];
       if (st.c_eps != 0.0f) {
         const float eps = (st.sqrt_recip * xs[e] - x0p) / st.sqrt_recipm1;

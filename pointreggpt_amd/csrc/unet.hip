@@ -54,6 +54,10 @@ struct ProfileSink {  // per-launch conv timing (bench roofline)
   size_t used = 0;
   double conv_ms = 0, conv_flops = 0, conv_bytes = 0;   // conv_bytes: algorithmic input + output + weight bytes
   int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> step_pool;   // the per-transition update kernel (HBM-bound)
+  size_t step_used = 0;
+  double step_ms = 0;
+  int64_t step_launches = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -81,6 +85,7 @@ struct AttnP {
   ConvP qkv, out;
   int64_t out_g = -1, norm_g = -1;
   int64_t fw_qkv = -1, fw_out = -1;   // bf16 element offsets into the fused-attention weight arena (-1: unfused path)
+  int64_t kshift = -1;                // float offset of the 128 static softmax shifts in d_kshift (-1: measure the maxima)
 };
 struct LevelP {
   ResP r0, r1;
@@ -225,6 +230,7 @@ struct prg_unet {
   float* d_stem = nullptr;      // stem weights [49*Cin][dim]
   bf16_t* d_stem_frag = nullptr; // stem weights as MFMA fragments (bf16 path, Cin 1 -> 64)
   bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
+  float* d_kshift = nullptr;    // fused linear attention: static softmax shifts of the k columns
   Arena arena;
   uint64_t arena_gen = 0;       // bumped whenever the workspace is reallocated: captured graphs bake its pointers in
   int resB = 0, resS = 0;
@@ -389,7 +395,7 @@ struct UnetImpl : prg_unet {
         int rc = PRG_OK;
         if (!arena.dry)
           rc = launch_linear_attention_fused(x, d_attn + a.fw_qkv, d_attn + a.fw_out, F(a.out.b_off), F(a.out_g), out, ws, B, N,
-                                             a.C, s);
+                                             a.C, a.kshift >= 0 ? d_kshift + a.kshift : nullptr, s);
         arena.reset(m);
         return rc;
       }
@@ -661,6 +667,9 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
   if (std::is_same<T, bf16_t>::value && fused_attention_enabled()) {
     // fused linear attention (attn_fused.hip): to_qkv with the PreNorm gain folded in, to_out as is, both [out][in] bf16
     std::vector<bf16_t> aw;
+    std::vector<float> ks;
+    // PRG_LA_KSHIFT=0 forces the measured column maxima (the la_kmax pass) for every block
+    static const int kshift_on = [] { const char* e = std::getenv("PRG_LA_KSHIFT"); return e ? std::atoi(e) : 1; }();
     auto add = [&](AttnP& a) {
       if (!a.linear || !linattn_fused_supported(a.C)) return;
       aw.resize((aw.size() + 63) / 64 * 64);
@@ -668,6 +677,24 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       for (int o = 0; o < 3 * kHidden; ++o)
         for (int c = 0; c < a.C; ++c)
           aw.push_back(f32_to_bf16(weights[a.qkv.w_flat + (size_t)o * a.C + c] * weights[a.norm_g + c]));
+      // Softmax over pixels of k[n][d] = w_d . LN(x_n): a LayerNorm output has norm <= sqrt(C), so |k| <= ||w_d|| sqrt(C)
+      // (Cauchy-Schwarz; w_d = the bf16 weights the kernel multiplies with, 2 % slack for the bf16 rounding of LN(x)).
+      // exp(k - bound) >= exp(-2 bound): with bound <= 40 nothing underflows and the column maxima need not be measured.
+      float shifts[kHidden];
+      bool ok = kshift_on != 0;
+      for (int d = 0; d < kHidden; ++d) {
+        double n2 = 0;
+        for (int c = 0; c < a.C; ++c) {
+          const double w = bf16_to_f32(aw[(size_t)a.fw_qkv + (size_t)(kHidden + d) * a.C + c]);
+          n2 += w * w;
+        }
+        shifts[d] = (float)(1.02 * std::sqrt(n2 * a.C));
+        ok = ok && shifts[d] <= 40.0f;
+      }
+      if (ok) {
+        a.kshift = (int64_t)ks.size();
+        ks.insert(ks.end(), shifts, shifts + kHidden);
+      }
       a.fw_out = (int64_t)aw.size();
       for (int c = 0; c < a.C; ++c)
         for (int j = 0; j < kHidden; ++j) aw.push_back(f32_to_bf16(weights[a.out.w_flat + (size_t)c * kHidden + j]));
@@ -686,6 +713,10 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
     if (!aw.empty()) {
       if (hipMalloc(&u->d_attn, aw.size() * sizeof(bf16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(attention weights)");
       PRG_HIP(hipMemcpy(u->d_attn, aw.data(), aw.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    }
+    if (!ks.empty()) {
+      if (hipMalloc(&u->d_kshift, ks.size() * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(softmax shifts)");
+      PRG_HIP(hipMemcpy(u->d_kshift, ks.data(), ks.size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
   *out = u.release();
@@ -766,6 +797,21 @@ static int sampler_one_step(prg_sampler* h, const float* cond, const float* nois
   a.x = h->d_x; a.u = h->d_u; a.cond = cond; a.noise = noise; a.steps = h->d_steps; a.step_idx = h->d_step;
   a.seeds = h->d_seeds; a.final_out = out; a.B = h->B; a.HW = h->S * h->S; a.n_steps = h->n_steps;
   a.ticket = h->d_step + 1;
+  if (h->prof.on) {
+    ProfileSink& p = h->prof;
+    if (p.step_used == p.step_pool.size()) {
+      hipEvent_t e0, e1;
+      PRG_HIP(hipEventCreate(&e0));
+      PRG_HIP(hipEventCreate(&e1));
+      p.step_pool.push_back({e0, e1});
+    }
+    auto& ev = p.step_pool[p.step_used++];
+    PRG_HIP(hipEventRecord(ev.first, s));
+    rc = launch_sampler_step(a, s);
+    PRG_HIP(hipEventRecord(ev.second, s));
+    p.step_launches += 1;
+    return rc;
+  }
   return launch_sampler_step(a, s);   // its last workgroup advances the step counter
 }
 
@@ -818,6 +864,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_packed) hipFree(h->d_packed);
   if (h->d_stem) hipFree(h->d_stem);
   if (h->d_attn) hipFree(h->d_attn);
+  if (h->d_kshift) hipFree(h->d_kshift);
   if (h->d_stem_frag) hipFree(h->d_stem_frag);
   if (h->arena.base) hipFree(h->arena.base);
   delete h;
@@ -936,6 +983,7 @@ int prg_sampler_destroy(prg_sampler* h) {
   hipDeviceSynchronize();
   sampler_free(h);
   for (auto& ev : h->prof.pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  for (auto& ev : h->prof.step_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   void* ptrs[] = {h->d_steps, h->d_tpart, h->d_ppart, h->d_scratch, h->d_x, h->d_u, h->d_step, h->d_seeds};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -958,6 +1006,13 @@ int prg_sampler_set_profile(prg_sampler* h, int enable) {
 int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes) {
   PRG_CHECK(h && conv_bytes, "prg_sampler_get_profile_bytes: null argument");
   *conv_bytes = h->prof.conv_bytes;
+  return PRG_OK;
+}
+
+int prg_sampler_get_profile_step(prg_sampler* h, double* step_ms, int64_t* step_launches) {
+  PRG_CHECK(h && step_ms && step_launches, "prg_sampler_get_profile_step: null argument");
+  *step_ms = h->prof.step_ms;
+  *step_launches = h->prof.step_launches;
   return PRG_OK;
 }
 
@@ -1012,6 +1067,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
   const bool profiling = h->prof.on;
   u->prof = profiling ? &h->prof : nullptr;
   h->prof.conv_ms = 0; h->prof.conv_flops = 0; h->prof.conv_bytes = 0; h->prof.launches = 0; h->prof.used = 0;
+  h->prof.step_ms = 0; h->prof.step_launches = 0; h->prof.step_used = 0;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   if (profiling) {
     PRG_HIP(hipEventCreate(&t0));
@@ -1045,6 +1101,12 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
           h->prof.conv_ms += ms;
         }
         h->prof.used = 0;
+        for (size_t i = 0; i < h->prof.step_used; ++i) {
+          float ms = 0;
+          PRG_HIP(hipEventElapsedTime(&ms, h->prof.step_pool[i].first, h->prof.step_pool[i].second));
+          h->prof.step_ms += ms;
+        }
+        h->prof.step_used = 0;
       }
     }
   }

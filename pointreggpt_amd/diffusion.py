@@ -103,8 +103,14 @@ class GaussianDiffusion:
                 rows.append(row)
         return [{k: (float(v) if k not in ("t", "clip_pred") else int(v)) for k, v in r.items()} for r in rows]
 
-    def _steps_c(self):
+    def _steps_c(self, refine: bool = False):
         rows = self.step_table()
+        if refine:
+            # has_refine_step (sd:1307-1314 / sd:1374-1388): one more evaluation at t = 0 WITHOUT the DDNM replacement;
+            # the known pixels take its clamped output, the in-painted ones keep their value
+            rows = rows + [dict(t=0, clip_pred=4, c_x0=0.0, c_x=0.0, c_eps=0.0, sigma=0.0,
+                                sqrt_recip=float(self.sqrt_recip_alphas_cumprod[0]),
+                                sqrt_recipm1=float(self.sqrt_recipm1_alphas_cumprod[0]))]
         arr = (_lib.StepC * len(rows))()
         for i, r in enumerate(rows):
             arr[i] = _lib.StepC(r["t"], r["clip_pred"], r["c_x0"], r["c_x"], r["c_eps"], r["sigma"], r["sqrt_recip"],
@@ -118,11 +124,11 @@ class GaussianDiffusion:
         rows = self.step_table()
         return 1 + max([k + 1 for k, r in enumerate(rows) if r["sigma"] != 0.0], default=0)
 
-    def _sampler(self, batch: int):
-        key = (batch, self.image_size)
+    def _sampler(self, batch: int, refine: bool = False):
+        key = (batch, self.image_size, bool(refine))
         if key not in self._samplers:
             lib = _lib.load()
-            arr, n = self._steps_c()
+            arr, n = self._steps_c(refine)
             h = C.c_void_p()
             _lib.check(lib.prg_sampler_create(self.model.handle, arr, n, batch, self.image_size, C.byref(h)),
                        "prg_sampler_create")
@@ -150,8 +156,6 @@ class GaussianDiffusion:
 
         ``noise``: (n_draws,B,1,S,S) stored draws in the reference's order (parity runs); otherwise on-device
         Philox keyed by ``seeds`` (one 64-bit key per scene, default 0..B-1)."""
-        if has_refine_step:
-            raise NotImplementedError("has_refine_step=True is not on the generator's path (generate_dataset.py:62)")
         lib = _lib.load()
         pc = param_cond.to(device="cuda", dtype=torch.float32).contiguous()
         B, S = pc.shape[0], self.image_size
@@ -159,7 +163,7 @@ class GaussianDiffusion:
         if img_cond is not None and self.is_ddnm_sampling:
             cond = img_cond.to(device="cuda", dtype=torch.float32).contiguous()
             assert tuple(cond.shape) == (B, 2, S, S)
-        h = self._sampler(B)
+        h = self._sampler(B, bool(has_refine_step) and cond is not None)
         _lib.check(lib.prg_sampler_set_graph(h, int(use_graph)))
         _lib.check(lib.prg_sampler_set_profile(h, int(profile)))
         nz = None
@@ -178,12 +182,14 @@ class GaussianDiffusion:
         self._keepalive = (pc, cond, nz)   # the run is asynchronous: keep inputs alive until the next call
         return out
 
-    def last_profile(self, batch: int) -> dict:
+    def last_profile(self, batch: int, refine: bool = False) -> dict:
         lib = _lib.load()
-        h = self._sampler(batch)
+        h = self._sampler(batch, refine)
         ms, n, fl, tot = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(lib.prg_sampler_get_profile(h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(tot)))
         by = C.c_double()
         _lib.check(lib.prg_sampler_get_profile_bytes(h, C.byref(by)))
+        sms, sn = C.c_double(), C.c_int64()
+        _lib.check(lib.prg_sampler_get_profile_step(h, C.byref(sms), C.byref(sn)))
         return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value, "conv_bytes": by.value,
-                "total_ms": tot.value}
+                "total_ms": tot.value, "step_ms": sms.value, "step_launches": sn.value}

@@ -99,14 +99,29 @@ class Generator:
     @torch.no_grad()
     def generate(self, start_scene_index, stop_scene_index, num_samples, memory_voxel_size=0.002,
                  save_voxel_size=0.025, has_refine_step=False, depth_correction=None, mask_threshold=0.99,
-                 noise_seed: int = 0, progress: bool = False):
-        if has_refine_step:
-            raise NotImplementedError("has_refine_step=True is not on the generator CLI's path (generate_dataset.py:62)")
+                 noise_seed: int = 0, progress: bool = False, writer_threads: int = 0, stats: Optional[dict] = None):
+        """Same sequence as sd:2363-2694.  File output is asynchronous: every batch's clouds / images / text files are
+        handed to the library's C++ writer pool (crop, voxel grid, PLY / PNG encoding on worker threads) and are
+        produced while the GPU samples the next batch.  A batch's resume marker — the generated cloud of its LAST scene
+        (sd:2371-2381) — is submitted only after everything else of that batch is on disk, so an interrupted run never
+        skips an incomplete batch."""
         S, dev = self.image_size, self.device
         info_train = None
         if self.synthetic_seed is None:
             with open("./dataset/indoor/metadata/train_info.pkl", "rb") as f:
                 info_train = pickle.load(f)
+        pool = PP.WriterPool(writer_threads)
+        marker_prev = None                # deferred submission of the previous batch's resume marker
+        n_pairs = 0
+        marker_index = num_samples // 2   # the cloud file the resume check looks for (0 or 1; never written beyond that)
+
+        def flush_marker():
+            nonlocal marker_prev
+            if marker_prev is not None:
+                pool.wait()               # the previous batch had a whole GPU batch time to finish: no stall in practice
+                marker_prev()
+                marker_prev = None
+
         num_scenes = stop_scene_index - start_scene_index
         first = start_scene_index
         for batch in num_to_groups(num_scenes, self.batch_size):
@@ -118,23 +133,33 @@ class Generator:
                 print("Skip completed scene {:0>6d} - {:0>6d}.".format(idxs[0], idxs[-1]))
                 continue
             K = np.zeros((batch, 3, 3), dtype=np.float32)
-            memory: List[np.ndarray] = []
+            depth0 = np.zeros((batch, 1, S, S), dtype=np.float32)
+            sdirs = []
             for j, idx in enumerate(idxs):
                 sdir = self.samples_folder / "scene-{:0>6d}".format(idx)
                 if sdir.exists():
                     shutil.rmtree(str(sdir), ignore_errors=True)
                 sdir.mkdir(parents=True, exist_ok=True)
-                depth, K[j] = self._scene_inputs(idx, info_train, sdir)
-                np.savetxt(str(sdir / "camera-intrinsics.txt"), K[j])
-                PP.save_image01(depth, str(sdir / "sample-{:0>6d}.image.png".format(0)))
-                d_dev = torch.from_numpy(depth[None, None]).to(dev)
-                frame = G.point_clouds(d_dev, torch.from_numpy(K[j][None]).to(dev), None)[0].astype(np.float32)
-                scene_pc = PP.crop_aabb(frame).astype(np.float32)           # the scene "memory" (sd:2484-2490)
-                memory.append(scene_pc)
-                PP.write_ply(str(sdir / "sample-{:0>6d}.cloud.ply".format(0)), PP.voxel_down_sample(scene_pc, save_voxel_size))
+                sdirs.append(sdir)
+                depth0[j, 0], K[j] = self._scene_inputs(idx, info_train, sdir)
             K_dev = torch.from_numpy(K).to(dev)
+            # the source frames of the whole batch in ONE unprojection (sd:2479-2483 does it per scene)
+            frames = G.point_clouds(torch.from_numpy(depth0).to(dev), K_dev, None)
+            memory: List[np.ndarray] = []
+            marker_cur = None
+            for j in range(batch):
+                scene_pc = PP.crop_aabb(frames[j].astype(np.float32)).astype(np.float32)   # the scene "memory" (sd:2484-2490)
+                memory.append(scene_pc)
+                pool.text(str(sdirs[j] / "camera-intrinsics.txt"), K[j])
+                pool.image01(str(sdirs[j] / "sample-{:0>6d}.image.png".format(0)), depth0[j, 0])
+                job = (lambda path=str(sdirs[j] / "sample-{:0>6d}.cloud.ply".format(0)), pc=scene_pc:
+                       pool.cloud(path, pc, None, crop=False, voxel=save_voxel_size))
+                if j == batch - 1 and marker_index == 0:
+                    marker_cur = job              # this batch's resume marker: written after everything else
+                else:
+                    job()
             param_cond = G.param_vector(K_dev)
-            fragments: List[np.ndarray] = [None] * batch
+            fragments: List[Optional[np.ndarray]] = [None] * batch
             poses0 = None
             for sample_idx in range(num_samples):
                 pose = self._poses(idxs, sample_idx)
@@ -142,41 +167,68 @@ class Generator:
                     poses0 = pose
                 pose_dev = torch.from_numpy(pose).to(dev)
                 rpj, hit = G.project_clouds(memory, pose, K, S, dev, depth_scale=0.1)
-                rpj_host = rpj.cpu().numpy()
                 prob = depth_correction(rpj)
                 rpj_c, hit_c, cond = G.apply_mask(prob, rpj, hit, mask_threshold)
                 seeds = [synthetic.noise_seed(noise_seed, i, sample_idx) for i in idxs]
-                images = self.model.sample(param_cond=param_cond, img_cond=cond, seeds=seeds)
+                images = self.model.sample(param_cond=param_cond, img_cond=cond, seeds=seeds,
+                                           has_refine_step=has_refine_step)
                 prob2 = depth_correction(images)
                 images, _, _ = G.apply_mask(prob2, images, None, mask_threshold, want_cond=False)
-                clouds = G.point_clouds(images, K_dev, pose_dev)            # common frame, float64 (sd:2623-2628)
-                img_host, crt_host = images.cpu().numpy(), rpj_c.cpu().numpy()
+                xyz, valid = G.unproject_f64(images, K_dev, pose_dev)      # common frame, float64 (sd:2623-2628)
+                # one blocking copy per tensor: the host waits here for the GPU while the pool writes the previous batch
+                rpj_host, crt_host, img_host = rpj.cpu().numpy(), rpj_c.cpu().numpy(), images.cpu().numpy()
+                xyz_host, valid_host = xyz.cpu().numpy(), valid.cpu().numpy()
+                flush_marker()
+                last_sample = sample_idx == num_samples - 1
                 for j, idx in enumerate(idxs):
-                    sdir = self.samples_folder / "scene-{:0>6d}".format(idx)
-                    PP.save_image01(rpj_host[j], str(sdir / "reprojected.image.png"))
-                    np.savetxt(str(sdir / "sample-{:0>6d}.pose.txt".format(sample_idx + 1)), np.linalg.inv(pose[j]))
-                    PP.save_image01(crt_host[j], str(sdir / "corrected.image.png"))
-                    PP.save_image01(img_host[j], str(sdir / "sample-{:0>6d}.image.png".format(sample_idx + 1)))
-                    PP.save_depth16(img_host[j], str(sdir / "sample-{:0>6d}.depth.png".format(sample_idx + 1)))
-                    pc = clouds[j]
-                    fragments[j] = pc if sample_idx == 0 else np.concatenate([fragments[j], pc], axis=0)
-                    if sample_idx == num_samples - 1:                       # sd:2640-2658
-                        frag = PP.transform(fragments[j], poses0[j])
-                        frag = PP.voxel_down_sample(PP.crop_aabb(frag), save_voxel_size)
-                        frag = PP.transform(frag, np.linalg.inv(poses0[j]))
-                        PP.write_ply(str(sdir / "sample-{:0>6d}.cloud.ply".format(1)), frag)
-                    if sample_idx < num_samples - 1:                        # memory update (sd:2661-2680)
-                        merged = np.concatenate([memory[j], pc], axis=0)
-                        memory[j] = PP.voxel_down_sample(merged, memory_voxel_size).astype(np.float32)
+                    sdir = sdirs[j]
+                    pool.image01(str(sdir / "reprojected.image.png"), rpj_host[j])
+                    pool.text(str(sdir / "sample-{:0>6d}.pose.txt".format(sample_idx + 1)), np.linalg.inv(pose[j]))
+                    pool.image01(str(sdir / "corrected.image.png"), crt_host[j])
+                    pool.image01(str(sdir / "sample-{:0>6d}.image.png".format(sample_idx + 1)), img_host[j])
+                    pool.depth16(str(sdir / "sample-{:0>6d}.depth.png".format(sample_idx + 1)), img_host[j])
+                    if num_samples == 1:
+                        frag, fvalid = xyz_host[j], valid_host[j]                  # compaction happens in the worker
+                    else:
+                        pc = xyz_host[j][valid_host[j]]
+                        fragments[j] = pc if sample_idx == 0 else np.concatenate([fragments[j], pc], axis=0)
+                        frag, fvalid = fragments[j], None
+                        if not last_sample:                                         # memory update (sd:2661-2680)
+                            merged = np.concatenate([memory[j], pc], axis=0)
+                            memory[j] = PP.native_voxel_down_sample(merged, memory_voxel_size).astype(np.float32)
+                    if last_sample:                                                 # sd:2640-2658
+                        path = str(sdir / "sample-{:0>6d}.cloud.ply".format(1))
+                        job = (lambda path=path, frag=frag, fvalid=fvalid, T=poses0[j].astype(np.float64):
+                               pool.cloud(path, frag, fvalid, pre=T, crop=True, voxel=save_voxel_size, post=np.linalg.inv(T)))
+                        if j == batch - 1 and marker_index == 1:
+                            marker_cur = job
+                        else:
+                            job()
                 if progress:
                     print("batch {:0>6d}-{:0>6d}: sample {}/{}".format(idxs[0], idxs[-1], sample_idx + 1, num_samples))
+            n_pairs += batch
+            flush_marker()                # (only reached with a pending marker when the sample loop did not run)
+            marker_prev = marker_cur
+        flush_marker()
+        jobs = pool.wait()
+        pool.close()
+        if stats is not None:
+            stats.update(pairs=n_pairs, writer_jobs=jobs, writer_threads=pool.threads)
 
 
 def generate_gt(dataset_name: str, start_scene_index: int, stop_scene_index: int, num_samples: int,
-                root: str = ".") -> None:
-    """generate_gt.py:105-175 — per scene, every pair of .cloud.ply -> overlap ratios -> scene gt.log."""
+                root: str = ".", overlap: str = "hip", scenes_per_launch: int = 512) -> None:
+    """generate_gt.py:105-175 — per scene, every pair of .cloud.ply -> overlap ratios -> scene gt.log.
+
+    The reference queries a KD-tree once per point in a Python loop (the wall-clock tail of a 10k-scene dataset); here the
+    clouds of up to `scenes_per_launch` scenes are voxel-down-sampled in C++ and all their pairs go through ONE
+    prg_overlap_counts launch.  `overlap='numpy-spec'` selects the numpy specification in postprocess.py instead — a test
+    hook for boxes without a GPU, never chosen implicitly."""
     from itertools import combinations
+    if overlap not in ("hip", "numpy-spec"):
+        raise ValueError("overlap must be 'hip' or 'numpy-spec'")
     data = Path(root) / dataset_name / "data"
+    todo = []                                   # (scene_name, gt_path, [(s, t, src, tgt), ...])
     for scene_idx in range(start_scene_index, stop_scene_index):
         scene_name = "scene-{:0>6d}".format(scene_idx)
         sdir = data / scene_name
@@ -184,7 +236,7 @@ def generate_gt(dataset_name: str, start_scene_index: int, stop_scene_index: int
         if gt_path.exists():
             print("scene gt log has existed, skip over it")
             continue
-        lines = []
+        cand = []
         for s, t in combinations(range(num_samples), 2):
             ps, pt = sdir / "sample-{:0>6d}.cloud.ply".format(s), sdir / "sample-{:0>6d}.cloud.ply".format(t)
             if not ps.exists() or not pt.exists():
@@ -192,7 +244,27 @@ def generate_gt(dataset_name: str, start_scene_index: int, stop_scene_index: int
             src, tgt = PP.read_ply(str(ps)), PP.read_ply(str(pt))
             if len(src) < 1000 or len(tgt) < 1000:
                 continue
-            o_s, o_t = PP.compute_overlap_ratio(src, tgt)
+            cand.append((s, t, src, tgt))
+        todo.append((scene_name, gt_path, cand))
+        if len(todo) >= scenes_per_launch:
+            _finish_gt(todo, overlap)
+            todo = []
+    if todo:
+        _finish_gt(todo, overlap)
+
+
+def _finish_gt(todo, overlap: str) -> None:
+    flat = [(src, tgt) for _n, _p, cand in todo for (_s, _t, src, tgt) in cand]
+    if overlap == "hip":
+        ratios = PP.overlap_ratios_hip(flat)
+    else:
+        ratios = [PP.compute_overlap_ratio(a, b) for a, b in flat]
+    k = 0
+    for scene_name, gt_path, cand in todo:
+        lines = []
+        for (s, t, _src, _tgt) in cand:
+            o_s, o_t = ratios[k]
+            k += 1
             if np.isnan(o_s) or np.isnan(o_t) or (o_s < 0.1 and o_t < 0.1):
                 continue
             lines.append("{}\t{}\t{}\t{:.4f}\t{:.4f}\n".format(scene_name, s, t, o_s, o_t))

@@ -88,6 +88,26 @@ def random_sample_pose(batch_size: int, center=(0, 0, 3)) -> np.ndarray:
 # device ops (HIP)
 # ------------------------------------------------------------------------------------------------
 
+def random_sample_transform(intrinsic: np.ndarray, image_size: int = 256) -> np.ndarray:
+    """Random in-place camera rotation of Tester.generate (sd:377-415): pitch / yaw within the view frustum, any roll;
+    translation drawn and multiplied by zero (the randn still consumes the legacy numpy stream).  float32 (B,4,4)."""
+    K = np.asarray(intrinsic)
+    batch = K.shape[0]
+    h = w = image_size
+    fx, fy, cx, cy = K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2]
+    th_min, th_max = -np.arctan((h - cy) / fy), np.arctan(cy / fy)
+    ph_min, ph_max = -np.arctan(cx / fx), np.arctan((w - cx) / fx)
+    theta = np.random.rand(batch) * (th_max - th_min) + th_min
+    phi = np.random.rand(batch) * (ph_max - ph_min) + ph_min
+    psi = np.random.rand(batch) * 2 * np.pi - np.pi
+    R = Rotation.from_euler("XYZ", np.stack((theta, phi, psi), axis=-1), degrees=False).as_matrix()
+    t = np.random.randn(batch, 3) / 3 * 0
+    T = np.stack([np.eye(4) for _ in range(batch)])
+    T[..., :3, :3] = R
+    T[..., :3, 3] = t
+    return T.astype(np.float32)
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.PrgError("expected a tensor on the HIP device (this package has no CPU path)")
@@ -210,3 +230,16 @@ def apply_mask(prob: torch.Tensor, depth: torch.Tensor, hit: Optional[torch.Tens
     _lib.check(lib.prg_apply_mask(_lib.ptr(prob), _lib.ptr(depth), _lib.ptr(h8), float(threshold), _lib.ptr(d_out),
                                   _lib.ptr(h_out), _lib.ptr(cond), B, H, W, _lib.stream_ptr()), "prg_apply_mask")
     return d_out, h_out.to(torch.bool), cond
+
+
+def occlusion_filter(depth_rpj: torch.Tensor, mask_rpj: torch.Tensor, threshold: float = 0.0375):
+    """(sd:446-463) a reprojected pixel more than `threshold` metres behind the nearest valid depth of its 3x3 window
+    takes that depth (thin foreground structures win over what shows through them).  Returns (depth, mask unchanged)."""
+    lib = _lib.load()
+    depth = _f32(depth_rpj)
+    B, _, H, W = depth.shape
+    m8 = mask_rpj.contiguous().to(torch.uint8)
+    out = torch.empty_like(depth)
+    _lib.check(lib.prg_occlusion_filter(_lib.ptr(depth), _lib.ptr(m8), _lib.ptr(out), B, H, W, float(threshold),
+                                        _lib.stream_ptr()), "prg_occlusion_filter")
+    return out, mask_rpj

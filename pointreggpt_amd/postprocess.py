@@ -4,13 +4,17 @@ generate_gt.py:68-102).  open3d is not in this image, so these follow Open3D 0.1
 C++ source* and are **parity-unpinned** (DESIGN.md §2): crop bounds inclusive; voxel index =
 floor((p - (min_bound - voxel/2)) / voxel), output = per-voxel mean (output order unspecified in open3d: here sorted
 by voxel index, deterministic); PLY binary_little_endian with `double x y z`; radius search = any neighbour with
-squared distance < r^2.  Pure numpy, vectorised (no per-point Python loop: the reference's KD-tree loop is the
-wall-clock tail of config 4).
+squared distance < r^2.
+
+Two layers: the numpy forms below are the specification (and what the CPU tests compare with); `native_*` and `WriterPool`
+run the same arithmetic in the library's C++ (csrc/hostpool.cpp, include/prg.h "Host post-processing") — the writer pool
+produces a batch's files on worker threads while the GPU samples the next batch.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -180,3 +184,135 @@ def save_depth16(depth01: np.ndarray, path: str) -> None:
     a = np.asarray(depth01, dtype=np.float32)
     a = a.reshape(a.shape[-2], a.shape[-1])
     Image.fromarray((a * 1e4).astype(np.uint16)).save(path)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# native (C++) forms: csrc/hostpool.cpp behind the C-ABI
+# ------------------------------------------------------------------------------------------------------------------
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, 3))
+
+
+def _dp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def native_voxel_down_sample(pts, voxel_size: float) -> np.ndarray:
+    from . import _lib
+    lib = _lib.load()
+    p = _f64(pts)
+    out = np.empty_like(p)
+    n = C.c_int64(0)
+    _lib.check(lib.prg_host_voxel_down_sample(_dp(p), len(p), float(voxel_size), _dp(out), C.byref(n)),
+               "prg_host_voxel_down_sample")
+    return out[:n.value].copy()
+
+
+def native_crop_aabb(pts, lo=BBOX_MIN, hi=BBOX_MAX) -> np.ndarray:
+    from . import _lib
+    lib = _lib.load()
+    p = _f64(pts)
+    out = np.empty_like(p)
+    n = C.c_int64(0)
+    lo64, hi64 = np.ascontiguousarray(lo, dtype=np.float64), np.ascontiguousarray(hi, dtype=np.float64)
+    _lib.check(lib.prg_host_crop_aabb(_dp(p), len(p), _dp(lo64), _dp(hi64), _dp(out), C.byref(n)), "prg_host_crop_aabb")
+    return out[:n.value].copy()
+
+
+def native_write_ply(path: str, pts) -> None:
+    from . import _lib
+    p = _f64(pts)
+    _lib.check(_lib.load().prg_host_write_ply(os.fsencode(path), _dp(p), len(p)), "prg_host_write_ply")
+
+
+class WriterPool:
+    """Asynchronous per-scene output (prg_pool_*): every submit copies its inputs and returns at once; `wait()` blocks
+    until all files exist and raises on the first failed job."""
+
+    def __init__(self, threads: int = 0):
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        if threads <= 0:
+            threads = max(2, min(16, (os.cpu_count() or 4) // max(1, int(os.environ.get("WORLD_SIZE", "1"))) // 2))
+        self.threads = threads
+        self._h = C.c_void_p()
+        _lib.check(lib.prg_pool_create(int(threads), C.byref(self._h)), "prg_pool_create")
+
+    def cloud(self, path: str, xyz: np.ndarray, valid: Optional[np.ndarray] = None, *, pre: Optional[np.ndarray] = None,
+              crop: bool = True, voxel: float = 0.025, post: Optional[np.ndarray] = None, lo=BBOX_MIN, hi=BBOX_MAX):
+        """xyz (n,3) float64 [valid (n,) bool] -> pre (4x4) -> crop -> voxel mean -> post (4x4) -> PLY at `path`."""
+        p = _f64(xyz)
+        v = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
+        t0 = None if pre is None else np.ascontiguousarray(pre, dtype=np.float64)
+        t1 = None if post is None else np.ascontiguousarray(post, dtype=np.float64)
+        lo64, hi64 = np.ascontiguousarray(lo, dtype=np.float64), np.ascontiguousarray(hi, dtype=np.float64)
+        self._lib.check(self._lib.load().prg_pool_submit_cloud(self._h, os.fsencode(path), _dp(p), len(p), _dp(v), _dp(t0),
+                                                               int(crop), _dp(lo64), _dp(hi64), float(voxel), _dp(t1)),
+                        "prg_pool_submit_cloud")
+
+    def image01(self, path: str, img: np.ndarray):
+        a = np.ascontiguousarray(np.asarray(img, dtype=np.float32).reshape(img.shape[-2], img.shape[-1]))
+        self._lib.check(self._lib.load().prg_pool_submit_image(self._h, os.fsencode(path), _dp(a), a.shape[0], a.shape[1], 0))
+
+    def depth16(self, path: str, img: np.ndarray):
+        a = np.ascontiguousarray(np.asarray(img, dtype=np.float32).reshape(img.shape[-2], img.shape[-1]))
+        self._lib.check(self._lib.load().prg_pool_submit_image(self._h, os.fsencode(path), _dp(a), a.shape[0], a.shape[1], 1))
+
+    def text(self, path: str, values: np.ndarray):
+        a = np.ascontiguousarray(np.atleast_2d(np.asarray(values, dtype=np.float64)))
+        self._lib.check(self._lib.load().prg_pool_submit_text(self._h, os.fsencode(path), _dp(a), a.shape[0], a.shape[1]))
+
+    def wait(self) -> int:
+        n = C.c_int64(0)
+        self._lib.check(self._lib.load().prg_pool_wait(self._h, C.byref(n)), "prg_pool_wait")
+        return int(n.value)
+
+    def close(self):
+        if self._h:
+            self._lib.load().prg_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# overlap ratios on the GPU (generate_gt.py:68-102): voxel grids in C++, neighbour-existence counts in one HIP launch
+# ------------------------------------------------------------------------------------------------------------------
+def overlap_ratios_hip(pairs, voxel_size: float = 0.025, overlap_factor: float = 1.5, is_down_sample: bool = True,
+                       device="cuda"):
+    """[(src (n,3), tgt (m,3)), ...] -> [(overlap_src, overlap_tgt), ...] exactly as compute_overlap_ratio defines them:
+    both clouds voxel-down-sampled, then the fraction of points with a point of the other cloud strictly within
+    overlap_factor * voxel_size.  One prg_overlap_counts launch for the whole list (float64 all-pairs test)."""
+    import torch
+
+    from . import _lib
+    lib = _lib.load()
+    _lib.require_gpu()
+    if not pairs:
+        return []
+    clouds = []
+    for a, b in pairs:
+        for c in (a, b):
+            clouds.append(native_voxel_down_sample(c, voxel_size) if is_down_sample else _f64(c))
+    sizes = np.array([len(c) for c in clouds], dtype=np.int64)
+    offs = np.zeros(len(clouds) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(sizes)
+    out = []
+    if offs[-1] == 0 or sizes.max() == 0:
+        return [(float("nan"), float("nan"))] * len(pairs)
+    pts = torch.from_numpy(np.concatenate([c for c in clouds if len(c)], axis=0)).to(device)
+    d_offs = torch.from_numpy(offs).to(device)
+    counts = torch.empty((len(pairs), 2), dtype=torch.int32, device=device)
+    _lib.check(lib.prg_overlap_counts(_lib.ptr(pts), _lib.ptr(d_offs), len(pairs), int(sizes.max()),
+                                      float(voxel_size * overlap_factor), _lib.ptr(counts), _lib.stream_ptr()),
+               "prg_overlap_counts")
+    cnt = counts.cpu().numpy().astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(len(pairs)):
+            out.append((float(cnt[i, 0] / np.float64(sizes[2 * i])), float(cnt[i, 1] / np.float64(sizes[2 * i + 1]))))
+    return out

@@ -5,8 +5,8 @@ Tolerances (stated per assert):
   * geometry / z-buffer / masks / DDNM known pixels: bit-exact;
   * fp32 mode (exact-f32 MFMA): |err| <= 1e-4 on O(1..10) activations — accumulation-order roundoff only
     (observed 3e-6 .. 1.4e-5);
-  * bf16 mode: |err| <= 0.25 max, <= 0.03 mean on O(1..10) activations (observed 0.05 / 0.011): bf16 storage of
-    ~100 chained layers; reported, not hidden — the parity claim of the round is made in fp32 mode.
+  * bf16 mode: |err| <= 0.125 max, <= 0.022 mean on O(1..10) activations (observed 0.062 / 0.0104 at the benchmarked
+    size): bf16 storage of ~100 chained layers; bounds are <= 2x what is observed, and the drift is printed.
 """
 import numpy as np
 import pytest
@@ -17,7 +17,10 @@ from pointreggpt_amd import weights as W
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4
-BF16_MAX, BF16_MEAN = 0.25, 0.03
+BF16_MAX, BF16_MEAN = 0.125, 0.022       # <= 2x observed (dim 64: max 0.062 / mean 0.0104 at 128x128, 0.056 / 0.0094 at 256x256)
+NORTH_STAR = 1e-5          # point-XYZ L-infinity 1e-4 m == 1e-5 in normalised depth (1.0 == 10 m)
+XYZ_FLOOR_FACTOR = 2.0
+BF16_CHAIN_MAX, BF16_CHAIN_MEAN = 0.08, 0.004    # few-transition chains, in-painted pixels, normalised depth: <= 2x observed (0.038 / 0.002)
 
 
 @pytest.fixture(scope="module")
@@ -137,6 +140,7 @@ def test_unet_small_bf16(hip, golden, dim):
     g = golden("G7_unet_small_taps")
     net = hip.Unet(dim, dtype="bf16").load_state_dict(W.synth_state_dict(W.unet_config(dim), 7))
     y = net(D(g[f"d{dim}_x"]), D(g[f"d{dim}_t"]), D(g[f"d{dim}_pc"]))
+    print(f"dim {dim} bf16: max {maxerr(y, g[f'd{dim}_y']):.3e} mean {meanerr(y, g[f'd{dim}_y']):.3e}")
     assert maxerr(y, g[f"d{dim}_y"]) <= BF16_MAX and meanerr(y, g[f"d{dim}_y"]) <= BF16_MEAN
 
 
@@ -146,6 +150,7 @@ def test_unet_dim64(hip, golden):
     y = hip.Unet(64, dtype="fp32").load_state_dict(sd)(D(g["x"]), D(g["t"]), D(g["pc"]))
     assert maxerr(y, g["y"]) <= FP32_TOL
     y = hip.Unet(64, dtype="bf16").load_state_dict(sd)(D(g["x"]), D(g["t"]), D(g["pc"]))
+    print(f"dim 64 @64 bf16: max {maxerr(y, g['y']):.3e} mean {meanerr(y, g['y']):.3e}")
     assert maxerr(y, g["y"]) <= BF16_MAX and meanerr(y, g["y"]) <= BF16_MEAN
 
 
@@ -179,19 +184,22 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gold = os.path.join(root, "tests", "golden", "G8_unet_dim64.npz")
     outs = {}
-    for name, env in {"fast": {}, "no_ws": {"PRG_CONV_WS": "0"}, "no_fused_attn": {"PRG_FUSED_ATTN": "0"}}.items():
+    variants = {"fast": {}, "no_ws": {"PRG_CONV_WS": "0"}, "no_fused_attn": {"PRG_FUSED_ATTN": "0"},
+                "no_kshift": {"PRG_LA_KSHIFT": "0"}}       # measured column maxima instead of the static softmax shift
+    for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
         r = subprocess.run([sys.executable, "-c", _FASTPATH_SCRIPT.format(root=root, gold=gold, out=out)], env=e,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
-    for name in ("no_ws", "no_fused_attn"):
+    for name in ("no_ws", "no_fused_attn", "no_kshift"):
         for k in ("y64", "y128", "y40"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()
             # bf16 re-rounding of ~100 chained layers; observed max 0.06 / mean 0.008 on O(7) activations
-            assert d.max() <= 0.2 and d.mean() <= 0.02, (name, k, d.max(), d.mean())
+            print(f"fast vs {name} [{k}]: max {d.max():.3e} mean {d.mean():.3e}")
+            assert d.max() <= 0.12 and d.mean() <= 0.016, (name, k, d.max(), d.mean())
 
 
 def test_unet_vs_oracle_odd_batch_and_size(hip):
@@ -214,7 +222,9 @@ def test_maskunet(hip, golden, dim):
     p = hip.MaskUnet(dim, dtype="fp32").load_state_dict(sd)(D(g["depth"]))
     assert maxerr(p, g[f"d{dim}_prob"]) <= 1e-5           # probabilities: observed 6e-7
     p = hip.MaskUnet(dim, dtype="bf16").load_state_dict(sd)(D(g["depth"]))
-    assert maxerr(p, g[f"d{dim}_prob"]) <= 0.03           # observed 4e-3
+    e = maxerr(p, g[f"d{dim}_prob"])
+    print(f"MaskUnet dim {dim} bf16: {e:.3e}")
+    assert e <= 0.01                                           # observed 4e-3
 
 
 def test_bad_arguments_fail_loudly(hip):
@@ -288,7 +298,7 @@ def test_short_chains_bf16_drift_reported(hip, golden):
     assert np.array_equal(out.cpu().numpy()[known], g["ddim5_out"][known])       # exact even in bf16
     e = maxerr(out, g["ddim5_out"])
     print(f"bf16 5-step DDIM drift on in-painted pixels: max {e:.3e} (normalised depth; x10 for metres)")
-    assert e <= 0.2
+    assert e <= 0.07                                           # <= 2x observed (3.3e-2)
 
 
 def test_philox_noise_is_shard_invariant(hip):
@@ -333,13 +343,267 @@ def test_end_to_end_pair_64(hip, golden):
     out, _, _ = hip.G.apply_mask(prob2, img, None, float(g["thr2"]), want_cond=False)
     same_mask = np.array_equal((out.cpu().numpy() > 0), (g["depth_out"] > 0))
     cloud = hip.G.point_clouds(out, K, pose)[0]
-    print(f"end-to-end 64x64/50-step: |depth err|max = {e_img:.3e} (normalised), mask identical = {same_mask}, "
-          f"points {len(cloud)} vs {len(g['cloud'])}")
-    assert e_img <= 1e-4                                   # normalised depth; = 1e-3 m
-    if same_mask and len(cloud) == len(g["cloud"]):
-        linf = float(np.abs(cloud - g["cloud"]).max())
-        print(f"point-XYZ L-infinity vs reference: {linf:.3e} m")
-        assert linf <= 1e-3
+    env = golden("G12b_envelope")
+    floor = float(env["xyz_exact"])        # reference fp32 vs exact arithmetic on this very chain: 1.41e-4 m
+    e_exact = maxerr(img, env["sampled_exact"])
+    print(f"end-to-end 64x64/50-step: |depth err|max = {e_img:.3e} vs reference, {e_exact:.3e} vs exact arithmetic "
+          f"(reference vs exact {float(env['depth_exact']):.3e}, reference 1 thread vs 8 threads {float(env['depth_1thread']):.3e}); "
+          f"mask identical = {same_mask}, points {len(cloud)} vs {len(g['cloud'])}")
+    # The parity metric, unconditionally: same mask, same point count, point-XYZ L-infinity.
+    assert same_mask and len(cloud) == len(g["cloud"]), "a depth-correction mask pixel flipped"
+    linf = float(np.abs(cloud - g["cloud"]).max())
+    print(f"point-XYZ L-infinity vs reference: {linf:.3e} m  (north star 1e-4 m; measured floor of this chain: the reference "
+          f"moves by {float(env['xyz_1thread']):.2e} m with another thread count and sits {floor:.2e} m from exact arithmetic)")
+    # BASELINE's tolerance is 1e-4 m.  On THIS chain the reference itself is not reproducible to 1e-4 m (G12b): the bound is
+    # the north star or, where the measured floor is above it, XYZ_FLOOR_FACTOR x that floor (two fp32 evaluations with
+    # independent roundoff differ by up to the sum of their distances from exact arithmetic).
+    assert linf <= max(1e-4, XYZ_FLOOR_FACTOR * floor), linf
+    assert e_exact <= XYZ_FLOOR_FACTOR * float(env["depth_exact"])      # HIP fp32 is as close to exact as the reference is
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the benchmarked configuration: dim 64 at 128x128 (and the reference's shipped 256x256), against the real reference's
+# fixtures and their float64 "exact arithmetic" twins
+# ------------------------------------------------------------------------------------------------------------------
+def _tap_report(net, g, B, label):
+    rows = []
+    for k in TAPS:
+        t = net.get_tap(k, B).reshape(-1)[D(g[f"tap_{k}_idx"])]
+        rows.append((k, maxerr(t, g[f"tap_{k}"]), maxerr(t, g[f"tap_{k}_64"]),
+                     float(np.abs(g[f"tap_{k}"].astype(np.float64) - g[f"tap_{k}_64"]).max()), float(np.abs(g[f"tap_{k}_64"]).max())))
+    print(f"\n{label}: tap | hip-ref32 | hip-exact | ref32-exact | scale")
+    for r in rows:
+        print("   %-14s %.3e  %.3e  %.3e  %.2f" % r)
+    return rows
+
+
+@pytest.mark.parametrize("fixture,wseed,B", [("G13_unet_dim64_128", 13, 2), ("G16_unet_dim64_256", 16, 1)])
+def test_unet_dim64_full_size_taps(hip, golden, fixture, wseed, B):
+    """dim-64 U-Net at 128x128 (the benchmarked resolution) and 256x256 (the shipped one): output + seven taps."""
+    g = golden(fixture)
+    sd = W.synth_state_dict(W.unet_config(64), wseed)
+    net = hip.Unet(64, dtype="fp32").load_state_dict(sd)
+    net.set_taps(True)
+    y = net(D(g["x"]), D(g["t"]), D(g["pc"]))
+    rows = _tap_report(net, g, B, fixture + " fp32")
+    e_ref, e_exact, floor = maxerr(y, g["y"]), maxerr(y, g["y64"]), float(np.abs(g["y"].astype(np.float64) - g["y64"]).max())
+    print(f"   output: hip-ref32 {e_ref:.3e}  hip-exact {e_exact:.3e}  ref32-exact {floor:.3e}")
+    for k, e, _, _, _ in rows:
+        assert e <= FP32_TOL, k
+    assert e_ref <= 2e-5 and e_exact <= 3 * floor      # output O(5): fp32 roundoff only, and not further from exact than 3x the reference
+    net.close()
+    net = hip.Unet(64, dtype="bf16").load_state_dict(sd)
+    net.set_taps(True)
+    y = net(D(g["x"]), D(g["t"]), D(g["pc"]))
+    _tap_report(net, g, B, fixture + " bf16")
+    print(f"   output bf16: max {maxerr(y, g['y']):.3e} mean {meanerr(y, g['y']):.3e}")
+    assert maxerr(y, g["y"]) <= BF16_MAX and meanerr(y, g["y"]) <= BF16_MEAN
+
+
+def test_chain8_dim64_128(hip, golden):
+    """dim-64 ancestral chain (8 transitions, mixed DDNM mask, stored noise) at 128x128: the north-star tolerance
+    (1e-5 normalised = 1e-4 m) holds in fp32 mode; bf16 drift of the same chain is reported and bounded."""
+    g = golden("G14_chain8_dim64_128")
+    sd = W.synth_state_dict(W.unet_config(64), 14)
+    known = (g["cond"][:, 1:2] + 1) * 0.5 > 0.5
+    for graph in (True, False):
+        net = hip.Unet(64, dtype="fp32").load_state_dict(sd)
+        d8 = hip.GaussianDiffusion(net, image_size=128, timesteps=8)
+        out = d8.sample(param_cond=D(g["pc"]), img_cond=D(g["cond"]), noise=D(g["noise"]), use_graph=graph)
+        e, ex = maxerr(out, g["out"]), maxerr(out, g["out64"])
+        print(f"chain8@128 fp32 (graph={graph}): hip-ref32 {e:.3e}  hip-exact {ex:.3e}  ref32-exact "
+              f"{float(np.abs(g['out'] - g['out64']).max()):.3e}")
+        assert e <= NORTH_STAR
+        assert np.array_equal(out.cpu().numpy()[known], g["out"][known])
+        net.close()
+    net = hip.Unet(64, dtype="bf16").load_state_dict(sd)
+    d8 = hip.GaussianDiffusion(net, image_size=128, timesteps=8)
+    out = d8.sample(param_cond=D(g["pc"]), img_cond=D(g["cond"]), noise=D(g["noise"]))
+    assert np.array_equal(out.cpu().numpy()[known], g["out"][known])
+    e, em = maxerr(out, g["out"]), meanerr(out, g["out"])
+    print(f"chain8@128 bf16: in-painted pixels max {e:.3e} mean {em:.3e} (normalised depth; x10 for metres)")
+    assert e <= BF16_CHAIN_MAX and em <= BF16_CHAIN_MEAN
+
+
+def test_maskunet_dim64_128(hip, golden):
+    g = golden("G15_maskunet_dim64_128")
+    sd = W.synth_state_dict(W.maskunet_config(64), 15, final_bias=6.0)
+    p = hip.MaskUnet(64, dtype="fp32").load_state_dict(sd)(D(g["depth"]))
+    e = maxerr(p, g["prob"])
+    print(f"MaskUnet dim64@128 fp32: {e:.3e} (exact {maxerr(p, g['prob64']):.3e})")
+    assert e <= 1e-5
+    p = hip.MaskUnet(64, dtype="bf16").load_state_dict(sd)(D(g["depth"]))
+    e = maxerr(p, g["prob"])
+    print(f"MaskUnet dim64@128 bf16: max {e:.3e} mean {meanerr(p, g['prob']):.3e}")
+    assert e <= 1e-3                                           # observed 2.3e-4
+
+
+def test_ddim_known_pixels_above_one(hip, golden):
+    """ddim_sample does not clamp the DDNM-replaced pixels (sd:1197-1218, 1371); p_sample does (sd:1250)."""
+    g = golden("G17_ddim_cond_gt1")
+    net = hip.Unet(16, dtype="fp32").load_state_dict(W.synth_state_dict(W.unet_config(16), 9))
+    known = (g["cond"][:, 1:2] + 1) * 0.5 > 0.5
+    d5 = hip.GaussianDiffusion(net, image_size=32, timesteps=1000, sampling_timesteps=5)
+    out = d5.sample(param_cond=D(g["pc"]), img_cond=D(g["cond"]), noise=D(g["ddim5_noise"]))
+    assert maxerr(out, g["ddim5_out"]) <= FP32_TOL and float(out.max()) > 1.0
+    assert np.array_equal(out.cpu().numpy()[known], g["ddim5_out"][known])
+    d8 = hip.GaussianDiffusion(net, image_size=32, timesteps=8)
+    out = d8.sample(param_cond=D(g["pc"]), img_cond=D(g["cond"]), noise=D(g["chain8_noise"]))
+    assert maxerr(out, g["chain8_out"]) <= FP32_TOL and float(out.max()) <= 1.0
+
+
+def test_benchmark_batch_bf16_against_oracle(hip):
+    """The benchmarked launch shapes themselves: B = 64, 128x128, dim 64, bf16, four ancestral DDNM transitions
+    (t = 999, 500, 1, 0 rows of the 1000-step table) with stored noise and a mixed mask, compared per image with the
+    CPU oracle (batch-invariant) for three batch slots."""
+    from oracle import diffusion as OD
+    from oracle import unet as OU
+    from pointreggpt_amd import synthetic
+    B, S = 64, 128
+    sd = W.synth_state_dict(W.unet_config(64), 64)
+    depth, K, pose = synthetic.synth_batch(64, range(B), S)
+    Kd = D(K)
+    rpj, hit = hip.G.reproject_tensor(D(depth), Kd, D(pose), clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+    _, _, cond = hip.G.apply_mask(torch.ones_like(rpj), rpj, hit, 0.5)
+    pc = hip.G.param_vector(Kd)
+    gen = torch.Generator().manual_seed(64)
+    noise = torch.randn((5, B, 1, S, S), generator=gen)
+    net = hip.Unet(64, dtype="bf16").load_state_dict(sd)
+    d = hip.GaussianDiffusion(net, image_size=S, timesteps=1000)
+    table = d.step_table()
+    rows = [table[0], table[499], table[998], table[999]]
+    d.step_table = lambda: rows
+    out = d.sample(param_cond=pc, img_cond=cond, noise=noise.cuda()).cpu()
+    sch = OD.schedule(1000)
+    den = lambda x, t, c: OU.unet_forward(sd, x, t, c)
+    cond_h, pc_h = cond.cpu(), pc.cpu()
+    worst = 0.0
+    for b in (0, 31, 63):
+        x = noise[0, b:b + 1]
+        for k, r in enumerate(rows):
+            x, _ = OD.p_sample(sch, den, x, r["t"], pc_h[b:b + 1], cond_h[b:b + 1], noise[k + 1, b:b + 1])
+        ref = (x + 1) * 0.5
+        known = OD.cond_mask(cond_h[b:b + 1])
+        assert torch.equal(out[b:b + 1][known], ref[known])
+        e, em = float((out[b:b + 1] - ref).abs().max()), float((out[b:b + 1] - ref).abs().mean())
+        print(f"B=64 bf16 slot {b}: 4 transitions, in-painted max {e:.3e} mean {em:.3e}; known pixels exact")
+        worst = max(worst, e)
+        assert e <= BF16_CHAIN_MAX and em <= BF16_CHAIN_MEAN
+    assert worst > 0.0          # bf16 is not expected to be exact: a zero would mean the comparison is vacuous
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# successive multi-view generation (Tester.sample / Tester.generate, sd:1960-2247): refine step, occlusion filter
+# ------------------------------------------------------------------------------------------------------------------
+def test_refine_step_and_occlusion_filter(hip, golden):
+    g = golden("G18_refine_occlusion_transform")
+    net = hip.Unet(16, dtype="fp32").load_state_dict(W.synth_state_dict(W.unet_config(16), 9))
+    known = (g["cond"][:, 1:2] + 1) * 0.5 > 0.5
+    d5 = hip.GaussianDiffusion(net, image_size=32, timesteps=1000, sampling_timesteps=5)
+    out = d5.sample(param_cond=D(g["pc"]), img_cond=D(g["cond"]), noise=D(g["ddim5_refine_noise"]), has_refine_step=True)
+    assert maxerr(out, g["ddim5_refine_out"]) <= FP32_TOL
+    # the refine step rewrites exactly the KNOWN pixels (with the network's own prediction); without it they hold the condition
+    plain = d5.sample(param_cond=D(g["pc"]), img_cond=D(g["cond"]), noise=D(g["ddim5_refine_noise"]))
+    assert torch.equal(plain.cpu()[torch.from_numpy(~known)], out.cpu()[torch.from_numpy(~known)])
+    assert not torch.equal(plain.cpu()[torch.from_numpy(known)], out.cpu()[torch.from_numpy(known)])
+    d8 = hip.GaussianDiffusion(net, image_size=32, timesteps=8)
+    out = d8.sample(param_cond=D(g["pc"]), img_cond=D(g["cond"]), noise=D(g["chain8_refine_noise"]), has_refine_step=True)
+    assert maxerr(out, g["chain8_refine_out"]) <= FP32_TOL
+    d, m = hip.G.occlusion_filter(D(g["of_depth_in"]), D(g["of_mask_in"]))
+    assert np.array_equal(d.cpu().numpy(), g["of_depth_out"]) and np.array_equal(m.cpu().numpy(), g["of_mask_out"])
+
+
+def test_tester_successive_views_against_oracle_sequence(hip, tmp_path):
+    """Tester.sample (sd:1960-2093): unconditional view, then two views 0.5 m further each, conditioned on the reprojected,
+    occlusion-filtered previous view — the same sequence restated with the oracle's functions on the stored noise."""
+    from oracle import diffusion as OD
+    from oracle import geometry as OG
+    from oracle import unet as OU
+    from pointreggpt_amd.tester import Tester
+    from pointreggpt_amd import postprocess as PP
+    S, B, steps, views = 32, 2, 4, 3
+    sd = W.synth_state_dict(W.unet_config(16), 31)
+    net = hip.Unet(16, dtype="fp32").load_state_dict(sd)
+    diff = hip.GaussianDiffusion(net, image_size=S, timesteps=1000, sampling_timesteps=steps)
+    gen = torch.Generator().manual_seed(31)
+    noise = [torch.randn((steps, B, 1, S, S), generator=gen) for _ in range(views)]
+    np.random.seed(31)
+    strips = Tester(diff, batch_size=B, samples_folder=str(tmp_path / "s")).sample(B, views, noise=noise)
+    assert len(strips) == 1 and tuple(strips[0].shape) == (B, 1, S, S * views)
+    # oracle restatement
+    np.random.seed(31)
+    K = hip.G.intrinsic_transform(hip.G.random_sample_intrinsic(B), resize=S, centercrop=S).astype(np.float32)
+    sch, Kt = OD.schedule(1000), torch.from_numpy(K)
+    pc = OG.param_vector(Kt)
+    den = lambda x, t, c: OU.unet_forward(sd, x, t, c)
+    img = OD.sample(sch, den, pc, None, S, OD.stored_noise(noise[0]), sampling_steps=steps)
+    got = strips[0].cpu()
+    assert float((got[..., :S] - img).abs().max()) <= FP32_TOL
+    absolute = np.stack([np.eye(4)] * B).astype(np.float32)
+    for k in range(1, views):
+        rel = np.stack([np.eye(4)] * B)
+        rel[:, :3, 3] = [0, 0, 0.5]
+        rel = rel.astype(np.float32)
+        absolute = rel @ absolute
+        # condition built from the HIP path's own previous view: a last-bit difference upstream must not move a z-buffer pixel
+        prev = got[..., (k - 1) * S:k * S].contiguous()
+        d_rpj, hit = OG.reproject_tensor(prev * 10, Kt, torch.from_numpy(rel), (0, 10))
+        d_rpj, hit = OG.occlusion_filter(d_rpj, hit)
+        cond = torch.cat([d_rpj * 0.1, hit.float()], 1) * 2 - 1
+        img = OD.sample(sch, den, pc, cond, S, OD.stored_noise(noise[k]), sampling_steps=steps)
+        view = got[..., k * S:(k + 1) * S]
+        known = OD.cond_mask(cond)
+        assert float((view - img).abs().max()) <= FP32_TOL, k
+        assert int((view[known] != img[known]).sum()) <= 2        # (2-ulp host-BLAS effect on z, DESIGN.md section 2)
+        cloud = PP.read_ply(str(tmp_path / "s" / f"scene-1-sample-{k}.ply"))
+        ref = OG.inverse_pose_apply(OG.point_cloud(view[1, 0].numpy() * 10, K[1], (0.5, 3.5)), absolute[1])
+        assert cloud.shape == ref.shape and np.abs(cloud - ref).max() < 1e-12
+    assert (tmp_path / "s" / "scene-0-camera-intrinsics.txt").is_file() and (tmp_path / "s" / "scene-1-sample-2.png").is_file()
+
+
+def test_tester_generate_accumulates_a_scene(hip, tmp_path):
+    """Tester.generate (sd:2095-2247): random in-place rotations, accumulated cloud re-projected as the condition."""
+    from pointreggpt_amd.tester import Tester
+    from pointreggpt_amd import postprocess as PP
+    net = hip.Unet(16, dtype="fp32").init_synthetic(32)
+    diff = hip.GaussianDiffusion(net, image_size=32, timesteps=1000, sampling_timesteps=3)
+    np.random.seed(5)
+    t = Tester(diff, batch_size=2, samples_folder=str(tmp_path / "g"), seed=9)
+    scenes = t.generate(3, 3, voxel_size=0.005)
+    assert [len(b) for b in scenes] == [2, 1]
+    for i in range(3):
+        final = PP.read_ply(str(tmp_path / "g" / f"scene-{i}.ply"))
+        acc = scenes[i // 2][i % 2]
+        assert acc.dtype == np.float32 and len(acc) > 0 and np.isfinite(final).all()
+        ref = PP.voxel_down_sample(acc, 0.025)
+        assert final.shape == ref.shape and np.abs(final - ref).max() < 1e-12
+    # same seeds, same scenes: the run is reproducible (Philox keys per scene and view, numpy stream for the rotations)
+    np.random.seed(5)
+    again = Tester(diff, batch_size=2, samples_folder=str(tmp_path / "g2"), seed=9).generate(3, 3, voxel_size=0.005)
+    assert all(np.array_equal(a, b) for ba, bb in zip(scenes, again) for a, b in zip(ba, bb))
+
+
+def test_overlap_counts_against_kdtree_oracle(hip):
+    """generate_gt's overlap ratio (generate_gt.py:68-102): HIP all-pairs kernel vs scipy cKDTree (oracle) and the numpy
+    grid specification, on overlapping, disjoint, tiny and empty clouds."""
+    from oracle import postprocess as OP
+    from pointreggpt_amd import postprocess as PP
+    rng = np.random.default_rng(8)
+
+    def cloud(n, shift):
+        return np.c_[rng.uniform(-1.2, 1.2, n) + shift, rng.uniform(-1.0, 1.0, n), 2.0 + 0.05 * rng.standard_normal(n)]
+
+    pairs = [(cloud(6000, 0.0), cloud(5000, 0.4)), (cloud(3000, 0.0), cloud(3000, 5.0)), (cloud(40, 0.0), cloud(4000, 0.0)),
+             (cloud(2500, 0.0), cloud(2500, 0.02))]
+    got = PP.overlap_ratios_hip(pairs)
+    for (a, b), (o1, o2) in zip(pairs, got):
+        r1, r2 = OP.overlap_ratio(a, b)
+        s1, s2 = PP.compute_overlap_ratio(a, b)
+        assert (o1, o2) == (s1, s2), ((o1, o2), (s1, s2))          # identical counts -> identical float64 ratios
+        assert abs(o1 - r1) < 1e-12 and abs(o2 - r2) < 1e-12
+    assert got[1] == (0.0, 0.0) and 0.2 < got[0][0] < 1.0
+    e = PP.overlap_ratios_hip([(np.zeros((0, 3)), cloud(100, 0.0))])
+    assert np.isnan(e[0][0]) and e[0][1] == 0.0
 
 
 # ------------------------------------------------------------------------------------------------------------------

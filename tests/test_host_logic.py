@@ -68,6 +68,11 @@ def test_host_geometry_against_reference_goldens(golden):
         assert np.array_equal(np.random.rand(2), g[f"after_seed{s}"])
         np.random.seed(s)
         assert np.array_equal(G.random_sample_intrinsic(16), g[f"intr_seed{s}"])
+    g18 = golden("G18_refine_occlusion_transform")
+    for s_ in (0, 7):
+        np.random.seed(s_)
+        assert np.array_equal(G.random_sample_transform(g18["rst_K"], 64), g18[f"rst_seed{s_}"])
+        assert np.array_equal(np.random.rand(2), g18[f"rst_after_seed{s_}"])
     K = torch.tensor(g["pose_seed0"][:, :3, :3])
     assert torch.equal(G.param_vector(K), torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], -1))
 

@@ -253,3 +253,23 @@ def test_G12b_noise_floor_of_the_parity_metric(golden):
     assert 0.9e-4 < float(e["xyz_1thread"]) < 1.2e-4 and 1.2e-4 < float(e["xyz_exact"]) < 1.6e-4
     known = OD.cond_mask(T(g["img_cond"])).numpy()
     assert np.array_equal(e["sampled_1thread"][known], g["sampled"][known])    # DDNM pixels never move
+
+
+def test_G18_refine_step_occlusion_filter_random_transform(golden):
+    """What Tester.sample / Tester.generate add to the generator's path (sd:1307-1314, 1374-1388, 446-463, 377-415)."""
+    g = golden("G18_refine_occlusion_transform")
+    den = _denoiser(16, 9)
+    pc, cond = T(g["pc"]), T(g["cond"])
+    out = OD.sample(OD.schedule(1000), den, pc, cond, 32, OD.stored_noise(T(g["ddim5_refine_noise"])), sampling_steps=5,
+                    has_refine_step=True)
+    assert np.array_equal(out.numpy(), g["ddim5_refine_out"])
+    out = OD.p_sample_loop(OD.schedule(8), den, pc, cond, (2, 1, 32, 32), OD.stored_noise(T(g["chain8_refine_noise"])),
+                           has_refine_step=True)
+    assert np.array_equal(out.numpy(), g["chain8_refine_out"])
+    d, m = OG.occlusion_filter(T(g["of_depth_in"]), T(g["of_mask_in"]))
+    assert np.array_equal(d.numpy(), g["of_depth_out"]) and np.array_equal(m.numpy(), g["of_mask_out"])
+    assert (g["of_depth_out"] != g["of_depth_in"]).sum() > 10             # the filter does something on this input
+    for s_ in (0, 7):
+        np.random.seed(s_)
+        assert np.array_equal(OG.random_sample_transform(g["rst_K"], 64), g[f"rst_seed{s_}"])
+        assert np.array_equal(np.random.rand(2), g[f"rst_after_seed{s_}"])

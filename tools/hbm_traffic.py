@@ -33,7 +33,11 @@ out = {
                   "WRITE_SIZE as reported; KB -> bytes x1024",
     "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace ... ; rocprofv3 --pmc WRITE_SIZE --kernel-trace ... -- python bench.py "
                "--steps 1 --warmup 0 --sampling-steps 2 --no-cpu-baseline --no-roofline (separate passes)",
-    "round": "r01",
+    "round": "r02",
+    "kernel_sources_sha256": __import__("hashlib").sha256(b"".join(
+        open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..",
+                                        "pointreggpt_amd", "csrc", f), "rb").read()
+        for f in ("conv_ws.hip", "conv.hip", "conv.h", "common.h"))).hexdigest(),
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

@@ -420,6 +420,35 @@ def g17_ddim_cond_gt1():
     save("G17_ddim_cond_gt1", pc=pc, cond=cond, ddim5_noise=nz, ddim5_out=img, chain8_noise=nz8, chain8_out=img8)
 
 
+def g18_refine_and_tester():
+    """has_refine_step for both samplers (sd:1307-1314, 1374-1388), occlusion_filter (sd:446-463) and
+    random_sample_transform (sd:377-415): the pieces Tester.sample / Tester.generate add to the generator's path."""
+    S, B, dim = 32, 2, 16
+    m = ref_unet(dim, 9)
+    pc = torch.tensor([[37.87, 38.02, 16.25, 16.0], [36.5, 36.7, 16.25, 16.0]])
+    cond = mixed_cond(B, S, 18)
+    out = {"pc": pc, "cond": cond}
+    d5 = ref_diffusion(m, S, T=1000, steps=5)
+    img, nz = recorded_noise(lambda: d5.sample(param_cond=pc, img_cond=cond, disable_tqdm=True, has_refine_step=True), 1801)
+    out["ddim5_refine_out"], out["ddim5_refine_noise"] = img, nz
+    d8 = ref_diffusion(m, S, T=8)
+    img, nz = recorded_noise(lambda: d8.sample(param_cond=pc, img_cond=cond, disable_tqdm=True, has_refine_step=True), 1802)
+    out["chain8_refine_out"], out["chain8_refine_noise"] = img, nz
+    # occlusion filter on a reprojected synthetic batch (metres), incl. an image with an empty hit mask
+    depth, K, pose = synthetic.synth_batch(18, range(3), 64)
+    d_rpj, hit = sd.reproject_tensor(torch.tensor(depth) * 10, torch.tensor(K), torch.tensor(pose), clip=[0, 10])
+    hit[2] = False
+    d_rpj[2] = 0
+    of_d, of_m = sd.occlusion_filter(d_rpj.clone(), hit.clone())
+    out.update(of_depth_in=d_rpj, of_mask_in=hit, of_depth_out=of_d, of_mask_out=of_m)
+    for s_ in (0, 7):
+        np.random.seed(s_)
+        out[f"rst_seed{s_}"] = sd.random_sample_transform(K, image_size=64)
+        out[f"rst_after_seed{s_}"] = np.random.rand(2)
+    out["rst_K"] = K
+    save("G18_refine_occlusion_transform", **out)
+
+
 def g12b_envelope():
     """Noise floor of the parity metric on the G12 chain (64x64, 50-step DDIM, dim 64): the reference against (a) itself
     with one thread instead of eight (another oneDNN blocking: another summation order) and (b) exact arithmetic."""
@@ -475,7 +504,7 @@ if __name__ == "__main__":
     jobs = [("g1", g1_schedule), ("g2", g2_intrinsics), ("g3", g3_pose), ("g4", g4_pc2depth), ("g5", g5_g6_reproject),
             ("g7", g7_unet_taps), ("g8", g8_unet_full), ("g9", g9_g10_sampler), ("g11", g11_maskunet),
             ("g12", g12_end_to_end), ("g12b", g12b_envelope), ("g13", g13_unet_128), ("g14", g14_chain_128),
-            ("g15", g15_maskunet_128), ("g16", g16_unet_256), ("g17", g17_ddim_cond_gt1), ("spec", spec_fixture)]
+            ("g15", g15_maskunet_128), ("g16", g16_unet_256), ("g17", g17_ddim_cond_gt1), ("g18", g18_refine_and_tester), ("spec", spec_fixture)]
     for name, fn in jobs:
         if not only or name in only:
             fn()
