@@ -127,6 +127,11 @@ int64_t prg_unet_param_count(const prg_unet_config* cfg);
 int prg_unet_create(const prg_unet_config* cfg, const float* weights, int64_t n_floats, int dtype,
                     prg_unet** out);
 int prg_unet_destroy(prg_unet* h);
+/* SinusoidalPosEmb frequencies (sd:645-657): freqs (HOST, dim/2 float32) = exp(arange(dim/2) * -ln(1e4)/(dim/2-1)).  The
+ * reference evaluates this float32 exp with torch on its own device and its outputs depend on that at the 4e-5 level over
+ * a 50-step chain (1 ulp of a frequency x t <= 999), so the table is the caller's: pass what torch computes on the host
+ * (pointreggpt_amd.unet does).  Default: this host's libm.  Call before creating samplers on the handle.            */
+int prg_unet_set_time_freqs(prg_unet* h, const float* freqs, int n);
 /* Pre-size the activation workspace for (B, S) so later forwards never allocate.                          */
 int prg_unet_reserve(prg_unet* h, int B, int S);
 

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "prg_unet_create": (C.c_int, [C.POINTER(UnetConfigC), _P, _L, _I, C.POINTER(_P)]),
     "prg_unet_destroy": (C.c_int, [_P]),
     "prg_unet_reserve": (C.c_int, [_P, _I, _I]),
+    "prg_unet_set_time_freqs": (C.c_int, [_P, _P, _I]),
     "prg_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "prg_maskunet_forward": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "prg_unet_set_taps": (C.c_int, [_P, _I]),

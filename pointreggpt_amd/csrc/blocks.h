@@ -76,8 +76,8 @@ enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
 int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, int woff, const float* bias, float* y,
                   int ldy, int R, int I, int O, int act_in, int act_out, hipStream_t s);
 // sinusoidal embedding (sd:645-657): t (R,) int64 -> (R, dim) float32
-int launch_sinusoidal(const int64_t* t, float* out, int R, int dim, hipStream_t s);
-int launch_sinusoidal_i32(const int32_t* t, float* out, int R, int dim, hipStream_t s);
+int launch_sinusoidal(const int64_t* t, const float* freqs, float* out, int R, int dim, hipStream_t s);
+int launch_sinusoidal_i32(const int32_t* t, const float* freqs, float* out, int R, int dim, hipStream_t s);
 
 // float32 NCHW <- T NHWC (debug taps)
 template <typename T>

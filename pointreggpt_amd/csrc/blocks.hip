@@ -732,28 +732,31 @@ int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, in
   return PRG_OK;
 }
 
+// freqs[i] = exp(-i ln(1e4) / (half - 1)) comes from the HOST (prg_unet_set_time_freqs): the reference evaluates that
+// float32 exp with torch on whatever device it runs on, and a 1-ulp difference in a frequency, multiplied by t <= 999,
+// moves every time embedding by up to 6e-5 — enough to shift a 50-step chain by 4e-5 (measured: the same reference code on
+// two CPUs).  Taking the table as data keeps this library on the caller's side of that dependence.
 template <typename TI>
-__global__ void sinusoidal_kernel(const TI* __restrict__ t, float* __restrict__ out, int R, int dim) {
+__global__ void sinusoidal_kernel(const TI* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int R,
+                                  int dim) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int half = dim / 2;
   if (idx >= R * half) return;
   const int r = idx / half, i = idx - r * half;
-  const float step = -(float)(9.210340371976184 / (double)(half - 1));  // -ln(1e4)/(half-1), rounded to f32 like torch
-  const float f = expf((float)i * step);
-  const float a = (float)t[r] * f;
+  const float a = (float)t[r] * freqs[i];
   out[(size_t)r * dim + i] = sinf(a);
   out[(size_t)r * dim + half + i] = cosf(a);
 }
 
-int launch_sinusoidal(const int64_t* t, float* out, int R, int dim, hipStream_t s) {
-  PRG_CHECK(t && out && R > 0 && dim >= 4 && dim % 2 == 0, "sinusoidal: bad arguments");
-  sinusoidal_kernel<int64_t><<<ceil_div(R * (dim / 2), 256), 256, 0, s>>>(t, out, R, dim);
+int launch_sinusoidal(const int64_t* t, const float* freqs, float* out, int R, int dim, hipStream_t s) {
+  PRG_CHECK(t && freqs && out && R > 0 && dim >= 4 && dim % 2 == 0, "sinusoidal: bad arguments");
+  sinusoidal_kernel<int64_t><<<ceil_div(R * (dim / 2), 256), 256, 0, s>>>(t, freqs, out, R, dim);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
-int launch_sinusoidal_i32(const int32_t* t, float* out, int R, int dim, hipStream_t s) {
-  PRG_CHECK(t && out && R > 0 && dim >= 4 && dim % 2 == 0, "sinusoidal: bad arguments");
-  sinusoidal_kernel<int32_t><<<ceil_div(R * (dim / 2), 256), 256, 0, s>>>(t, out, R, dim);
+int launch_sinusoidal_i32(const int32_t* t, const float* freqs, float* out, int R, int dim, hipStream_t s) {
+  PRG_CHECK(t && freqs && out && R > 0 && dim >= 4 && dim % 2 == 0, "sinusoidal: bad arguments");
+  sinusoidal_kernel<int32_t><<<ceil_div(R * (dim / 2), 256), 256, 0, s>>>(t, freqs, out, R, dim);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }

@@ -231,6 +231,7 @@ struct prg_unet {
   bf16_t* d_stem_frag = nullptr; // stem weights as MFMA fragments (bf16 path, Cin 1 -> 64)
   bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
   float* d_kshift = nullptr;    // fused linear attention: static softmax shifts of the k columns
+  float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
   Arena arena;
   uint64_t arena_gen = 0;       // bumped whenever the workspace is reallocated: captured graphs bake its pointers in
   int resB = 0, resS = 0;
@@ -564,7 +565,7 @@ struct UnetImpl : prg_unet {
     float* h2 = cat + (size_t)B * 2 * e;      // [B][e]
     float* ss = h2 + (size_t)B * e;           // [B][ss_total]
     int rc;
-    if ((rc = launch_sinusoidal(time, sinu, B, d0, s))) return rc;
+    if ((rc = launch_sinusoidal(time, d_freqs, sinu, B, d0, s))) return rc;
     if ((rc = launch_linear(sinu, d0, 0, F(L.tm1_w), d0, 0, F(L.tm1_b), h1, e, B, d0, e, ACT_NONE, ACT_GELU, s))) return rc;
     if ((rc = launch_linear(h1, e, 0, F(L.tm3_w), e, 0, F(L.tm3_b), cat, 2 * e, B, e, e, ACT_NONE, ACT_NONE, s))) return rc;
     const int pc = L.cfg.param_cond_dim;
@@ -658,6 +659,16 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
   PRG_HIP(hipMemcpy(u->d_flat, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   PRG_HIP(hipMemcpy(u->d_packed, packed.data(), packed.size() * sizeof(T), hipMemcpyHostToDevice));
   PRG_HIP(hipMemcpy(u->d_stem, stem.data(), stem.size() * sizeof(float), hipMemcpyHostToDevice));
+  {
+    // default frequency table: the reference's expression in float32 with this host's libm (the Python front-end
+    // replaces it with torch's own evaluation, which is what the reference would compute on the same host)
+    const int half = L.cfg.dim / 2;
+    std::vector<float> fr(half);
+    const float stepf = -(float)(9.210340371976184 / (double)(half - 1));
+    for (int i = 0; i < half; ++i) fr[i] = std::exp((float)i * stepf);
+    if (hipMalloc(&u->d_freqs, half * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(time frequencies)");
+    PRG_HIP(hipMemcpy(u->d_freqs, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  }
   if (std::is_same<T, bf16_t>::value && L.cfg.in_channels == 1 && L.cfg.dim == 64) {
     std::vector<bf16_t> sf;
     pack_stem_mfma_weights(weights + L.stem_w, sf);
@@ -865,9 +876,18 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_stem) hipFree(h->d_stem);
   if (h->d_attn) hipFree(h->d_attn);
   if (h->d_kshift) hipFree(h->d_kshift);
+  if (h->d_freqs) hipFree(h->d_freqs);
   if (h->d_stem_frag) hipFree(h->d_stem_frag);
   if (h->arena.base) hipFree(h->arena.base);
   delete h;
+  return PRG_OK;
+}
+
+int prg_unet_set_time_freqs(prg_unet* h, const float* freqs, int n) {
+  PRG_CHECK(h && freqs, "prg_unet_set_time_freqs: null pointer");
+  PRG_CHECK(n == h->lay.cfg.dim / 2, "prg_unet_set_time_freqs: need dim/2 frequencies");
+  PRG_HIP(hipDeviceSynchronize());
+  PRG_HIP(hipMemcpy(h->d_freqs, freqs, sizeof(float) * n, hipMemcpyHostToDevice));
   return PRG_OK;
 }
 
@@ -960,7 +980,7 @@ int prg_sampler_create(prg_unet* unet, const prg_step* steps, int n_steps, int B
     for (int k = 0; k < n_steps; ++k) tt[k] = steps[k].t;
     PRG_HIP(hipMemcpyAsync(tdev, tt.data(), sizeof(int32_t) * n_steps, hipMemcpyHostToDevice, s));
     const float* F = unet->d_flat;
-    if ((rc = launch_sinusoidal_i32(tdev, sinu, n_steps, d0, s))) return rc;
+    if ((rc = launch_sinusoidal_i32(tdev, unet->d_freqs, sinu, n_steps, d0, s))) return rc;
     if ((rc = launch_linear(sinu, d0, 0, F + L.tm1_w, d0, 0, F + L.tm1_b, h1, e, n_steps, d0, e, ACT_NONE, ACT_GELU, s))) return rc;
     if ((rc = launch_linear(h1, e, 0, F + L.tm3_w, e, 0, F + L.tm3_b, temb, e, n_steps, e, e, ACT_NONE, ACT_NONE, s))) return rc;
     auto one = [&](const ResP& r) -> int {

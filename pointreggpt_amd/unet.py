@@ -56,6 +56,7 @@ class _HipNet:
         # objects holding library handles that point INTO this network's handle (samplers: captured graphs bake in its
         # weight and workspace pointers); they are closed before the handle is destroyed
         self._dependents: "weakref.WeakSet" = weakref.WeakSet()
+        self._freqs = None
         self.channels = cfg.in_channels if cfg.conditional else 1
         self.out_dim = cfg.out_channels
         self.random_or_learned_sinusoidal_cond = False   # asserted off by GaussianDiffusion (sd:1034)
@@ -74,6 +75,27 @@ class _HipNet:
         _lib.check(lib.prg_unet_create(C.byref(cc), flat.ctypes.data_as(C.c_void_p), flat.size, _DTYPES[self.dtype],
                                        C.byref(h)), "prg_unet_create")
         self._h = h
+        if self.cfg.conditional:
+            self.set_time_freqs(self._freqs)
+        return self
+
+    def set_time_freqs(self, freqs=None):
+        """SinusoidalPosEmb's frequency table (sd:645-657).  Default = the reference's own expression evaluated by torch on
+        this host, i.e. what the reference would use here; pass the table of another host to reproduce results made
+        there (the reference's outputs depend on this float32 exp at the 4e-5 level over a 50-step chain)."""
+        import math
+        half = self.cfg.dim // 2
+        if freqs is None:
+            freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+        f = np.ascontiguousarray(np.asarray(freqs, dtype=np.float32).reshape(-1))
+        if f.size != half:
+            raise ValueError(f"need {half} frequencies")
+        self._freqs = f
+        if self._h is not None:
+            for dep in list(self._dependents):
+                dep.close()          # samplers bake the time table built from the old frequencies
+            _lib.check(_lib.load().prg_unet_set_time_freqs(self._h, f.ctypes.data_as(C.c_void_p), int(f.size)),
+                       "prg_unet_set_time_freqs")
         return self
 
     def init_synthetic(self, seed: int = 0, **kw):

@@ -273,3 +273,15 @@ def test_G18_refine_step_occlusion_filter_random_transform(golden):
         np.random.seed(s_)
         assert np.array_equal(OG.random_sample_transform(g["rst_K"], 64), g[f"rst_seed{s_}"])
         assert np.array_equal(np.random.rand(2), g[f"rst_after_seed{s_}"])
+
+
+def test_G0_host_tables_are_this_hosts():
+    """The SinusoidalPosEmb frequency table of the fixtures' host (the reference's float32 torch.exp, sd:645-657): the CPU
+    tests run on that host, so torch reproduces it bit for bit here; the GPU tests hand it to the library explicitly."""
+    import math
+    g = dict(np.load(os.path.join(GOLDEN, "G0_host_tables.npz")))
+    for dim in (8, 16, 64):
+        half = dim // 2
+        f = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+        assert np.array_equal(f.numpy(), g[f"freqs_dim{dim}"])
+        assert np.array_equal(OU.sinusoidal(torch.tensor([999.0]), dim)[0, :half].numpy(), (999.0 * f).sin().numpy())

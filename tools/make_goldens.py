@@ -449,6 +449,37 @@ def g18_refine_and_tester():
     save("G18_refine_occlusion_transform", **out)
 
 
+def g0_host_tables():
+    """Float32 tables the reference evaluates with torch on ITS host and whose last bit matters downstream: the
+    SinusoidalPosEmb frequencies (sd:645-657).  A 1-ulp difference in a frequency times t <= 999 moves every time
+    embedding by up to 6e-5; the same reference code on two CPUs ends a 50-step chain 4.5e-5 apart (tools/chain_budget.py).
+    The fixtures below were produced with THESE tables; the GPU tests hand them to the library (prg_unet_set_time_freqs)."""
+    import math
+    out = {}
+    for dim in (8, 16, 64):
+        half = dim // 2
+        f = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+        emb = sd.SinusoidalPosEmb(dim)(torch.tensor([1.0, 999.0]))
+        assert torch.equal(emb[:, :half], (torch.tensor([1.0, 999.0])[:, None] * f[None, :]).sin())
+        out[f"freqs_dim{dim}"] = f
+    # DDIM coefficients (sd:1357-1368): sigma = eta sqrt((1 - a/a')(1 - a')/(1 - a)), c = sqrt(1 - a' - sigma^2) are float32
+    # expressions with cancellation; two x86 hosts disagree by 8.7e-6 (relative) on c of the FIRST transition, which is
+    # 3.4e-5 in the state at once (tools/_dump_chain.py).  The product evaluates them with torch on ITS host exactly as the
+    # reference does; comparisons with these fixtures need the values of the host that made them.
+    from pointreggpt_amd.diffusion import GaussianDiffusion
+
+    class _Net:
+        channels = out_dim = 1
+        random_or_learned_sinusoidal_cond = False
+
+    for steps in (5, 50, 250):
+        rows = GaussianDiffusion(_Net(), image_size=32, timesteps=1000, sampling_timesteps=steps).step_table()
+        out[f"ddim{steps}_rows"] = np.array([[r["c_x0"], r["c_x"], r["c_eps"], r["sigma"], r["sqrt_recip"], r["sqrt_recipm1"]]
+                                             for r in rows], dtype=np.float32)
+        out[f"ddim{steps}_t"] = np.array([r["t"] for r in rows], dtype=np.int32)
+    save("G0_host_tables", **out)
+
+
 def g12b_envelope():
     """Noise floor of the parity metric on the G12 chain (64x64, 50-step DDIM, dim 64): the reference against (a) itself
     with one thread instead of eight (another oneDNN blocking: another summation order) and (b) exact arithmetic."""
@@ -501,7 +532,7 @@ def spec_fixture():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
-    jobs = [("g1", g1_schedule), ("g2", g2_intrinsics), ("g3", g3_pose), ("g4", g4_pc2depth), ("g5", g5_g6_reproject),
+    jobs = [("g0", g0_host_tables), ("g1", g1_schedule), ("g2", g2_intrinsics), ("g3", g3_pose), ("g4", g4_pc2depth), ("g5", g5_g6_reproject),
             ("g7", g7_unet_taps), ("g8", g8_unet_full), ("g9", g9_g10_sampler), ("g11", g11_maskunet),
             ("g12", g12_end_to_end), ("g12b", g12b_envelope), ("g13", g13_unet_128), ("g14", g14_chain_128),
             ("g15", g15_maskunet_128), ("g16", g16_unet_256), ("g17", g17_ddim_cond_gt1), ("g18", g18_refine_and_tester), ("spec", spec_fixture)]
