@@ -618,7 +618,11 @@ static int launch_igemm(const ConvLaunch<T>& L, int M, hipStream_t s, int want_s
 }
 
 int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_ws.hip
-static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n) { return try_launch_conv3x3_ws(L, s, n); }
+int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);  // conv_c64.hip
+static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n) {
+  const int r = try_launch_conv3x3_c64(L, s, n);            // weights-stationary kernel for the 64 -> 64 convs
+  return r != 0 ? r : try_launch_conv3x3_ws(L, s, n);
+}
 static inline int try_ws(const ConvLaunch<float>&, hipStream_t, int*) { return 0; }
 
 template <typename T>

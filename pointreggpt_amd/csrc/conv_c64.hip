@@ -1,0 +1,364 @@
+// conv_c64.hip — weights-stationary 3x3 convolution for Cin = Cout = 64 (bf16 throughput path).
+//
+// The 64 -> 64 convs of the two full-resolution levels (down0/down1 blocks, the second conv of every up3 / final block,
+// the last up conv) are the ones the wave-specialised kernel (conv_ws.hip) handles worst: one 64-channel chunk means a
+// tile is finished after nine taps, so per 4608 MFMA cycles it re-stages the whole 72 KB weight set through LDS, meets
+// nine workgroup barriers and pays one epilogue — 0.25-0.33 of the MFMA peak, while the shape itself is HBM-bound
+// (256 B of activations per pixel against 73.7 kFLOP: 49 us of HBM time, 31 us of MFMA time at B = 64, 128 x 128).
+//
+// Here the weights never touch LDS again after the prologue: a consumer wave owns 32 output channels and keeps their
+// 9 x 64 weights as 36 MFMA A-fragments in registers (144 VGPRs) for the whole launch; its B operands are the pixels of
+// a 128-pixel half tile read from the halo (16 ds_read_b128 per 16 MFMAs, as before, but no weight reads, no weight
+// ring, no per-tap barrier).  The workgroup (512 threads, 256 registers per lane) is
+//
+//   waves 0-3  CONSUMERS (2 pixel halves x 2 channel halves of a 8 x 32 pixel x 64 channel tile): 144 MFMAs per tile,
+//              fragments prefetched one call ahead; epilogue = bias, bf16, LDS stage, GroupNorm partial sums (the
+//              deterministic butterfly of conv_ws.hip);
+//   waves 4-7  PRODUCERS: write halo s+1 (loaded a whole step earlier; optional fused GroupNorm + (scale+1, shift) + SiLU
+//              prologue of the previous Block, sd:690-696), re-issue the registers for halo s+2, drain the finished tile
+//              from the stage to HBM in 128-byte rows.  A step is ~5000 cycles, so plain loads with compiler-managed waits
+//              are enough: every load has a full step to land.
+//
+// Two barriers per tile: (1) "stage drained" before the consumers' epilogue, (2) "halo s+1 written, stage s written".
+// LDS: 2 halos x 340 rows x 144 B (padded rows: conflict-free ds_read_b128 with immediate tap offsets) + 32 KB stage.
+#include <cstdlib>
+
+#include "conv.h"
+
+namespace prg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 c64_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float c64_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int c64_u32x4;
+
+namespace {
+
+constexpr int TH = 8, TW = 32, HP = TW + 2, HALO = (TH + 2) * HP;   // 340 halo rows
+constexpr int ROWB = 144;                                              // padded LDS row (64 bf16 = 128 B + 16)
+constexpr size_t AH_BYTES = (size_t)HALO * ROWB;
+constexpr size_t STG_BYTES = 4 * 128 * 64;                             // per consumer wave: 128 pixels x 32 channels bf16
+constexpr size_t C64_LDS = 2 * AH_BYTES + STG_BYTES;
+constexpr int NPT = 256;                                               // producer threads
+constexpr int RPP = NPT / 8;                                           // halo rows per pass
+constexpr int KU = (HALO + RPP - 1) / RPP;                             // 11 units per producer thread
+
+__device__ inline float c64_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ inline float c64_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ inline uint32_t c64_pack(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ inline float c64_silu(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+template <int CTRL>
+__device__ inline float c64_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int XOR>
+__device__ inline float c64_swz(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1F));
+}
+
+// tile t of this workgroup: XCD-contiguous runs (workgroup b runs on XCD b % 8; speed only), image-major
+__device__ inline void c64_tile(int t, int tiles_x, int tiles_y, int& b, int& y0, int& x0) {
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  b = t / tiles_y;
+  y0 = ty * TH;
+  x0 = tx * TW;
+}
+
+// one LDS-visibility point: this wave's LDS operations are done, then the workgroup barrier.  Never waits for VMEM: the
+// producers' halo loads and drain stores stay in flight across it.
+__device__ __forceinline__ void c64_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool PRO>
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
+                                                          const int fuse_stats) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const stage = smem + 2 * AH_BYTES;
+  const ConvDesc& d = L.d;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int total = tiles_x * tiles_y * d.B;
+  // XCD-contiguous tile runs (gridDim.x is a multiple of 8): XCD x owns tiles [x per, (x+1) per), its workgroups interleave
+  const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  const int per = (total + 7) / 8;
+  const int first = xcd * per + widx;
+  const int hi_t = min((xcd + 1) * per, total);
+  const int nsteps = first < hi_t ? (hi_t - first + stride - 1) / stride : 0;
+  if (nsteps == 0) return;
+
+  // ---------------------------------------------------------------------------------------------------
+  if (wave < 4) {
+    __builtin_amdgcn_s_setprio(3);
+    const int wm = wave >> 1, wn = wave & 1;              // pixel half (tile rows 4 wm .. 4 wm + 3), channel half
+    const int l31 = lane & 31, hi = lane >> 5;
+    // weights of channel wn*32 + l31: 9 taps x 4 k-steps; lane half hi takes k = 16 c + 8 hi .. + 7
+    c64_bf16x8 wf[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16_t* p = L.w + ((size_t)(tap * d.kchunks + (c >> 1)) * d.CoutPad + wn * 32 + l31) * 32 + (c & 1) * 16 + hi * 8;
+        wf[tap][c] = *reinterpret_cast<const c64_bf16x8*>(p);
+      }
+    const float* const biasp = L.bias + wn * 32 + 4 * hi;
+    const int gn_per = fuse_stats ? (64 / L.gn_groups) >> 3 : 1;   // 8-channel chunks per group (1, 2, 4 or 8)
+    // LDS byte offset of pixel (row 4 wm + pt, column l31), tap (0,0), k-step 0: rows are HP * ROWB apart
+    const unsigned x0off = (unsigned)(((wm * 4) * HP + l31) * ROWB + hi * 16);
+    char* const stg = stage + wave * (128 * 64);
+    c64_barrier();                                         // halo 0 is in LDS (producers' prologue)
+    for (int s = 0; s < nsteps; ++s) {
+      const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
+      c64_f32x16 acc[4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pt][e] = 0.0f;
+      c64_bf16x8 fx[2][4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) fx[0][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int cur = (tap * 4 + c) & 1, nxt = cur ^ 1;
+          const int ntap = c == 3 ? tap + 1 : tap, nc = c == 3 ? 0 : c + 1;   // the call after this one
+          if (ntap < 9) {
+            const int toff = ((ntap / 3) * HP + (ntap % 3)) * ROWB + nc * 32;
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+              fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+              acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+              acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+          }
+        }
+      }
+      // ---- epilogue: lane holds pixel (row 4 wm + pt, col l31), channels wn*32 + 8 q + 4 hi + {0..3}
+      int tb, ty0, tx0;
+      c64_tile(first + s * stride, tiles_x, tiles_y, tb, ty0, tx0);
+      c64_barrier();                                       // (1) the producers have drained the previous tile's stage
+      float V[8];                                          // [sum | sumsq][q]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[pt][4 * q + r] + bv[r];
+            sm += v[r];
+            sq = fmaf(v[r], v[r], sq);
+          }
+          uint2 w;
+          w.x = c64_pack(v[0], v[1]);
+          w.y = c64_pack(v[2], v[3]);
+          // stage row = pixel pt*32 + l31 (64 B = 32 channels), 16-byte unit q (XOR-swizzled by the row), half hi
+          const int px = pt * 32 + l31;
+          *reinterpret_cast<uint2*>(stg + px * 64 + ((q ^ ((px >> 1) & 3)) << 4) + hi * 8) = w;
+        }
+        V[q] = sm;
+        V[4 + q] = sq;
+      }
+      if (fuse_stats) {
+        // 8 full-wave sums with a halving butterfly (conv_ws.hip's, one level shorter): fixed order, deterministic
+        const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+        float A4[4], B2[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A4[j] = (b0 ? V[4 + j] : V[j]) + c64_dpp<0xB1>(b0 ? V[j] : V[4 + j]);        // lane ^ 1
+#pragma unroll
+        for (int j = 0; j < 2; ++j) B2[j] = (b1 ? A4[2 + j] : A4[j]) + c64_dpp<0x4E>(b1 ? A4[j] : A4[2 + j]);    // lane ^ 2
+        float D = (b2 ? B2[1] : B2[0]) + c64_swz<4>(b2 ? B2[0] : B2[1]);
+        D += c64_swz<8>(D);
+        D += c64_swz<16>(D);
+        D += __shfl_xor(D, 32, 64);
+        // lane (< 8) holds the wave total of value i = 4 b0 + 2 b1 + b2 = [sq][q]: 8-channel chunk q of this wave's 32
+        // channels.  Fold the chunks of one group (per = cpg / 8 <= 4 inside a wave; 8 = both channel halves: two slabs).
+        const int per = gn_per > 4 ? 4 : gn_per;
+        if (per >= 2) D += c64_swz<4>(D);                  // q ^ 1  (lane bit 2)
+        if (per >= 4) D += c64_dpp<0x4E>(D);               // q ^ 2  (lane bit 1)
+        const int i = (lane & 1) * 4 + (lane & 2) + ((lane >> 2) & 1);
+        const int q = i & 3;
+        if (lane < 8 && (q & (per - 1)) == 0) {
+          const int split_n = gn_per > 4 ? 2 : 1;
+          const int nsplit = tiles_x * tiles_y * 2 * split_n;
+          const int slab = (((ty0 / TH) * tiles_x + tx0 / TW) * 2 + wm) * split_n + (split_n == 2 ? wn : 0);
+          const int grp = (wn * 4 + q) / gn_per;
+          L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 2)] = D;
+        }
+      }
+      c64_barrier();                                       // (2) stage written; halo s+1 written by the producers
+    }
+    c64_barrier();                                         // matches the producers' final barrier
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  {
+    const int ptid = tid - 256;
+    const int slot = ptid & 7, row = ptid >> 3;           // 16-byte unit of a 128-byte pixel row; halo rows row + 32 k
+    char* const ah = smem + row * ROWB + slot * 16;
+    const int Hl = d.Hout, Wl = d.Wout;
+    int hy[KU], hx[KU];                                    // tile-independent halo geometry of this thread's units
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int hp = k * RPP + row;
+      hy[k] = hp / HP;
+      hx[k] = hp - hy[k] * HP;
+    }
+    c64_u32x4 hreg[KU];
+    unsigned okmask = 0, okmask_nxt = 0;
+    float4 ca[2], cb[2], ca_n[2], cb_n[2];
+    auto issue = [&](int s) {                              // loads of halo s into hreg
+      int b, y0, x0;
+      c64_tile(first + s * stride, tiles_x, tiles_y, b, y0, x0);
+      okmask_nxt = 0;
+      const bf16_t* src = L.src0 + (size_t)b * d.Hin * d.Win * 64 + slot * 8;
+      const int yd = y0 >> d.ups, xd = x0 >> d.ups;        // the tile origin: always mapped (stand-in for padding taps)
+#pragma unroll
+      for (int k = 0; k < KU; ++k) {
+        const int hp = k * RPP + row;
+        int y = y0 - 1 + hy[k], x = x0 - 1 + hx[k];
+        const bool ok = hp < HALO && (unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl;
+        y >>= d.ups;
+        x >>= d.ups;
+        y = ok ? y : yd;                                   // every load is issued unconditionally (no branch per unit)
+        x = ok ? x : xd;
+        hreg[k] = *reinterpret_cast<const c64_u32x4*>(src + ((size_t)y * d.Win + x) * 64);
+        okmask_nxt |= (ok ? 1u : 0u) << k;
+      }
+      if constexpr (PRO) {
+        const float* pa = L.pro_a + (size_t)b * 64 + slot * 8;
+        const float* pb = L.pro_b + (size_t)b * 64 + slot * 8;
+        ca_n[0] = *reinterpret_cast<const float4*>(pa);
+        ca_n[1] = *reinterpret_cast<const float4*>(pa + 4);
+        cb_n[0] = *reinterpret_cast<const float4*>(pb);
+        cb_n[1] = *reinterpret_cast<const float4*>(pb + 4);
+      }
+    };
+    auto write = [&](int s) {                              // hreg (halo s) -> LDS buffer s & 1
+      char* dst = ah + (size_t)(s & 1) * AH_BYTES;
+      const float a8[8] = {ca[0].x, ca[0].y, ca[0].z, ca[0].w, ca[1].x, ca[1].y, ca[1].z, ca[1].w};
+      const float b8[8] = {cb[0].x, cb[0].y, cb[0].z, cb[0].w, cb[1].x, cb[1].y, cb[1].z, cb[1].w};
+#pragma unroll
+      for (int k = 0; k < KU; ++k) {
+        const int hp = k * RPP + row;
+        if (hp < HALO) {
+          c64_u32x4 v = hreg[k];
+          if constexpr (PRO) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float lo = c64_silu(fmaf(c64_lo(v[j]), a8[2 * j], b8[2 * j]));
+              const float hh = c64_silu(fmaf(c64_hi(v[j]), a8[2 * j + 1], b8[2 * j + 1]));
+              v[j] = c64_pack(lo, hh);
+            }
+          }
+          if (!((okmask >> k) & 1u)) v = c64_u32x4{0u, 0u, 0u, 0u};
+          *reinterpret_cast<c64_u32x4*>(dst + k * RPP * ROWB) = v;
+        }
+      }
+    };
+    auto drain = [&](int s) {                              // stage (tile s) -> HBM: 8 lanes write one pixel's 128 bytes
+      int b, y0, x0;
+      c64_tile(first + s * stride, tiles_x, tiles_y, b, y0, x0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = ptid + 256 * j;                       // 2048 units: [wm][pixel 0..127][wn][unit q]
+        const int wm = u >> 10, px = (u >> 3) & 127, wn = (u >> 2) & 1, q = u & 3;
+        const c64_u32x4 v =
+            *reinterpret_cast<const c64_u32x4*>(stage + (wm * 2 + wn) * (128 * 64) + px * 64 + ((q ^ ((px >> 1) & 3)) << 4));
+        const int y = y0 + wm * 4 + (px >> 5), x = x0 + (px & 31);
+        *reinterpret_cast<c64_u32x4*>(L.out + (((size_t)b * Hl + y) * Wl + x) * 64 + wn * 32 + q * 8) = v;
+      }
+    };
+    auto adopt = [&]() {
+      okmask = okmask_nxt;
+      if constexpr (PRO) {
+        ca[0] = ca_n[0]; ca[1] = ca_n[1]; cb[0] = cb_n[0]; cb[1] = cb_n[1];
+      }
+    };
+    issue(0);
+    adopt();
+    write(0);
+    if (nsteps > 1) issue(1);
+    c64_barrier();                                         // halo 0 ready
+    for (int s = 0; s < nsteps; ++s) {
+      // during the consumers' MFMAs of step s: halo s+1 into the buffer they left before barrier (1) of step s-1,
+      // the loads of halo s+2, and the drain of tile s-1 (in the stage since barrier (2) of step s-1)
+      if (s + 1 < nsteps) {
+        adopt();
+        write(s + 1);
+        if (s + 2 < nsteps) issue(s + 2);
+      }
+      if (s > 0) drain(s - 1);
+      c64_barrier();                                       // (1) stage free
+      c64_barrier();                                       // (2)
+    }
+    drain(nsteps - 1);
+    c64_barrier();
+  }
+}
+
+}  // namespace
+
+// Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
+int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+  static const int enabled = [] {
+    const char* e = std::getenv("PRG_CONV_C64");
+    return e ? std::atoi(e) : 1;
+  }();
+  if (!enabled) return 0;
+  const ConvDesc& d = L.d;
+  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
+  if (d.C0 != 64 || d.C1 != 0 || d.Cout != 64 || d.CoutPad != 64 || d.kchunks != 2) return 0;
+  if (L.residual || !L.bias) return 0;
+  if (d.Wout % TW || d.Hout % TH) return 0;
+  const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH;
+  const int total = tiles_x * tiles_y * d.B;
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    num_cus = p.multiProcessorCount;
+  }
+  int grid = (total < num_cus ? total : num_cus) & ~7;       // multiple of 8: XCD-contiguous tile runs
+  if (grid < 8) return 0;                                    // tiny launches stay on the generic kernels
+  const int cpg = L.gn_groups > 0 ? 64 / L.gn_groups : 0;
+  const int split_n = cpg > 32 ? 2 : 1;
+  int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
+             tiles_x * tiles_y * 2 * split_n <= kGnMaxSplit;
+  if (L.gn_partials && !fuse) return 0;
+  static bool attr_done[2] = {false, false};
+  const int pro = L.pro_a ? 1 : 0;
+  if (!attr_done[pro]) {
+    hipError_t e = pro ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS)
+                       : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS);
+    if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(c64 conv): ") + hipGetErrorString(e));
+    attr_done[pro] = true;
+  }
+  if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 * split_n : 0;
+  if (pro) conv3x3_c64_kernel<true><<<dim3(grid), 512, C64_LDS, s>>>(L, tiles_x, tiles_y, fuse);
+  else conv3x3_c64_kernel<false><<<dim3(grid), 512, C64_LDS, s>>>(L, tiles_x, tiles_y, fuse);
+  PRG_LAUNCH_CHECK();
+  return 1;
+}
+
+}  // namespace prg

@@ -126,7 +126,7 @@ def depth2pc_tensor(depth: torch.Tensor, intrinsic: torch.Tensor, *, clip=(0, 10
     inv = float("nan") if invalid_num is None else float(invalid_num)
     _lib.check(lib.prg_depth2pc(_lib.ptr(depth), _lib.ptr(K), _lib.ptr(pc), _lib.ptr(valid), B, H, W, lo, hi, inv,
                                 _lib.stream_ptr()), "prg_depth2pc")
-    return pc, valid.to(torch.bool)
+    return pc, valid.view(torch.bool)
 
 
 def pc2depth_tensor(pc: torch.Tensor, valid: Optional[torch.Tensor], intrinsic: torch.Tensor, *,
@@ -136,12 +136,12 @@ def pc2depth_tensor(pc: torch.Tensor, valid: Optional[torch.Tensor], intrinsic: 
     pc, K = _f32(pc), _f32(intrinsic)
     B, N, _ = pc.shape
     H, W = int(image_size[0]), int(image_size[1])
-    v8 = None if valid is None else valid.contiguous().to(torch.uint8)
+    v8 = None if valid is None else valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.contiguous().to(torch.uint8)
     depth = torch.empty((B, 1, H, W), dtype=torch.float32, device=pc.device)
     mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=pc.device)
     _lib.check(lib.prg_pc2depth(_lib.ptr(pc), _lib.ptr(v8), _lib.ptr(K), _lib.ptr(depth), _lib.ptr(mask), B, N, H, W,
                                 _lib.stream_ptr()), "prg_pc2depth")
-    return depth, mask.to(torch.bool)
+    return depth, mask.view(torch.bool)
 
 
 def reproject_tensor(depth: torch.Tensor, intrinsic: torch.Tensor, relative_pose: torch.Tensor, *, clip=(0, 10),
@@ -158,7 +158,7 @@ def reproject_tensor(depth: torch.Tensor, intrinsic: torch.Tensor, relative_pose
     _lib.check(lib.prg_reproject_zbuffer(_lib.ptr(depth), _lib.ptr(K), _lib.ptr(P), _lib.ptr(out), _lib.ptr(mask), B,
                                          H, W, float(depth_unit), float(clip[0]), float(clip[1]), float(out_scale),
                                          _lib.stream_ptr()), "prg_reproject_zbuffer")
-    return out, mask.to(torch.bool)
+    return out, mask.view(torch.bool)
 
 
 def project_clouds(clouds: Sequence[np.ndarray], poses: np.ndarray, intrinsic: np.ndarray, image_size: int,
@@ -180,7 +180,7 @@ def project_clouds(clouds: Sequence[np.ndarray], poses: np.ndarray, intrinsic: n
     _lib.check(lib.prg_project_points_zbuffer(_lib.ptr(pts), _lib.ptr(d_offs), _lib.ptr(P), _lib.ptr(K), _lib.ptr(depth),
                                               _lib.ptr(mask), B, S, S, float(depth_scale), _lib.stream_ptr()),
                "prg_project_points_zbuffer")
-    return depth, mask.to(torch.bool)
+    return depth, mask.view(torch.bool)
 
 
 def unproject_f64(depth: torch.Tensor, intrinsic: torch.Tensor, pose: Optional[torch.Tensor], *,
@@ -195,7 +195,7 @@ def unproject_f64(depth: torch.Tensor, intrinsic: torch.Tensor, pose: Optional[t
     _lib.check(lib.prg_unproject_f64(_lib.ptr(depth), _lib.ptr(K), _lib.ptr(P), _lib.ptr(xyz), _lib.ptr(valid), B, H, W,
                                      float(depth_unit), float(clip[0]), float(clip[1]), _lib.stream_ptr()),
                "prg_unproject_f64")
-    return xyz, valid.to(torch.bool)
+    return xyz, valid.view(torch.bool)
 
 
 def point_clouds(depth: torch.Tensor, intrinsic: torch.Tensor, pose: Optional[torch.Tensor] = None, *,
@@ -223,13 +223,13 @@ def apply_mask(prob: torch.Tensor, depth: torch.Tensor, hit: Optional[torch.Tens
     lib = _lib.load()
     prob, depth = _f32(prob), _f32(depth)
     B, _, H, W = depth.shape
-    h8 = None if hit is None else hit.contiguous().to(torch.uint8)
+    h8 = None if hit is None else (hit.contiguous().view(torch.uint8) if hit.dtype == torch.bool else hit.contiguous().to(torch.uint8))
     d_out = torch.empty_like(depth)
     h_out = torch.empty((B, 1, H, W), dtype=torch.uint8, device=depth.device)
     cond = torch.empty((B, 2, H, W), dtype=torch.float32, device=depth.device) if want_cond else None
     _lib.check(lib.prg_apply_mask(_lib.ptr(prob), _lib.ptr(depth), _lib.ptr(h8), float(threshold), _lib.ptr(d_out),
                                   _lib.ptr(h_out), _lib.ptr(cond), B, H, W, _lib.stream_ptr()), "prg_apply_mask")
-    return d_out, h_out.to(torch.bool), cond
+    return d_out, h_out.view(torch.bool), cond
 
 
 def occlusion_filter(depth_rpj: torch.Tensor, mask_rpj: torch.Tensor, threshold: float = 0.0375):
@@ -238,7 +238,7 @@ def occlusion_filter(depth_rpj: torch.Tensor, mask_rpj: torch.Tensor, threshold:
     lib = _lib.load()
     depth = _f32(depth_rpj)
     B, _, H, W = depth.shape
-    m8 = mask_rpj.contiguous().to(torch.uint8)
+    m8 = mask_rpj.contiguous().view(torch.uint8) if mask_rpj.dtype == torch.bool else mask_rpj.contiguous().to(torch.uint8)
     out = torch.empty_like(depth)
     _lib.check(lib.prg_occlusion_filter(_lib.ptr(depth), _lib.ptr(m8), _lib.ptr(out), B, H, W, float(threshold),
                                         _lib.stream_ptr()), "prg_occlusion_filter")
