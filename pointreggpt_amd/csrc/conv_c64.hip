@@ -33,6 +33,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int c64_u32x4;
 
 namespace {
 
+// Timing experiments only (results become garbage): -DPRG_C64_EXP=1 consumers skip fragment reads + MFMAs, 2 producers skip
+// the halo loads / writes, 4 no epilogue, 8 no priority raise, 16 producers skip the drain, 32 producers skip only the
+// prologue arithmetic.
+#ifndef PRG_C64_EXP
+#define PRG_C64_EXP 0
+#endif
+
 constexpr int TH = 8, TW = 32, HP = TW + 2, HALO = (TH + 2) * HP;   // 340 halo rows
 constexpr int ROWB = 144;                                              // padded LDS row (64 bf16 = 128 B + 16)
 constexpr size_t AH_BYTES = (size_t)HALO * ROWB;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
 
   // ---------------------------------------------------------------------------------------------------
   if (wave < 4) {
-    __builtin_amdgcn_s_setprio(3);
+    if (!(PRG_C64_EXP & 8)) __builtin_amdgcn_s_setprio(3);
     const int wm = wave >> 1, wn = wave & 1;              // pixel half (tile rows 4 wm .. 4 wm + 3), channel half
     const int l31 = lane & 31, hi = lane >> 5;
     // weights of channel wn*32 + l31: 9 taps x 4 k-steps; lane half hi takes k = 16 c + 8 hi .. + 7
@@ -126,18 +133,34 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) fx[0][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      for (int tap = 0; tap < ((PRG_C64_EXP & 1) ? 0 : 9); ++tap) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int cur = (tap * 4 + c) & 1, nxt = cur ^ 1;
           const int ntap = c == 3 ? tap + 1 : tap, nc = c == 3 ? 0 : c + 1;   // the call after this one
           if (ntap < 9) {
             const int toff = ((ntap / 3) * HP + (ntap % 3)) * ROWB + nc * 32;
+            if constexpr ((PRG_C64_EXP & 64) != 0) {         // variant: the next call's four reads first, then the four MFMAs
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-              fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
-              acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+              for (int pt = 0; pt < 4; ++pt) fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
               __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt)
+                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr ((PRG_C64_EXP & 128) != 0) { // variant: leave the interleave to the compiler
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt) {
+                fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+              }
+            } else {
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt) {
+                fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
           } else {
 #pragma unroll
@@ -150,9 +173,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
       int tb, ty0, tx0;
       c64_tile(first + s * stride, tiles_x, tiles_y, tb, ty0, tx0);
       c64_barrier();                                       // (1) the producers have drained the previous tile's stage
+      if (PRG_C64_EXP & 4) {                               // keep the accumulators live (no dead-code elimination of the MFMAs)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) asm volatile("" ::"v"(acc[pt]));
+      }
       float V[8];                                          // [sum | sumsq][q]
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < ((PRG_C64_EXP & 4) ? 0 : 4); ++q) {
         const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
         const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
         float sm = 0.0f, sq = 0.0f;
@@ -175,7 +202,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         V[q] = sm;
         V[4 + q] = sq;
       }
-      if (fuse_stats) {
+      if (fuse_stats && !(PRG_C64_EXP & 4)) {
         // 8 full-wave sums with a halving butterfly (conv_ws.hip's, one level shorter): fixed order, deterministic
         const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
         float A4[4], B2[2];
@@ -260,7 +287,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         const int hp = k * RPP + row;
         if (hp < HALO) {
           c64_u32x4 v = hreg[k];
-          if constexpr (PRO) {
+          if constexpr (PRO && !(PRG_C64_EXP & 32)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float lo = c64_silu(fmaf(c64_lo(v[j]), a8[2 * j], b8[2 * j]));
@@ -300,12 +327,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     for (int s = 0; s < nsteps; ++s) {
       // during the consumers' MFMAs of step s: halo s+1 into the buffer they left before barrier (1) of step s-1,
       // the loads of halo s+2, and the drain of tile s-1 (in the stage since barrier (2) of step s-1)
-      if (s + 1 < nsteps) {
+      if (s + 1 < nsteps && !(PRG_C64_EXP & 2)) {
         adopt();
         write(s + 1);
         if (s + 2 < nsteps) issue(s + 2);
       }
-      if (s > 0) drain(s - 1);
+      if (s > 0 && !(PRG_C64_EXP & 16)) drain(s - 1);
       c64_barrier();                                       // (1) stage free
       c64_barrier();                                       // (2)
     }

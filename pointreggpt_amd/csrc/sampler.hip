@@ -121,8 +121,11 @@ __global__ void sampler_init_kernel(float* __restrict__ x, const float* __restri
 }
 
 static inline dim3 step_grid(int HW, int B) {
+  // about one workgroup per CU: the last-arriver ticket of sampler_step_kernel is one atomic per workgroup on a single
+  // address (~12 ns each, serialised): 1024 workgroups cost more than the launch the ticket saves
   int gx = ceil_div(HW / 4, 256);
-  if (gx > 64) gx = 64;
+  const int cap = 256 / B > 1 ? 256 / B : 1;
+  if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   return dim3(gx, B, 1);
 }

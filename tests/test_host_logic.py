@@ -183,3 +183,56 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["cover"] == [1] * 37 and res["max_load"] == 20.0
+
+
+def test_real_data_input_side(tmp_path, monkeypatch):
+    """the 3DMatch input side of Generator.generate (sd:2352-2361, 2397-2459) on a synthetic
+    layout — train_info.pkl -> <cloud>.info.txt -> frame-XXXXXX.depth.png (uint16 mm) -> Resize(S, NEAREST) ->
+    CenterCrop(S) -> x 1e-4 -> (> 1 -> 0), and the matching intrinsics.  torchvision is absent from the image, so the
+    expectation is a direct restatement of its documented arithmetic (resize: short side -> S, long side int(S*long/short),
+    nearest source pixel floor((i + 0.5) * scale); crop offset int(round((n - S) / 2))): parity-unpinned, but pinned to that."""
+    import pickle
+    from PIL import Image
+    from pointreggpt_amd.generator import PAIRS_PER_LAP, Generator
+    S = 64
+    rng = np.random.default_rng(22)
+    raw = rng.integers(300, 9000, size=(480, 640)).astype(np.uint16)
+    raw[:40, :40] = 0                          # holes
+    raw[100:120, 200:260] = 12000              # > 10 m: dropped by the (> 1 -> 0) rule
+    root = tmp_path / "3dmatch"
+    (root / "sceneA" / "seq-01").mkdir(parents=True)
+    Image.fromarray(raw).save(root / "sceneA" / "seq-01" / "frame-000012.depth.png")
+    (root / "sceneB" / "seq-02").mkdir(parents=True)
+    Image.fromarray(raw[::-1].copy()).save(root / "sceneB" / "seq-02" / "frame-000007.depth.png")
+    Kraw = np.array([[585.0, 0, 320.0], [0, 585.0, 240.0], [0, 0, 1.0]])
+    np.savetxt(root / "sceneA" / "camera-intrinsics.txt", Kraw)
+    np.savetxt(root / "sceneB" / "camera-intrinsics.txt", Kraw)
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "dataset/indoor/metadata").mkdir(parents=True)
+    (tmp_path / "dataset/indoor/data/train/sceneA").mkdir(parents=True)
+    (tmp_path / "dataset/indoor/data/train/sceneB").mkdir(parents=True)
+    info = {"src": ["train/sceneA/cloud_bin_0.pth"], "tgt": ["train/sceneB/cloud_bin_3.pth"]}
+    (tmp_path / "dataset/indoor/data/train/sceneA/cloud_bin_0.info.txt").write_text("sceneA seq-01 12 62\n")
+    (tmp_path / "dataset/indoor/data/train/sceneB/cloud_bin_3.info.txt").write_text("sceneB seq-02 7 57\n")
+
+    class _Diff:
+        image_size = S
+
+    gen = Generator(_Diff(), str(root), samples_folder=str(tmp_path / "out"), synthetic_seed=None, device="cpu")
+    # the index wraps every PAIRS_PER_LAP scenes; the fake list has one entry, so patch the modulus via a 1-entry view
+    lst = {"src": info["src"] * 1, "tgt": info["tgt"] * 1}
+    depth, K = gen._real_scene(0, {k: v * PAIRS_PER_LAP for k, v in lst.items()}, tmp_path)
+    # expectation
+    nw, nh = int(S * 640 / 480), S
+    xs = np.floor((np.arange(nw) + 0.5) * 640 / nw).astype(int)
+    ys = np.floor((np.arange(nh) + 0.5) * 480 / nh).astype(int)
+    left = int(round((nw - S) / 2.0))
+    exp = raw[ys][:, xs][:, left:left + S].astype(np.float32) * np.float32(1e-4)
+    exp[exp > 1] = 0
+    assert depth.dtype == np.float32 and depth.shape == (S, S) and np.array_equal(depth, exp)
+    assert (depth == 0).sum() > 0 and depth.max() <= 1.0
+    assert np.array_equal(K, G.intrinsic_transform(Kraw, resize=S, centercrop=S).astype(np.float32))
+    # odd laps swap src and tgt (sd:2397-2410)
+    depth2, _ = gen._real_scene(PAIRS_PER_LAP, {k: v * PAIRS_PER_LAP for k, v in lst.items()}, tmp_path)
+    assert np.array_equal(depth2, (raw[::-1][ys][:, xs][:, left:left + S].astype(np.float32) * np.float32(1e-4)) *
+                          ((raw[::-1][ys][:, xs][:, left:left + S].astype(np.float32) * np.float32(1e-4)) <= 1))
