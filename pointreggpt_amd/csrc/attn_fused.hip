@@ -801,7 +801,7 @@ int launch_full_attention_mfma(const bf16_t* qkv, bf16_t* out, int B, int N, hip
 
 bool resblock_tail_fused_supported(int C0, int C1, int Cout) {
   const int cin = C0 + C1;
-  return C0 % 8 == 0 && C1 % 8 == 0 && ((cin == 128 && Cout == 64) || (cin == 256 && Cout == 128));
+  return C0 % 8 == 0 && C1 % 8 == 0 && ((cin == 128 && Cout == 64) || (cin == 192 && Cout == 128) || (cin == 256 && Cout == 128));
 }
 
 // out (B, N, Cout) <- SiLU(h * A + Bc) + wres [Cout][C0+C1] . cat[s0 (B,N,C0), s1 (B,N,C1)] + bres.  out may alias h.
@@ -810,6 +810,7 @@ int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc,
                                hipStream_t s) {
   PRG_CHECK(resblock_tail_fused_supported(C0, C1, Cout) && bres, "fused resblock tail: unsupported shape");
   if (Cout == 64) return launch_tail<128, 64>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
+  if (C0 + C1 == 192) return launch_tail<192, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);   // up level 2
   return launch_tail<256, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
 }
 
