@@ -14,16 +14,7 @@ constexpr int kHeads = 4, kDimHead = 32, kHidden = 128;   // sd:738, sd:773
 template <typename T>
 int launch_gn_stats(const T* x, float* partials, int B, int HW, int C, int G, int* nsplit, hipStream_t s);
 
-struct GnApply {
-  const float* gamma;     // [C]
-  const float* beta;      // [C]
-  const float* ss_a;      // conditioning (scale | shift) rows of 2C floats, or null.  value = ss_a[b or step] + ss_b[b]
-  const float* ss_b;      // second addend (per image), or null
-  int64_t ss_b_stride;    // row stride of ss_b per image
-  int64_t ss_a_stride;    // row stride of ss_a per image (0 when shared by the whole batch)
-  const int* ss_a_row;    // optional device int: row index into ss_a added on top (sampler: current step), or null
-  int64_t ss_a_row_stride;
-};
+// (struct GnApply lives in common.h: the conv kernels that fold the coefficients themselves need it too)
 // Fold GroupNorm (+ conditioning) into per-(image, channel) affine coefficients y = x * A + B (the SiLU that follows
 // is applied by the consumer): the fused prologue of the next conv reads these.  A, Bc: [B][C] float32.
 int launch_gn_coeff(const float* partials, int nsplit, const GnApply& p, float* A, float* Bc, int B, int HW, int C,

@@ -250,12 +250,36 @@ template int launch_affine_silu<float>(const float*, const float*, const float*,
 template int launch_affine_silu<bf16_t>(const bf16_t*, const float*, const float*, const bf16_t*, bf16_t*, int, int, int,
                                         hipStream_t);
 
-// grid (B): GroupNorm (+ conditioning) folded to y = x * A[b][c] + Bc[b][c]
+// grid (B): GroupNorm (+ conditioning) folded to y = x * A[b][c] + Bc[b][c].  38 launches per U-Net evaluation, each a
+// short dependent chain: the per-channel parameters (norm gain / bias, the conditioning row found through the device step
+// counter) are fetched BEFORE the statistics so their latency runs under the partial-sum loads.
 __global__ __launch_bounds__(256) void gn_coeff_kernel(const float* __restrict__ partials, int nsplit, GnApply p,
                                                        float* __restrict__ A, float* __restrict__ Bc, int HW, int C,
                                                        int G) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.x;
+  // per-channel parameters of up to four channels per thread (C <= 1024)
+  const float* ssa = nullptr;
+  const float* ssb = nullptr;
+  if (p.ss_a) {
+    ssa = p.ss_a + (size_t)b * p.ss_a_stride;
+    if (p.ss_a_row) ssa += (size_t)(*p.ss_a_row) * p.ss_a_row_stride;
+    if (p.ss_b) ssb = p.ss_b + (size_t)b * p.ss_b_stride;
+  }
+  float gam[4] = {0, 0, 0, 0}, bet[4] = {0, 0, 0, 0}, s0v[4] = {0, 0, 0, 0}, s1v[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < C) {
+      gam[k] = p.gamma[c];
+      bet[k] = p.beta[c];
+      if (ssa) {
+        s0v[k] = ssa[c];
+        s1v[k] = ssa[C + c];
+        if (ssb) { s0v[k] += ssb[c]; s1v[k] += ssb[C + c]; }
+      }
+    }
+  }
   // LPG lanes (a power of two <= 64) share one group: strided partial sums, then a fixed shuffle tree (deterministic)
   int LPG = 64;
   while (LPG * G > 256) LPG >>= 1;
@@ -290,32 +314,27 @@ __global__ __launch_bounds__(256) void gn_coeff_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  const float* ssa = nullptr;
-  const float* ssb = nullptr;
-  if (p.ss_a) {
-    ssa = p.ss_a + (size_t)b * p.ss_a_stride;
-    if (p.ss_a_row) ssa += (size_t)(*p.ss_a_row) * p.ss_a_row_stride;
-    if (p.ss_b) ssb = p.ss_b + (size_t)b * p.ss_b_stride;
-  }
   const int cpg = C / G;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int g = c / cpg;
-    float a = s_rstd[g] * p.gamma[c];
-    float bb = p.beta[c] - s_mean[g] * a;
-    if (ssa) {
-      float s0 = ssa[c], s1 = ssa[C + c];
-      if (ssb) { s0 += ssb[c]; s1 += ssb[C + c]; }
-      a = a * (s0 + 1.0f);
-      bb = fmaf(bb, s0 + 1.0f, s1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < C) {
+      const int gg = c / cpg;
+      float a = s_rstd[gg] * gam[k];
+      float bb = bet[k] - s_mean[gg] * a;
+      if (ssa) {
+        a = a * (s0v[k] + 1.0f);
+        bb = fmaf(bb, s0v[k] + 1.0f, s1v[k]);
+      }
+      A[(size_t)b * C + c] = a;
+      Bc[(size_t)b * C + c] = bb;
     }
-    A[(size_t)b * C + c] = a;
-    Bc[(size_t)b * C + c] = bb;
   }
 }
 
 int launch_gn_coeff(const float* partials, int nsplit, const GnApply& p, float* A, float* Bc, int B, int HW, int C,
                     int G, hipStream_t s) {
-  PRG_CHECK(partials && A && Bc && G <= 64 && C % G == 0, "gn_coeff: bad arguments");
+  PRG_CHECK(partials && A && Bc && G <= 64 && C % G == 0 && C <= 1024, "gn_coeff: bad arguments");
   gn_coeff_kernel<<<B, 256, 0, s>>>(partials, nsplit, p, A, Bc, HW, C, G);
   PRG_LAUNCH_CHECK();
   return PRG_OK;

@@ -138,7 +138,20 @@ __device__ inline double wave_sum_d(double v) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+constexpr int kMaxTicketImages = 4096;   // per-image arrival counters (conv kernels folding GroupNorm coefficients): B <= this
 constexpr int kGnMaxSplit = 1024;  // max GroupNorm (sum, sumsq) partial slabs per image (256x256: 8x32 tiles x 4 wave rows)
+
+// GroupNorm parameters of one Block (+ the ResnetBlock conditioning): what folds the statistics into y = x * A + B
+struct GnApply {
+  const float* gamma;     // [C]
+  const float* beta;      // [C]
+  const float* ss_a;      // conditioning (scale | shift) rows of 2C floats, or null.  value = ss_a[b or step] + ss_b[b]
+  const float* ss_b;      // second addend (per image), or null
+  int64_t ss_b_stride;    // row stride of ss_b per image
+  int64_t ss_a_stride;    // row stride of ss_a per image (0 when shared by the whole batch)
+  const int* ss_a_row;    // optional device int: row index into ss_a added on top (sampler: current step), or null
+  int64_t ss_a_row_stride;
+};
 
 // ---------------------------------------------------------------------------------------------
 // activations

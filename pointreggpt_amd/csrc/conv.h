@@ -47,13 +47,20 @@ struct ConvLaunch {
   // coefficients (sd:690-696).  null = off.
   const float* pro_a;
   const float* pro_b;
+  // Optional in-kernel coefficient folding (kernels that support it report so through launch_conv's coef_done): the
+  // workgroup that completes an image's last tile turns the image's partial sums into gn_coef_a/b [B][Cout]
+  // (= what gn_coeff_kernel would compute in a launch of its own).  gn_tickets: [B] ints, zero between launches.
+  GnApply gn;
+  float* gn_coef_a;
+  float* gn_coef_b;
+  int* gn_tickets;
 };
 
 // Returns PRG_OK; *gn_nsplit_out (may be null) receives the number of statistic slabs per image written, or 0
 // when statistics were requested but this shape cannot fuse them.  `allow_prologue` must be checked by the
 // caller with conv_supports_prologue() before setting pro_a / pro_b.
 template <typename T>
-int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out);
+int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done = nullptr);
 
 // true when the 3x3 halo kernel will run this conv (so a fused input prologue is available)
 template <typename T>

@@ -618,15 +618,16 @@ static int launch_igemm(const ConvLaunch<T>& L, int M, hipStream_t s, int want_s
 }
 
 int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_ws.hip
-int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);  // conv_c64.hip
-static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n) {
-  const int r = try_launch_conv3x3_c64(L, s, n);            // weights-stationary kernel for the 64 -> 64 convs
+int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done);  // conv_c64.hip
+static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done) {
+  const int r = try_launch_conv3x3_c64(L, s, n, coef_done);  // weights-stationary kernel for the 64 -> 64 convs
   return r != 0 ? r : try_launch_conv3x3_ws(L, s, n);
 }
-static inline int try_ws(const ConvLaunch<float>&, hipStream_t, int*) { return 0; }
+static inline int try_ws(const ConvLaunch<float>&, hipStream_t, int*, int*) { return 0; }
 
 template <typename T>
-int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out) {
+int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done) {
+  if (coef_done) *coef_done = 0;
   const ConvDesc& d = L.d;
   constexpr int VEC = Elem<T>::kVec;
   PRG_CHECK(L.src0 && L.w && L.out, "conv: null pointer");
@@ -639,7 +640,7 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out) {
   const int want_stats = L.gn_partials != nullptr;
   if (gn_nsplit_out) *gn_nsplit_out = 0;
   {
-    const int r = try_ws(L, s, gn_nsplit_out);   // wave-specialised persistent kernel (bf16 throughput path)
+    const int r = try_ws(L, s, gn_nsplit_out, coef_done);   // persistent kernels of the bf16 throughput path
     if (r < 0) return r;
     if (r == 1) return PRG_OK;
   }
@@ -659,8 +660,8 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out) {
   return launch_igemm<T, 128, 64>(L, M, s, want_stats, gn_nsplit_out);
 }
 
-template int launch_conv<float>(const ConvLaunch<float>&, hipStream_t, int*);
-template int launch_conv<bf16_t>(const ConvLaunch<bf16_t>&, hipStream_t, int*);
+template int launch_conv<float>(const ConvLaunch<float>&, hipStream_t, int*, int*);
+template int launch_conv<bf16_t>(const ConvLaunch<bf16_t>&, hipStream_t, int*, int*);
 
 // ---------------------------------------------------------------------------------------------
 // weight packing (host)

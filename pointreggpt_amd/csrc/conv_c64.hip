@@ -86,20 +86,84 @@ __device__ __forceinline__ void c64_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// What gn_coeff_kernel does in a launch of its own, for ONE image, by one wave (lane = channel of the 64): the image's
+// (sum, sumsq) slabs summed in float64 — lanes of a group take slabs (c % cpg), + cpg, ... then a fixed xor tree —, mean /
+// rstd, folded with the norm's gain / bias and the ResnetBlock conditioning into y = x * A + B.  The slabs were written by
+// other CUs with agent-scope stores; they are read with agent-scope (L1-bypassing) loads.
+__device__ inline void c64_fold_coefficients(const ConvLaunch<bf16_t>& L, int img, int nsplit, int lane) {
+  const int G = L.gn_groups, cpg = 64 / G;
+  const int c = lane, g = c / cpg, j = c % cpg;
+  const GnApply& p = L.gn;
+  const float* ssa = nullptr;
+  const float* ssb = nullptr;
+  if (p.ss_a) {
+    ssa = p.ss_a + (size_t)img * p.ss_a_stride;
+    if (p.ss_a_row) ssa += (size_t)(*p.ss_a_row) * p.ss_a_row_stride;
+    if (p.ss_b) ssb = p.ss_b + (size_t)img * p.ss_b_stride;
+  }
+  const float gam = p.gamma[c], bet = p.beta[c];
+  float s0 = 0.0f, s1 = 0.0f;
+  if (ssa) {
+    s0 = ssa[c];
+    s1 = ssa[64 + c];
+    if (ssb) { s0 += ssb[c]; s1 += ssb[64 + c]; }
+  }
+  const unsigned long long* pp =
+      reinterpret_cast<const unsigned long long*>(L.gn_partials + ((size_t)img * nsplit * G + g) * 2);
+  double ss = 0, qq = 0;
+  for (int k0 = j; k0 < nsplit; k0 += 8 * cpg) {           // eight loads in flight per lane, summed in index order
+    unsigned long long v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 + i * cpg;
+      v[i] = k < nsplit ? __hip_atomic_load(pp + (size_t)k * G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ss += (double)__uint_as_float((unsigned)(v[i] & 0xffffffffull));
+      qq += (double)__uint_as_float((unsigned)(v[i] >> 32));
+    }
+  }
+  for (int o = cpg >> 1; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    qq += __shfl_xor(qq, o, 64);
+  }
+  const double n = (double)L.d.Hout * L.d.Wout * cpg;
+  const double mean = ss / n;
+  double var = qq / n - mean * mean;
+  if (var < 0) var = 0;
+  const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + 1e-5));
+  float a = frstd * gam;
+  float bb = bet - fmean * a;
+  if (ssa) {
+    a = a * (s0 + 1.0f);
+    bb = fmaf(bb, s0 + 1.0f, s1);
+  }
+  L.gn_coef_a[(size_t)img * 64 + c] = a;
+  L.gn_coef_b[(size_t)img * 64 + c] = bb;
+}
+
 template <bool PRO>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
-                                                          const int fuse_stats) {
+                                                          const int flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int fuse_stats = flags & 1;
   char* const stage = smem + 2 * AH_BYTES;
   const ConvDesc& d = L.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int total = tiles_x * tiles_y * d.B;
-  // XCD-contiguous tile runs (gridDim.x is a multiple of 8): XCD x owns tiles [x per, (x+1) per), its workgroups interleave
-  const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  // XCD-contiguous tile runs (gridDim.x is a multiple of 8): XCD x owns tiles [x per, (x+1) per); inside, every workgroup
+  // takes ONE contiguous run (stride 1): neighbouring tiles share halo rows in the XCD's L2 and a workgroup leaves an
+  // image at most twice per launch (the per-image coefficient ticket below is one atomic per departure).
+  const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wpx = gridDim.x >> 3;
   const int per = (total + 7) / 8;
-  const int first = xcd * per + widx;
-  const int hi_t = min((xcd + 1) * per, total);
-  const int nsteps = first < hi_t ? (hi_t - first + stride - 1) / stride : 0;
+  const int lo_t = min(xcd * per, total), hi_t = min((xcd + 1) * per, total);
+  const int nx = hi_t - lo_t, qx = nx / wpx, rx = nx % wpx;
+  // fuse_stats bit 1: interleaved assignment (workgroup w of the XCD takes tiles w, w + wpx, ...) instead of contiguous runs
+  const bool inter = (flags & 2) != 0;
+  const int first = inter ? lo_t + widx : lo_t + widx * qx + min(widx, rx);
+  const int nsteps = inter ? (widx < nx ? (nx - widx + wpx - 1) / wpx : 0) : qx + (widx < rx ? 1 : 0);
+  const int stride = inter ? wpx : 1;
   if (nsteps == 0) return;
 
   // ---------------------------------------------------------------------------------------------------
@@ -226,8 +290,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           const int nsplit = tiles_x * tiles_y * 2 * split_n;
           const int slab = (((ty0 / TH) * tiles_x + tx0 / TW) * 2 + wm) * split_n + (split_n == 2 ? wn : 0);
           const int grp = (wn * 4 + q) / gn_per;
-          L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 2)] = D;
+          // agent-scope (write-through, sc1) store: the workgroup that completes the image reads these from another CU
+          __hip_atomic_store(&L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 2)], D,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (L.gn_tickets) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials have left this CU before barrier (2)
       }
       c64_barrier();                                       // (2) stage written; halo s+1 written by the producers
     }
@@ -249,6 +316,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
       hx[k] = hp - hy[k] * HP;
     }
     c64_u32x4 hreg[KU];
+    const int tpi = tiles_x * tiles_y;                     // tiles per image
+    int done_in_img = 0;                                   // tiles of the current image this workgroup has finished
     unsigned okmask = 0, okmask_nxt = 0;
     float4 ca[2], cb[2], ca_n[2], cb_n[2];
     auto issue = [&](int s) {                              // loads of halo s into hreg
@@ -334,7 +403,23 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
       }
       if (s > 0 && !(PRG_C64_EXP & 16)) drain(s - 1);
       c64_barrier();                                       // (1) stage free
-      c64_barrier();                                       // (2)
+      c64_barrier();                                       // (2) + the consumers' partial sums of tile s have left the CU
+      if (fuse_stats && L.gn_tickets && ptid < 64) {       // first producer wave: per-image arrival ticket
+        const int t = first + s * stride;
+        const int img = t / tpi;
+        ++done_in_img;
+        const bool leave = s + 1 == nsteps || (t + stride) / tpi != img;
+        if (leave) {
+          int old = 0;
+          if (ptid == 0) old = __hip_atomic_fetch_add(L.gn_tickets + img, done_in_img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          old = __builtin_amdgcn_readfirstlane(old);
+          if (old + done_in_img == tpi) {                  // this workgroup completed image `img`: fold its statistics
+            if (ptid == 0) __hip_atomic_store(L.gn_tickets + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c64_fold_coefficients(L, img, tpi * 2 * (((64 / L.gn_groups) >> 3) > 4 ? 2 : 1), ptid);
+          }
+          done_in_img = 0;
+        }
+      }
     }
     drain(nsteps - 1);
     c64_barrier();
@@ -344,7 +429,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
 }  // namespace
 
 // Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
-int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done) {
   static const int enabled = [] {
     const char* e = std::getenv("PRG_CONV_C64");
     return e ? std::atoi(e) : 1;
@@ -382,8 +467,18 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
     attr_done[pro] = true;
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 * split_n : 0;
-  if (pro) conv3x3_c64_kernel<true><<<dim3(grid), 512, C64_LDS, s>>>(L, tiles_x, tiles_y, fuse);
-  else conv3x3_c64_kernel<false><<<dim3(grid), 512, C64_LDS, s>>>(L, tiles_x, tiles_y, fuse);
+  // the image-completing workgroup folds the statistics into the coefficients itself (no gn_coeff launch)
+  const bool fold = fuse && L.gn_tickets && L.gn_coef_a && L.gn_coef_b && L.gn.gamma && L.gn.beta && d.B <= kMaxTicketImages;
+  ConvLaunch<bf16_t> Lk = L;
+  if (!fold) Lk.gn_tickets = nullptr;
+  if (coef_done) *coef_done = fold ? 1 : 0;
+  // interleaved tile runs are ~2 % faster (neighbouring tiles run at the same time on neighbouring CUs of the XCD); the
+  // coefficient fold wants contiguous runs (one ticket per workgroup and image).  PRG_C64_INTERLEAVE=0/1 overrides.
+  static const int interleave_env = [] { const char* e = std::getenv("PRG_C64_INTERLEAVE"); return e ? std::atoi(e) : -1; }();
+  const int interleave = interleave_env >= 0 ? interleave_env : (fold ? 0 : 1);
+  const int flags = (fuse ? 1 : 0) | (interleave ? 2 : 0);
+  if (pro) conv3x3_c64_kernel<true><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  else conv3x3_c64_kernel<false><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
   PRG_LAUNCH_CHECK();
   return 1;
 }

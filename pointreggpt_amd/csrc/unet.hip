@@ -30,6 +30,15 @@ int fail(int code, const std::string& m) {
 }
 const char* last_error() { return g_err.c_str(); }
 
+// PRG_GN_FOLD=1: the conv kernels that can (conv_c64.hip) fold the GroupNorm statistics into coefficients themselves (last
+// workgroup of an image, per-image ticket) instead of a gn_coeff_kernel launch.  Measured net-neutral (every workgroup of a
+// persistent launch finishes at the same time, so the fold lands on the kernel's tail: +5-6 us per conv against the 5 us
+// launch + 1.7 us boundary it removes): off by default, kept as a tested option.
+static bool gn_fold_enabled() {
+  static const int on = [] { const char* e = std::getenv("PRG_GN_FOLD"); return e ? std::atoi(e) : 0; }();
+  return on != 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // device stack arena
 // ---------------------------------------------------------------------------------------------
@@ -232,6 +241,7 @@ struct prg_unet {
   bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
   float* d_kshift = nullptr;    // fused linear attention: static softmax shifts of the k columns
   float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
+  int* d_tickets = nullptr;     // [kMaxTicketImages] per-image arrival counters of the conv kernels that fold GroupNorm coefficients (self-resetting)
   Arena arena;
   uint64_t arena_gen = 0;       // bumped whenever the workspace is reallocated: captured graphs bake its pointers in
   int resB = 0, resS = 0;
@@ -261,6 +271,10 @@ struct UnetImpl : prg_unet {
     int* gn_nsplit = nullptr;       // out: slabs written (0 = not fused for this shape)
     const float* pro_a = nullptr;   // fused GroupNorm+cond+SiLU on the input (halo kernel)
     const float* pro_b = nullptr;
+    const GnApply* gn = nullptr;    // fold the output's statistics into coefficients inside the conv kernel when it can
+    float* coef_a = nullptr;
+    float* coef_b = nullptr;
+    int* coef_done = nullptr;       // out: 1 = coef_a / coef_b are written by the conv launch (no gn_coeff launch needed)
   };
 
   ConvDesc make_desc(const ConvP& p, int C0, int C1, int B, int Hin, int Win, int stride, int pad, int ups) const {
@@ -280,8 +294,12 @@ struct UnetImpl : prg_unet {
     L.d = make_desc(p, C0, C1, B, Hin, Win, stride, pad, ups);
     L.src0 = s0; L.src1 = s1; L.w = W(p); L.bias = F(p.b_off); L.residual = o.residual; L.out = out;
     L.gn_partials = o.gn_partials; L.gn_groups = lay.cfg.groups; L.pro_a = o.pro_a; L.pro_b = o.pro_b;
+    L.gn = o.gn ? *o.gn : GnApply{};
+    L.gn_coef_a = o.gn ? o.coef_a : nullptr; L.gn_coef_b = o.gn ? o.coef_b : nullptr;
+    L.gn_tickets = (o.gn && gn_fold_enabled()) ? d_tickets : nullptr;
     PRG_CHECK(C0 + C1 == p.Cin, "conv: channel mismatch");
     if (o.gn_nsplit) *o.gn_nsplit = 0;
+    if (o.coef_done) *o.coef_done = 0;
     if (arena.dry) return PRG_OK;
     if (prof && prof->on) {
       if (prof->used == prof->pool.size()) {
@@ -292,7 +310,7 @@ struct UnetImpl : prg_unet {
       }
       auto& ev = prof->pool[prof->used++];
       PRG_HIP(hipEventRecord(ev.first, s));
-      int rc = launch_conv<T>(L, s, o.gn_nsplit);
+      int rc = launch_conv<T>(L, s, o.gn_nsplit, o.coef_done);
       PRG_HIP(hipEventRecord(ev.second, s));
       prof->conv_flops += conv_flops(L.d);
       prof->conv_bytes += ((double)L.d.B * L.d.Hin * L.d.Win * (L.d.C0 + L.d.C1) + (double)L.d.B * L.d.Hout * L.d.Wout * L.d.Cout +
@@ -300,7 +318,7 @@ struct UnetImpl : prg_unet {
       prof->launches += 1;
       return rc;
     }
-    return launch_conv<T>(L, s, o.gn_nsplit);
+    return launch_conv<T>(L, s, o.gn_nsplit, o.coef_done);
   }
 
   GnApply gn_params(int64_t g_off, int64_t b_off, const CondSrc* cs, int ss_off) const {
@@ -331,22 +349,29 @@ struct UnetImpl : prg_unet {
     float* part2 = alloc<float>((size_t)B * kGnMaxSplit * G * 2);
     float* coefA = alloc<float>((size_t)B * r.cout);
     float* coefB = alloc<float>((size_t)B * r.cout);
-    PRG_CHECK(arena.dry || (h1 && part1 && part2 && coefA && coefB && (!r.has_res || res)), "workspace exhausted (resblock)");
+    float* coefA2 = alloc<float>((size_t)B * r.cout);
+    float* coefB2 = alloc<float>((size_t)B * r.cout);
+    PRG_CHECK(arena.dry || (h1 && part1 && part2 && coefA && coefB && coefA2 && coefB2 && (!r.has_res || res)),
+              "workspace exhausted (resblock)");
     const CondSrc* c1 = lay.cfg.conditional ? cs : nullptr;
-    int rc, ns1 = 0, ns2 = 0;
+    int rc, ns1 = 0, ns2 = 0, cd1 = 0, cd2 = 0;
+    const GnApply g1 = gn_params(r.g1, r.b1, c1, r.ss_off);
+    const GnApply g2 = gn_params(r.g2, r.b2, nullptr, 0);
     ConvOpt o1;
     o1.gn_partials = part1; o1.gn_nsplit = &ns1;
+    o1.gn = &g1; o1.coef_a = coefA; o1.coef_b = coefB; o1.coef_done = &cd1;
     if ((rc = conv(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, o1, h1, s))) return rc;
     if (!arena.dry && ns1 == 0 && (rc = launch_gn_stats<T>(h1, part1, B, HW, r.cout, G, &ns1, s))) return rc;
-    const GnApply g1 = gn_params(r.g1, r.b1, c1, r.ss_off);
+    // conv2's own statistics fold into a second coefficient pair (coefA / coefB are still being read by its prologue)
     ConvOpt o2;
     o2.gn_partials = part2; o2.gn_nsplit = &ns2;
+    o2.gn = &g2; o2.coef_a = coefA2; o2.coef_b = coefB2; o2.coef_done = &cd2;
     // PRG_FUSE_PRO: -1 (default) fuse wherever the conv supports it; 0 never; N > 0 only for widths >= N
     static const int fuse_min = [] { const char* e = std::getenv("PRG_FUSE_PRO"); return e ? std::atoi(e) : -1; }();
     const bool fuse_pro = conv_supports_prologue<T>(make_desc(r.c2, r.cout, 0, B, H, Wd, 1, 1, 0)) &&
                           (fuse_min < 0 || (fuse_min > 0 && r.cout >= fuse_min));
     if (!arena.dry) {
-      if ((rc = launch_gn_coeff(part1, ns1, g1, coefA, coefB, B, HW, r.cout, G, s))) return rc;
+      if (!cd1 && (rc = launch_gn_coeff(part1, ns1, g1, coefA, coefB, B, HW, r.cout, G, s))) return rc;
       if (fuse_pro) {
         o2.pro_a = coefA; o2.pro_b = coefB;
       } else if ((rc = launch_affine_silu<T>(h1, coefA, coefB, nullptr, h1, B, HW, r.cout, s))) {
@@ -369,16 +394,16 @@ struct UnetImpl : prg_unet {
     }
     if (!arena.dry) {
       // GroupNorm + SiLU + skip: fold the statistics into per-(image, channel) coefficients, then one flat pass
-      if ((rc = launch_gn_coeff(part2, ns2, gn_params(r.g2, r.b2, nullptr, 0), coefA, coefB, B, HW, r.cout, G, s))) return rc;
+      if (!cd2 && (rc = launch_gn_coeff(part2, ns2, g2, coefA2, coefB2, B, HW, r.cout, G, s))) return rc;
       if constexpr (std::is_same<T, bf16_t>::value) {
         if (fused_tail) {
-          rc = launch_resblock_tail_fused(out, coefA, coefB, s0, C0, s1, C1, d_attn + r.fw_res, F(r.res.b_off), out, B, HW,
+          rc = launch_resblock_tail_fused(out, coefA2, coefB2, s0, C0, s1, C1, d_attn + r.fw_res, F(r.res.b_off), out, B, HW,
                                           r.cout, s);
           arena.reset(m);
           return rc;
         }
       }
-      if ((rc = launch_affine_silu<T>(out, coefA, coefB, skip, out, B, HW, r.cout, s))) return rc;
+      if ((rc = launch_affine_silu<T>(out, coefA2, coefB2, skip, out, B, HW, r.cout, s))) return rc;
     }
     arena.reset(m);
     return PRG_OK;
@@ -669,6 +694,8 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
     if (hipMalloc(&u->d_freqs, half * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(time frequencies)");
     PRG_HIP(hipMemcpy(u->d_freqs, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (hipMalloc(&u->d_tickets, kMaxTicketImages * sizeof(int)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(tickets)");
+  PRG_HIP(hipMemset(u->d_tickets, 0, kMaxTicketImages * sizeof(int)));
   if (std::is_same<T, bf16_t>::value && L.cfg.in_channels == 1 && L.cfg.dim == 64) {
     std::vector<bf16_t> sf;
     pack_stem_mfma_weights(weights + L.stem_w, sf);
@@ -877,6 +904,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_attn) hipFree(h->d_attn);
   if (h->d_kshift) hipFree(h->d_kshift);
   if (h->d_freqs) hipFree(h->d_freqs);
+  if (h->d_tickets) hipFree(h->d_tickets);
   if (h->d_stem_frag) hipFree(h->d_stem_frag);
   if (h->arena.base) hipFree(h->arena.base);
   delete h;

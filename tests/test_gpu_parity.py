@@ -213,7 +213,9 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
     outs = {}
     variants = {"fast": {}, "no_ws": {"PRG_CONV_WS": "0"}, "no_fused_attn": {"PRG_FUSED_ATTN": "0"},
                 "no_kshift": {"PRG_LA_KSHIFT": "0"},       # measured column maxima instead of the static softmax shift
-                "no_c64": {"PRG_CONV_C64": "0"}}           # 64 -> 64 convs through the wave-specialised kernel instead
+                "no_c64": {"PRG_CONV_C64": "0"},           # 64 -> 64 convs through the wave-specialised kernel instead
+                "gn_fold": {"PRG_GN_FOLD": "1"},           # GroupNorm coefficients folded inside the c64 conv (per-image ticket)
+                "c64_contiguous": {"PRG_C64_INTERLEAVE": "0"}}   # contiguous instead of interleaved tile runs
     for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
@@ -221,7 +223,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
-    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64"):
+    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous"):
         for k in ("y64", "y128", "y40"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()
