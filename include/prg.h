@@ -36,7 +36,10 @@ enum {
   PRG_E_STATE = -4      /* handle used in the wrong state */
 };
 
-enum { PRG_F32 = 0, PRG_BF16 = 1 };          /* storage + MFMA input type of a U-Net handle */
+/* storage + MFMA input type of a U-Net handle.  PRG_MXFP8 (BASELINE configs[4]): activations stored in bf16, every 3x3
+ * convolution with 64-channel-multiple widths runs on v_mfma_scale_f32_32x32x64_f8f6f4 with OCP e4m3 operands and one
+ * E8M0 scale per 32 channels (weights quantised at prg_unet_create, activations while they are staged); the rest = bf16. */
+enum { PRG_F32 = 0, PRG_BF16 = 1, PRG_MXFP8 = 2 };
 
 int prg_abi_version(void);
 const char* prg_last_error(void);
@@ -147,6 +150,12 @@ int prg_maskunet_forward(prg_unet* h, const float* depth, float* prob, int B, in
 int prg_unet_set_taps(prg_unet* h, int enable);
 int prg_unet_get_tap(prg_unet* h, const char* name, float* out, int64_t out_capacity_floats, int* C, int* H,
                      int* W, void* stream);
+
+/* Kernel unit-test hook: one 3x3 / stride 1 / pad 1 convolution through the library's own dispatch in `dtype` (PRG_BF16
+ * or PRG_MXFP8).  x (B,Cin,H,W) float32 DEVICE, w (Cout,Cin,3,3) float32 HOST (used as is: no standardisation), bias
+ * (Cout) float32 HOST or NULL, out (B,Cout,H,W) float32 DEVICE (the bf16 result widened).  Synchronises.           */
+int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                      int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler: GaussianDiffusion.sample / p_sample_loop / ddim_sample (sd:1283-1409), DDNM replacement included

@@ -9,7 +9,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("PRG_HIP_LIB", _HERE / "libprg_hip.so"))
 
-PRG_F32, PRG_BF16 = 0, 1
+PRG_F32, PRG_BF16, PRG_MXFP8 = 0, 1, 2
 
 
 class PrgError(RuntimeError):
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "prg_unet_set_time_freqs": (C.c_int, [_P, _P, _I]),
     "prg_unet_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "prg_maskunet_forward": (C.c_int, [_P, _P, _P, _I, _I, _P]),
+    "prg_debug_conv3x3": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "prg_unet_set_taps": (C.c_int, [_P, _I]),
     "prg_unet_get_tap": (C.c_int, [_P, C.c_char_p, _P, _L, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P]),
     "prg_sampler_create": (C.c_int, [_P, C.POINTER(StepC), _I, _I, _I, C.POINTER(_P)]),

@@ -73,5 +73,7 @@ int launch_sinusoidal_i32(const int32_t* t, const float* freqs, float* out, int 
 // float32 NCHW <- T NHWC (debug taps)
 template <typename T>
 int launch_nhwc_to_nchw_f32(const T* x, float* out, int B, int HW, int C, hipStream_t s);
+template <typename T>
+int launch_nchw_f32_to_nhwc(const float* x, T* out, int B, int HW, int C, hipStream_t s);   // debug entry
 
 }  // namespace prg

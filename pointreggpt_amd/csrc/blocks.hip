@@ -800,6 +800,25 @@ int launch_nhwc_to_nchw_f32(const T* x, float* out, int B, int HW, int C, hipStr
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int HW, int C, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / ((size_t)HW * C), rem = i - b * HW * C;
+    const int p = (int)(rem / C), c = (int)(rem - (size_t)p * C);
+    out[i] = Elem<T>::store(x[(b * C + c) * HW + p]);
+  }
+}
+template <typename T>
+int launch_nchw_f32_to_nhwc(const float* x, T* out, int B, int HW, int C, hipStream_t s) {
+  const size_t n = (size_t)B * HW * C;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  nchw_to_nhwc_kernel<T><<<grid, 256, 0, s>>>(x, out, HW, C, n);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+template int launch_nchw_f32_to_nhwc<float>(const float*, float*, int, int, int, hipStream_t);
+template int launch_nchw_f32_to_nhwc<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t);
 template int launch_nhwc_to_nchw_f32<float>(const float*, float*, int, int, int, hipStream_t);
 template int launch_nhwc_to_nchw_f32<bf16_t>(const bf16_t*, float*, int, int, int, hipStream_t);
 

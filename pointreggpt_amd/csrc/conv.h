@@ -54,7 +54,20 @@ struct ConvLaunch {
   float* gn_coef_a;
   float* gn_coef_b;
   int* gn_tickets;
+  // MX-fp8 operands (handles of dtype PRG_MXFP8, 3x3 / s1 / p1 convs with 64-channel multiples): OCP e4m3 weights
+  // [tap][64-channel chunk][CoutPad][64] with one E8M0 scale per 32 input channels [tap][chunk][CoutPad][2]; null = bf16.
+  const uint8_t* w_mx;
+  const uint8_t* w_mx_scale;
 };
+
+// MX (OCP microscaling) fp8 packing of a conv weight: per (tap, output channel) the input channels are cut into blocks of
+// 32; block scale = 2^(floor(log2 max|w|) - 8) as an E8M0 byte (bias 127), elements = e4m3fn(w / scale), round to
+// nearest even, saturating at 448.  data: [tap][ceil(Cin/64)][CoutPad][64], scales: [tap][ceil(Cin/64)][CoutPad][2].
+void pack_conv_weight_mxfp8(const float* w_oihw, int Cout, int Cin, int KH, int KW, std::vector<uint8_t>& data,
+                            std::vector<uint8_t>& scales, int* CoutPad, int* chunks64);
+// host-side e4m3fn conversion used by the packer (and, through the debug entry, checked against the device's)
+uint8_t f32_to_e4m3(float v);
+float e4m3_to_f32(uint8_t b);
 
 // Returns PRG_OK; *gn_nsplit_out (may be null) receives the number of statistic slabs per image written, or 0
 // when statistics were requested but this shape cannot fuse them.  `allow_prologue` must be checked by the

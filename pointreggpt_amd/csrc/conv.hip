@@ -19,6 +19,8 @@
 // Shared epilogue: accumulators are transposed through LDS so every lane stores 16 contiguous bytes (full 128-byte
 // lines per 8 lanes) instead of 2-byte pieces, bias / residual are added on the way, and the per-(image, tile,
 // group) GroupNorm partial sums of the output are emitted in a fixed order (deterministic) for the consumer.
+#include <cmath>
+#include <cstring>
 #include <type_traits>
 
 #include "conv.h"
@@ -404,6 +406,214 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv3x3_halo_kern
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3 halo kernel with MX-fp8 operands (BASELINE configs[4]: "fp8 UNet weights on CDNA4 MFMA")
+// ---------------------------------------------------------------------------------------------
+// Same tiling as conv3x3_halo_kernel, but both MFMA operands are OCP e4m3 with one E8M0 scale per 32 channels and the
+// contraction runs on v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 = one channel chunk of one tap per instruction: a quarter of
+// the bf16 instruction count at twice the rate).  Weights arrive pre-quantised (pack_conv_weight_mxfp8); the bf16
+// activations are quantised while the halo is written to LDS, after the optional fused GroupNorm+SiLU prologue: the four
+// lanes that hold one pixel's 32 consecutive channels agree on the block maximum with two lane exchanges, the block scale
+// is 2^(floor(log2 max) - 8), the elements are rounded by v_cvt_pk_fp8_f32 (saturated at +-448 first).
+// Operand layout of the instruction (probed, tools/micro/mx_layout_probe.hip): lane l holds row/column l & 31; its 32
+// bytes are k = 16 h + (0..15) and 32 + 16 h + (0..15) with h = l >> 5; lane l's scale covers k in [32 h, 32 h + 32).
+// LDS rows are 64 data bytes padded to 80 (conflict-free ds_read_b128), scales sit in a byte array beside them.
+typedef __attribute__((ext_vector_type(8))) int mx_i32x8;
+
+__device__ inline uint32_t mx_cvt4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+
+template <int TH, int TW, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_mx_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
+                                                            const int tiles_n, const int fuse_stats) {
+  using T = bf16_t;
+  constexpr int CH = 64;                       // channels per chunk = K of one MFMA
+  constexpr int ROWB = 80;                     // LDS row: 64 fp8 + 16 pad
+  constexpr int BM = TH * TW;
+  constexpr int HP = TW + 2, HALO = (TH + 2) * HP;
+  constexpr int NH = (HALO * 8 + 255) / 256;   // halo units (8 channels) per thread
+  constexpr int NB = BN * 4 / 256;             // 16-byte weight units per thread (BN rows x 64 B)
+  constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M, TM = WM / 32;
+  static_assert(WM % 32 == 0 && TM >= 1 && NB >= 1, "wave tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ah = smem;                                        // [HALO][80]
+  char* Bw = Ah + HALO * ROWB;                            // [2][BN][80]
+  unsigned char* As = reinterpret_cast<unsigned char*>(Bw + 2 * BN * ROWB);   // [HALO][2] block scales
+  unsigned char* Bsc = As + ((HALO * 2 + 15) & ~15);      // [2][BN][2]
+  float* stage = reinterpret_cast<float*>(smem);          // epilogue scratch aliases the main-loop images
+
+  const ConvDesc& d = L.d;
+  const int nblk = tiles_x * tiles_y * tiles_n * d.B;
+  int lin = xcd_remap(blockIdx.x, nblk);
+  const int tn = lin % tiles_n; lin /= tiles_n;
+  const int tx = lin % tiles_x; lin /= tiles_x;
+  const int ty = lin % tiles_y;
+  const int b = lin / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nchunks = (d.C0 + d.C1) / CH;
+  const int Hl = d.Hout, Wl = d.Wout;
+  const int slot = tid & 7;
+
+  int64_t hsrc[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int hp = (tid >> 3) + k * 32;
+    hsrc[k] = -1;
+    if (hp < HALO) {
+      const int hy = hp / HP, hx = hp - hy * HP;
+      int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      if ((unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl) {
+        if (d.ups) { y >>= 1; x >>= 1; }
+        hsrc[k] = ((int64_t)b * d.Hin + y) * d.Win + x;
+      }
+    }
+  }
+  int ahp[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = wm * WM + i * 32 + l31;
+    ahp[i] = (p / TW) * HP + (p % TW);
+  }
+
+  Vec16<T> hreg[NH];
+  uint4 breg[NB];
+  uint16_t bsreg = 0;
+  auto gload_halo = [&](int chunk) {
+    const int c = chunk * CH + slot * 8;
+    const bool first = c < d.C0;
+    const T* base = first ? L.src0 : L.src1;
+    const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) hreg[k] = hsrc[k] >= 0 ? vec_load(base + hsrc[k] * Cs + cc) : vec_zero<T>();
+  };
+  auto gload_b = [&](int chunk, int tap) {
+    const size_t tile = (size_t)(tap * nchunks + chunk) * d.CoutPad + (size_t)tn * BN;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int u = tid + j * 256;                          // unit u: row u >> 2, 16-byte piece u & 3
+      breg[j] = *reinterpret_cast<const uint4*>(L.w_mx + (tile + (u >> 2)) * 64 + (u & 3) * 16);
+    }
+    if (tid < BN) bsreg = *reinterpret_cast<const uint16_t*>(L.w_mx_scale + (tile + tid) * 2);
+  };
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int niter = nchunks * 9;
+  gload_halo(0);
+  gload_b(0, 0);
+  int tap = 0, chunk = 0;
+  for (int it = 0; it < niter; ++it) {
+    if (tap == 0) {
+      if (it > 0) __syncthreads();            // every wave is done reading the previous chunk's halo
+      float pa[8], pb[8];
+      if (L.pro_a) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          pa[u] = L.pro_a[(size_t)b * d.C0 + chunk * CH + slot * 8 + u];
+          pb[u] = L.pro_b[(size_t)b * d.C0 + chunk * CH + slot * 8 + u];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int hp = (tid >> 3) + k * 32;           // (all 8 lanes of a row take the same branch: shuffles are safe)
+        if (hp < HALO) {
+          float f[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[u] = Elem<T>::load(hreg[k].e[u]);
+          if (L.pro_a && hsrc[k] >= 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[u] = Elem<T>::load(Elem<T>::store(Elem<T>::silu(fmaf(f[u], pa[u], pb[u]))));
+          }
+          float am = 0.0f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) am = fmaxf(am, fabsf(f[u]));
+          am = fmaxf(am, __shfl_xor(am, 1, 64));
+          am = fmaxf(am, __shfl_xor(am, 2, 64));      // maximum over the 32 channels of this block (slots 4q .. 4q+3)
+          const int E = (int)((__float_as_uint(am) >> 23) & 0xffu);
+          const int S = E > 8 ? E - 8 : 0;              // E8M0 scale 2^(S - 127); am == 0 -> S = 0 (elements are 0)
+          const float mult = __uint_as_float((uint32_t)(254 - S) << 23);   // 2^(127 - S)
+          float g[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g[u] = fminf(fmaxf(f[u] * mult, -448.0f), 448.0f);
+          uint2 w;
+          w.x = mx_cvt4(g[0], g[1], g[2], g[3]);
+          w.y = mx_cvt4(g[4], g[5], g[6], g[7]);
+          *reinterpret_cast<uint2*>(Ah + hp * ROWB + slot * 8) = w;
+          if ((slot & 3) == 0) As[hp * 2 + (slot >> 2)] = (unsigned char)S;
+        }
+      }
+    }
+    char* Bb = Bw + (it & 1) * BN * ROWB;
+    unsigned char* Sb = Bsc + (it & 1) * BN * 2;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int u = tid + j * 256;
+      *reinterpret_cast<uint4*>(Bb + (u >> 2) * ROWB + (u & 3) * 16) = breg[j];
+    }
+    if (tid < BN) *reinterpret_cast<uint16_t*>(Sb + tid * 2) = bsreg;
+    __syncthreads();
+    const int ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
+    if (it + 1 < niter) gload_b(nchunk, ntap);
+    if (tap == 0 && chunk + 1 < nchunks) gload_halo(chunk + 1);
+
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int toff = kh * HP + kw;
+    mx_i32x8 fa[TM], fb[2];
+    int sa[TM], sb[2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int hp = ahp[i] + toff;
+      const uint4 lo = *reinterpret_cast<const uint4*>(Ah + hp * ROWB + hi * 16);
+      const uint4 up = *reinterpret_cast<const uint4*>(Ah + hp * ROWB + 32 + hi * 16);
+      fa[i] = mx_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
+      sa[i] = As[hp * 2 + hi];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = wn * 64 + j * 32 + l31;
+      const uint4 lo = *reinterpret_cast<const uint4*>(Bb + n * ROWB + hi * 16);
+      const uint4 up = *reinterpret_cast<const uint4*>(Bb + n * ROWB + 32 + hi * 16);
+      fb[j] = mx_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
+      sb[j] = Sb[n * 2 + hi];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, sa[i], 0, sb[j]);
+    tap = ntap;
+    chunk = nchunk;
+  }
+
+  StatAcc<T> gs, gq;
+  auto row_to_m = [&](int r) -> int64_t {
+    const int p = wm * WM + r;
+    return ((int64_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+  };
+  epilogue_store<T, TM>(L, acc, stage + wave * 32 * 68, lane, tn * BN + wn * 64, row_to_m, gs, gq);
+  if (fuse_stats) {
+    const int nsplit = tiles_x * tiles_y;
+    float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
+    epilogue_stats<WAVES_M, WAVES_N>(reinterpret_cast<StatAcc<T>*>(stage + 4 * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout,
+                                     L.gn_groups, dst);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic gather kernel (1x1, 4x4 s2, ragged shapes)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN>
@@ -617,6 +827,37 @@ static int launch_igemm(const ConvLaunch<T>& L, int M, hipStream_t s, int want_s
   return PRG_OK;
 }
 
+template <int TH, int TW, int BN>
+static int launch_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, int* nsplit) {
+  const ConvDesc& d = L.d;
+  const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH, tiles_n = d.Cout / BN;
+  constexpr int HALO = (TH + 2) * (TW + 2);
+  size_t lds = (size_t)HALO * 80 + (size_t)2 * BN * 80 + ((HALO * 2 + 15) & ~15) + 2 * BN * 2 + 16;
+  if (lds < kEpilogueLds) lds = kEpilogueLds;
+  if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
+  conv3x3_mx_kernel<TH, TW, BN><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+// MX-fp8 operands: 1 = launched, 0 = shape not covered (bf16 kernels run instead)
+static int try_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+  if (!L.w_mx || !L.w_mx_scale) return 0;
+  const ConvDesc& d = L.d;
+  HaloPick<bf16_t> hp;
+  if (!pick_halo<bf16_t>(d, &hp) || L.residual) return 0;
+  const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
+  const int tiles = (d.Wout / hp.TW) * (d.Hout / hp.TH);
+  const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= hp.BN && tiles <= kGnMaxSplit;
+  int rc;
+  if (hp.TH == 8 && hp.TW == 32 && hp.BN == 64) rc = launch_mx<8, 32, 64>(L, s, fuse, gn_nsplit_out);
+  else if (hp.TH == 4 && hp.TW == 32 && hp.BN == 128) rc = launch_mx<4, 32, 128>(L, s, fuse, gn_nsplit_out);
+  else if (hp.TH == 8 && hp.TW == 16 && hp.BN == 128) rc = launch_mx<8, 16, 128>(L, s, fuse, gn_nsplit_out);
+  else if (hp.TH == 8 && hp.TW == 16 && hp.BN == 64) rc = launch_mx<8, 16, 64>(L, s, fuse, gn_nsplit_out);
+  else return 0;
+  return rc == PRG_OK ? 1 : rc;
+}
+static int try_mx(const ConvLaunch<float>&, hipStream_t, int*) { return 0; }
+
 int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_ws.hip
 int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done);  // conv_c64.hip
 static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done) {
@@ -639,6 +880,11 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* 
   const int M = (int)M64;
   const int want_stats = L.gn_partials != nullptr;
   if (gn_nsplit_out) *gn_nsplit_out = 0;
+  {
+    const int r = try_mx(L, s, gn_nsplit_out);              // MX-fp8 operands when the handle carries them
+    if (r < 0) return r;
+    if (r == 1) return PRG_OK;
+  }
   {
     const int r = try_ws(L, s, gn_nsplit_out, coef_done);   // persistent kernels of the bf16 throughput path
     if (r < 0) return r;
@@ -688,6 +934,66 @@ void pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, std::ve
 }
 template void pack_conv_weight<float>(const float*, int, int, int, int, std::vector<float>&, int*, int*);
 template void pack_conv_weight<bf16_t>(const float*, int, int, int, int, std::vector<bf16_t>&, int*, int*);
+
+// e4m3fn (OCP): 1-4-3, bias 7, max 448, no infinities; round to nearest even, saturating
+uint8_t f32_to_e4m3(float v) {
+  const uint8_t sign = std::signbit(v) ? 0x80 : 0;
+  float a = std::fabs(v);
+  if (!(a == a)) return sign | 0x7f;
+  if (a >= 448.0f) return sign | 0x7e;
+  if (a < 0.0009765625f) return sign;                       // < 2^-10: rounds to 0 (half of the smallest subnormal 2^-9, ties to even)
+  int e;
+  std::frexp(a, &e);                                         // a = m 2^e, m in [0.5, 1)
+  int E = e - 1;                                             // floor(log2 a)
+  if (E < -6) E = -6;                                        // subnormal range: fixed exponent, step 2^-9
+  const float step = std::ldexp(1.0f, E - 3);
+  float q = std::nearbyint(a / step);                        // round-half-even in the default rounding mode
+  float r = q * step;
+  if (r >= 448.0f) return sign | 0x7e;
+  if (r < 0.015625f) return sign | (uint8_t)q;               // subnormal: q in 0..7
+  int e2;
+  const float m2 = std::frexp(r, &e2);                       // r may have carried into the next binade
+  const int Eb = e2 - 1 + 7;
+  const int man = (int)std::nearbyint((m2 * 2.0f - 1.0f) * 8.0f);
+  return sign | (uint8_t)((Eb << 3) | man);
+}
+float e4m3_to_f32(uint8_t b) {
+  const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+  const float x = e == 0 ? std::ldexp((float)m, -9) : std::ldexp(1.0f + m / 8.0f, e - 7);
+  return s ? -x : x;
+}
+
+void pack_conv_weight_mxfp8(const float* w, int Cout, int Cin, int KH, int KW, std::vector<uint8_t>& data,
+                            std::vector<uint8_t>& scales, int* CoutPad, int* chunks64) {
+  const int cp = (Cout + 63) / 64 * 64, kc = (Cin + 63) / 64;
+  data.assign((size_t)KH * KW * kc * cp * 64, 0);
+  scales.assign((size_t)KH * KW * kc * cp * 2, 0);
+  for (int tap = 0; tap < KH * KW; ++tap)
+    for (int c64 = 0; c64 < kc; ++c64)
+      for (int n = 0; n < Cout; ++n)
+        for (int blk = 0; blk < 2; ++blk) {
+          float v[32], am = 0.0f;
+          for (int k = 0; k < 32; ++k) {
+            const int c = c64 * 64 + blk * 32 + k;
+            v[k] = c < Cin ? w[((size_t)n * Cin + c) * KH * KW + tap] : 0.0f;
+            am = std::fmax(am, std::fabs(v[k]));
+          }
+          uint32_t bits;
+          std::memcpy(&bits, &am, 4);
+          const int E = (int)((bits >> 23) & 0xff);
+          const int S = E > 8 ? E - 8 : 0;
+          const float mult = std::ldexp(1.0f, 127 - S);
+          const size_t row = ((size_t)(tap * kc + c64) * cp + n);
+          scales[row * 2 + blk] = (uint8_t)S;
+          for (int k = 0; k < 32; ++k) {
+            float g = v[k] * mult;
+            g = g > 448.0f ? 448.0f : (g < -448.0f ? -448.0f : g);
+            data[row * 64 + blk * 32 + k] = f32_to_e4m3(g);
+          }
+        }
+  *CoutPad = cp;
+  *chunks64 = kc;
+}
 
 // ---------------------------------------------------------------------------------------------
 // stem: 7x7 pad 3 direct conv, float32 NCHW in (Cin 1 or 3) -> T NHWC out (sd:824 / dc:822)

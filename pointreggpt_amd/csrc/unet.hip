@@ -78,6 +78,8 @@ struct ConvP {
   int64_t b_off = -1;      // float offset of the bias in the flat array (-1: none)
   int64_t w_flat = -1;     // float offset of the raw OIHW weight in the flat array
   bool ws = false;         // weight-standardised (Block.proj)
+  int64_t mx_off = -1;     // byte offset of the MX-fp8 copy of the weights (-1: none) and of its block scales
+  int64_t mx_soff = -1;
 };
 struct ResP {
   int cin = 0, cout = 0;
@@ -240,6 +242,8 @@ struct prg_unet {
   bf16_t* d_stem_frag = nullptr; // stem weights as MFMA fragments (bf16 path, Cin 1 -> 64)
   bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
   float* d_kshift = nullptr;    // fused linear attention: static softmax shifts of the k columns
+  uint8_t* d_mx = nullptr;      // MX-fp8 conv weights (dtype PRG_MXFP8): e4m3 data and E8M0 block scales
+  uint8_t* d_mx_scale = nullptr;
   float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
   int* d_tickets = nullptr;     // [kMaxTicketImages] per-image arrival counters of the conv kernels that fold GroupNorm coefficients (self-resetting)
   Arena arena;
@@ -294,6 +298,8 @@ struct UnetImpl : prg_unet {
     L.d = make_desc(p, C0, C1, B, Hin, Win, stride, pad, ups);
     L.src0 = s0; L.src1 = s1; L.w = W(p); L.bias = F(p.b_off); L.residual = o.residual; L.out = out;
     L.gn_partials = o.gn_partials; L.gn_groups = lay.cfg.groups; L.pro_a = o.pro_a; L.pro_b = o.pro_b;
+    L.w_mx = (d_mx && p.mx_off >= 0) ? d_mx + p.mx_off : nullptr;
+    L.w_mx_scale = (d_mx_scale && p.mx_soff >= 0) ? d_mx_scale + p.mx_soff : nullptr;
     L.gn = o.gn ? *o.gn : GnApply{};
     L.gn_coef_a = o.gn ? o.coef_a : nullptr; L.gn_coef_b = o.gn ? o.coef_b : nullptr;
     L.gn_tickets = (o.gn && gn_fold_enabled()) ? d_tickets : nullptr;
@@ -662,8 +668,16 @@ static void pack_all(Layout& L, const float* flat, std::vector<T>& packed) {
   }
 }
 
+static void collect_convs(Layout& L, std::vector<ConvP*>& convs) {
+  auto add_res = [&](ResP& r) { convs.push_back(&r.c1); convs.push_back(&r.c2); if (r.has_res) convs.push_back(&r.res); };
+  auto add_at = [&](AttnP& a) { convs.push_back(&a.qkv); convs.push_back(&a.out); };
+  for (auto& lv : L.downs) { add_res(lv.r0); add_res(lv.r1); add_at(lv.at); convs.push_back(&lv.resample); }
+  for (auto& lv : L.ups) { add_res(lv.r0); add_res(lv.r1); add_at(lv.at); convs.push_back(&lv.resample); }
+  add_res(L.mid1); add_at(L.mid_at); add_res(L.mid2); add_res(L.fin);
+}
+
 template <typename T>
-static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t n, prg_unet** out) {
+static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t n, prg_unet** out, bool mx = false) {
   std::unique_ptr<UnetImpl<T>> u(new UnetImpl<T>());
   int rc = build_layout(*cfg, u->lay);
   if (rc) return rc;
@@ -693,6 +707,33 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
     for (int i = 0; i < half; ++i) fr[i] = std::exp((float)i * stepf);
     if (hipMalloc(&u->d_freqs, half * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(time frequencies)");
     PRG_HIP(hipMemcpy(u->d_freqs, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (mx) {
+    // MX-fp8 copies of every 3x3 conv weight whose widths are 64-channel multiples (what conv3x3_mx_kernel covers); the
+    // 1x1 / 4x4 / stem convs and everything that is not a convolution stay bf16.
+    std::vector<ConvP*> convs;
+    collect_convs(u->lay, convs);
+    std::vector<uint8_t> data, scales, one, ones;
+    std::vector<float> tmp;
+    for (ConvP* p : convs) {
+      if (!(p->KH == 3 && p->KW == 3 && p->Cin % 64 == 0 && p->Cout % 64 == 0)) continue;
+      const float* w = weights + p->w_flat;
+      if (p->ws) { standardize(w, p->Cout, p->Cin * 9, tmp); w = tmp.data(); }
+      int cp = 0, kc = 0;
+      pack_conv_weight_mxfp8(w, p->Cout, p->Cin, 3, 3, one, ones, &cp, &kc);
+      p->mx_off = (int64_t)((data.size() + 255) / 256 * 256);
+      data.resize((size_t)p->mx_off + one.size());
+      std::memcpy(data.data() + p->mx_off, one.data(), one.size());
+      p->mx_soff = (int64_t)((scales.size() + 255) / 256 * 256);
+      scales.resize((size_t)p->mx_soff + ones.size());
+      std::memcpy(scales.data() + p->mx_soff, ones.data(), ones.size());
+    }
+    if (!data.empty()) {
+      if (hipMalloc(&u->d_mx, data.size()) != hipSuccess || hipMalloc(&u->d_mx_scale, scales.size()) != hipSuccess)
+        return fail(PRG_E_NOMEM, "hipMalloc(MX-fp8 weights)");
+      PRG_HIP(hipMemcpy(u->d_mx, data.data(), data.size(), hipMemcpyHostToDevice));
+      PRG_HIP(hipMemcpy(u->d_mx_scale, scales.data(), scales.size(), hipMemcpyHostToDevice));
+    }
   }
   if (hipMalloc(&u->d_tickets, kMaxTicketImages * sizeof(int)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(tickets)");
   PRG_HIP(hipMemset(u->d_tickets, 0, kMaxTicketImages * sizeof(int)));
@@ -885,12 +926,12 @@ int64_t prg_unet_param_count(const prg_unet_config* cfg) {
 
 int prg_unet_create(const prg_unet_config* cfg, const float* weights, int64_t n_floats, int dtype, prg_unet** out) {
   PRG_CHECK(cfg && weights && out, "prg_unet_create: null pointer");
-  PRG_CHECK(dtype == PRG_F32 || dtype == PRG_BF16, "prg_unet_create: dtype must be PRG_F32 or PRG_BF16");
+  PRG_CHECK(dtype == PRG_F32 || dtype == PRG_BF16 || dtype == PRG_MXFP8, "prg_unet_create: dtype must be PRG_F32, PRG_BF16 or PRG_MXFP8");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PRG_E_HIP, "prg_unet_create: no HIP device");
   *out = nullptr;
   int rc = dtype == PRG_F32 ? create_impl<float>(cfg, weights, n_floats, out)
-                            : create_impl<bf16_t>(cfg, weights, n_floats, out);
+                            : create_impl<bf16_t>(cfg, weights, n_floats, out, dtype == PRG_MXFP8);
   if (rc == PRG_OK) (*out)->dtype = dtype;
   return rc;
 }
@@ -904,6 +945,8 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_attn) hipFree(h->d_attn);
   if (h->d_kshift) hipFree(h->d_kshift);
   if (h->d_freqs) hipFree(h->d_freqs);
+  if (h->d_mx) hipFree(h->d_mx);
+  if (h->d_mx_scale) hipFree(h->d_mx_scale);
   if (h->d_tickets) hipFree(h->d_tickets);
   if (h->d_stem_frag) hipFree(h->d_stem_frag);
   if (h->arena.base) hipFree(h->arena.base);
@@ -971,6 +1014,55 @@ int prg_maskunet_forward(prg_unet* h, const float* depth, float* prob, int B, in
   CondSrc cs;
   rc = h->forward(aug, cs, prob, B, S, s);
   if (h->taps_on) h->taps["augment"] = Tap{aug, 3, S, S, B, true};
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                      int dtype, void* stream) {
+  PRG_CHECK(x && w && out, "prg_debug_conv3x3: null pointer");
+  PRG_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0, "prg_debug_conv3x3: bad shape");
+  PRG_CHECK(dtype == PRG_BF16 || dtype == PRG_MXFP8, "prg_debug_conv3x3: dtype must be PRG_BF16 or PRG_MXFP8");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t M = (size_t)B * H * W;
+  std::vector<bf16_t> packed;
+  int cp = 0, kc = 0;
+  pack_conv_weight<bf16_t>(w, Cout, Cin, 3, 3, packed, &cp, &kc);
+  std::vector<uint8_t> mxd, mxs;
+  if (dtype == PRG_MXFP8) {
+    PRG_CHECK(Cin % 64 == 0 && Cout % 64 == 0, "prg_debug_conv3x3: MX-fp8 needs 64-channel multiples");
+    int cp2 = 0, kc2 = 0;
+    pack_conv_weight_mxfp8(w, Cout, Cin, 3, 3, mxd, mxs, &cp2, &kc2);
+  }
+  std::vector<float> zb(Cout, 0.0f);
+  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_mxd = nullptr, *d_mxs = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_mxd, d_mxs}) if (p) hipFree(p); };
+  if (hipMalloc(&d_in, M * Cin * 2) != hipSuccess || hipMalloc(&d_out, M * Cout * 2) != hipSuccess ||
+      hipMalloc(&d_w, packed.size() * 2) != hipSuccess || hipMalloc(&d_b, Cout * 4) != hipSuccess ||
+      (dtype == PRG_MXFP8 && (hipMalloc(&d_mxd, mxd.size()) != hipSuccess || hipMalloc(&d_mxs, mxs.size()) != hipSuccess))) {
+    cleanup();
+    return fail(PRG_E_NOMEM, "prg_debug_conv3x3: hipMalloc failed");
+  }
+  hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(d_b, bias ? bias : zb.data(), Cout * 4, hipMemcpyHostToDevice);
+  if (dtype == PRG_MXFP8) {
+    hipMemcpy(d_mxd, mxd.data(), mxd.size(), hipMemcpyHostToDevice);
+    hipMemcpy(d_mxs, mxs.data(), mxs.size(), hipMemcpyHostToDevice);
+  }
+  int rc = launch_nchw_f32_to_nhwc<bf16_t>(x, reinterpret_cast<bf16_t*>(d_in), B, H * W, Cin, s);
+  if (rc == PRG_OK) {
+    ConvLaunch<bf16_t> L{};
+    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = 0; L.d.KH = 3; L.d.KW = 3; L.d.stride = 1; L.d.pad = 1;
+    L.d.Hout = H; L.d.Wout = W; L.d.Cout = Cout; L.d.CoutPad = cp; L.d.kchunks = kc;
+    L.src0 = reinterpret_cast<const bf16_t*>(d_in); L.w = reinterpret_cast<const bf16_t*>(d_w);
+    L.bias = reinterpret_cast<const float*>(d_b); L.out = reinterpret_cast<bf16_t*>(d_out);
+    L.gn_groups = 8;
+    L.w_mx = reinterpret_cast<const uint8_t*>(d_mxd); L.w_mx_scale = reinterpret_cast<const uint8_t*>(d_mxs);
+    rc = launch_conv<bf16_t>(L, s, nullptr);
+  }
+  if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<bf16_t>(reinterpret_cast<const bf16_t*>(d_out), out, B, H * W, Cout, s);
+  hipStreamSynchronize(s);
+  cleanup();
   return rc;
 }
 

@@ -5,8 +5,8 @@
 
 Both are thin handles: ``load_state_dict`` flattens a reference-layout state dict into the float32 arena the
 C-ABI expects (``prg_unet_create`` standardises / packs / uploads), ``forward`` / ``__call__`` launch the HIP
-kernels.  dtype 'bf16' (MFMA bf16, fp32 accumulate; the throughput mode) or 'fp32' (exact-f32 MFMA; the
-parity mode).  sd / dc = the reference's successive_ddnm_diffusion.py / depth_correction.py.
+kernels.  dtype 'bf16' (MFMA bf16, fp32 accumulate; the throughput mode), 'fp32' (exact-f32 MFMA; the parity mode)
+or 'mxfp8' (bf16 storage, 3x3 convs on the block-scaled fp8 MFMA: BASELINE configs[4]).  sd / dc = the reference's successive_ddnm_diffusion.py / depth_correction.py.
 """
 from __future__ import annotations
 
@@ -21,7 +21,7 @@ from . import _lib
 from .weights import UnetConfig, maskunet_config, param_spec, synth_state_dict, unet_config
 
 _DTYPES = {"fp32": _lib.PRG_F32, "f32": _lib.PRG_F32, "float32": _lib.PRG_F32, "bf16": _lib.PRG_BF16,
-           "bfloat16": _lib.PRG_BF16}
+           "bfloat16": _lib.PRG_BF16, "mxfp8": _lib.PRG_MXFP8}
 
 
 def _cfg_c(cfg: UnetConfig) -> _lib.UnetConfigC:

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4
 BF16_MAX, BF16_MEAN = 0.125, 0.022       # <= 2x observed (dim 64: max 0.062 / mean 0.0104 at 128x128, 0.056 / 0.0094 at 256x256)
+MXFP8_MAX, MXFP8_MEAN = 0.95, 0.17          # MX-fp8 3x3 convs (3-bit mantissas): <= 2x observed (0.47 / 0.085 on O(5) outputs, 8x bf16)
 NORTH_STAR = 1e-5          # point-XYZ L-infinity 1e-4 m == 1e-5 in normalised depth (1.0 == 10 m)
 XYZ_FLOOR_FACTOR = 1.0
 BF16_CHAIN_MAX, BF16_CHAIN_MEAN = 0.08, 0.004    # few-transition chains, in-painted pixels, normalised depth: <= 2x observed (0.038 / 0.002)
@@ -636,6 +637,81 @@ def test_overlap_counts_against_kdtree_oracle(hip):
     assert got[1] == (0.0, 0.0) and 0.2 < got[0][0] < 1.0
     e = PP.overlap_ratios_hip([(np.zeros((0, 3)), cloud(100, 0.0))])
     assert np.isnan(e[0][0]) and e[0][1] == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# conv kernels one at a time (prg_debug_conv3x3) and the MX-fp8 operand path of BASELINE configs[4]
+# ------------------------------------------------------------------------------------------------------------------
+def _debug_conv(hip, x, w, bias, dtype):
+    import ctypes as C
+    lib = hip.lib.load()
+    B, Cin, H, Wd = x.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, Cout, H, Wd), dtype=torch.float32, device="cuda")
+    wh = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    bh = None if bias is None else np.ascontiguousarray(bias.numpy(), dtype=np.float32)
+    hip.lib.check(lib.prg_debug_conv3x3(hip.lib.ptr(x.cuda().contiguous()), wh.ctypes.data_as(C.c_void_p),
+                                        None if bh is None else bh.ctypes.data_as(C.c_void_p), hip.lib.ptr(out), B, Cin, Cout, H,
+                                        Wd, dtype, hip.lib.stream_ptr()), "prg_debug_conv3x3")
+    return out.cpu()
+
+
+CONV_SHAPES = [(2, 64, 64, 32, 64),     # 64 -> 64: the weights-stationary kernel (16 tiles)
+               (2, 64, 64, 16, 32),     # 64 -> 64, too few tiles for it: wave-specialised 8x32x64
+               (1, 128, 128, 8, 32),    # 4x32x128 tiles, two channel chunks
+               (2, 64, 128, 16, 16),    # 8x16x128 tiles
+               (1, 192, 64, 8, 32)]     # three chunks
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,Wd", CONV_SHAPES)
+def test_conv3x3_kernels_one_at_a_time(hip, B, Cin, Cout, H, Wd):
+    """Each bf16 3x3 kernel of the dispatch against a float64 convolution of the SAME bf16-rounded operands: what remains
+    is fp32 accumulation order and the bf16 rounding of the output (half an ulp = 2^-9 relative)."""
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout + H)
+    x = torch.randn((B, Cin, H, Wd), generator=g) * torch.exp(torch.randn((1, Cin, 1, 1), generator=g))
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3.0 * Cin ** 0.5)
+    bias = torch.randn((Cout,), generator=g)
+    got = _debug_conv(hip, x, w, bias, hip.lib.PRG_BF16)
+    xb, wb = x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
+    ref = torch.nn.functional.conv2d(xb, wb, bias.double(), padding=1)
+    err = (got.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-4 * float(ref.abs().max())
+    assert bool((err <= tol).all()), float((err - tol).max())
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,Wd", CONV_SHAPES)
+def test_mxfp8_conv_matches_block_scaled_reference(hip, B, Cin, Cout, H, Wd):
+    """v_mfma_scale_f32_32x32x64_f8f6f4 path: device-side quantisation of the activations (block maxima, E8M0 scales,
+    e4m3 rounding) and host-side quantisation of the weights, against the numpy restatement of OCP MX (oracle/mx.py)."""
+    from oracle import mx
+    g = torch.Generator().manual_seed(Cin * 77 + Cout + Wd)
+    # per-(pixel, block) dynamic range over ~6 binades, one all-zero block, values beyond the e4m3 range of their block
+    x = torch.randn((B, Cin, H, Wd), generator=g) * torch.exp2(torch.randint(-3, 4, (B, Cin // 32, H, Wd), generator=g)
+                                                               .repeat_interleave(32, dim=1).float())
+    x[0, :32, 0, :5] = 0.0
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3.0 * Cin ** 0.5)
+    bias = torch.randn((Cout,), generator=g)
+    got = _debug_conv(hip, x, w, bias, hip.lib.PRG_MXFP8)
+    ref = mx.conv3x3_mx_reference(x, w, bias)
+    err = (got.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-4 * float(ref.abs().max())
+    assert bool((err <= tol).all()), (float((err - tol).max()), float(ref.abs().max()))
+    # and the quantisation is not a no-op: the same conv on unquantised bf16 operands differs visibly
+    plain = torch.nn.functional.conv2d(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), bias.double(), padding=1)
+    assert float((plain - ref).abs().max()) > 3 * float(tol.max())
+
+
+def test_unet_mxfp8_drift_reported(hip, golden):
+    """BASELINE configs[4] operand format end to end: dim-64 U-Net at 128x128 with MX-fp8 3x3 convolutions against the
+    reference's fp32 output.  fp8 has a 3-bit mantissa: the drift is reported and bounded at <= 2x what is observed."""
+    g = golden("G13_unet_dim64_128")
+    sd = W.synth_state_dict(W.unet_config(64), 13)
+    y = golden_unet(hip, golden, 64, "mxfp8", sd)(D(g["x"]), D(g["t"]), D(g["pc"]))
+    yb = golden_unet(hip, golden, 64, "bf16", sd)(D(g["x"]), D(g["t"]), D(g["pc"]))
+    e, em = maxerr(y, g["y"]), meanerr(y, g["y"])
+    print(f"dim 64 @128 mxfp8: max {e:.3e} mean {em:.3e}   (bf16: max {maxerr(yb, g['y']):.3e} mean {meanerr(yb, g['y']):.3e})")
+    assert np.isfinite(y.cpu().numpy()).all()
+    assert e <= MXFP8_MAX and em <= MXFP8_MEAN
 
 
 # ------------------------------------------------------------------------------------------------------------------
