@@ -303,6 +303,8 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   using G = Geo<C>;
   constexpr int RT = C / 32;                 // 32-channel row tiles of y
   constexpr int NA = RT / 2;                 // y accumulators per wave (RT x 2 pixel tiles over 4 waves)
+  constexpr int NR = RT > 4 ? RT / 4 : 1;    // distinct row tiles per wave (C = 256: two, each with both pixel tiles)
+  constexpr int RTL = RT > 4 ? RT : 4;       // row-tile pitch of the LayerNorm partial sums
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]   (later: the normalised y tile)
   __bf16* ot = xn + kTP * G::LDW;                    // [64][kLdO]  attention output, pixel-major
@@ -324,10 +326,12 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
     if (RT == 2) { yrt[a] = wave & 1; ypt[a] = wave >> 1; }
-    else { yrt[a] = wave; ypt[a] = a; }
+    else if (RT <= 4) { yrt[a] = wave; ypt[a] = a; }
+    else { yrt[a] = wave * NR + (a >> 1); ypt[a] = a & 1; }
   }
-  bf16x8 wo[kHid / 16];                                // to_out rows of this wave's y row tile (the same for all its accumulators)
-  load_wfrags<kHid>(wo, wout, yrt[0] * 32, l31, hi);
+  bf16x8 wo[NR][kHid / 16];                            // to_out rows of this wave's y row tile(s)
+#pragma unroll
+  for (int r = 0; r < NR; ++r) load_wfrags<kHid>(wo[r], wout, yrt[RT > 4 ? 2 * r : 0] * 32, l31, hi);
   XTile<C> xt;
   if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
   for (int t = t0; t < t1; ++t) {
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
     for (int kk = 0; kk < kHid / 16; ++kk) {
 #pragma unroll
       for (int a = 0; a < NA; ++a)
-        ya[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[kk],
+        ya[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[RT > 4 ? (a >> 1) : 0][kk],
                                                         frag(ot + ypt[a] * 32 * kLdO, kLdO, l31, hi, kk), ya[a], 0, 0, 0);
     }
 #pragma unroll
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (hi == 0) {
-        float* dst = lnb + ((ypt[a] * 32 + l31) * 4 + yrt[a]) * 2;
+        float* dst = lnb + ((ypt[a] * 32 + l31) * RTL + yrt[a]) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
@@ -413,8 +417,8 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
       float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        s1 += lnb[(px * 4 + rt) * 2];
-        s2 += lnb[(px * 4 + rt) * 2 + 1];
+        s1 += lnb[(px * RTL + rt) * 2];
+        s2 += lnb[(px * RTL + rt) * 2 + 1];
       }
       const float mean = s1 * (1.0f / C);
       const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.0f) + kLnEps);
@@ -607,7 +611,7 @@ size_t lds_kmax() { return (size_t)kTP * Geo<C>::LDW * 2; }
 template <int C>
 size_t lds_ctx() { return (size_t)kTP * Geo<C>::LDW * 2 + (size_t)4 * 2 * 32 * kLdP * 2; }
 template <int C>
-size_t lds_out() { return (size_t)kTP * Geo<C>::LDW * 2 + (size_t)kTP * kLdO * 2 + (size_t)kTP * 4 * 2 * 4; }
+size_t lds_out() { return (size_t)kTP * Geo<C>::LDW * 2 + (size_t)kTP * kLdO * 2 + (size_t)kTP * (C / 32 > 4 ? C / 32 : 4) * 2 * 4; }
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
@@ -814,7 +818,7 @@ int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc,
   return launch_tail<256, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
 }
 
-bool linattn_fused_supported(int C) { return C == 64 || C == 128; }
+bool linattn_fused_supported(int C) { return C == 64 || C == 128 || C == 256; }
 
 size_t linattn_fused_ws_floats(int B, int N) {
   const size_t ns = la_slabs(N);
@@ -828,6 +832,7 @@ int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf1
   PRG_CHECK(linattn_fused_supported(C), "fused linear attention: unsupported width");
   PRG_CHECK(la_slabs(N) <= 4096, "fused linear attention: too many slabs");
   if (C == 64) return launch_c<64>(x, wqkv, wout, bias, out_g, out, ws, B, N, kshift, s);
+  if (C == 256) return launch_c<256>(x, wqkv, wout, bias, out_g, out, ws, B, N, kshift, s);
   return launch_c<128>(x, wqkv, wout, bias, out_g, out, ws, B, N, kshift, s);
 }
 
