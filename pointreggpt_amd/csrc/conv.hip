@@ -860,8 +860,10 @@ static int try_mx(const ConvLaunch<float>&, hipStream_t, int*) { return 0; }
 
 int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_ws.hip
 int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done);  // conv_c64.hip
+int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_w256.hip
 static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done) {
-  const int r = try_launch_conv3x3_c64(L, s, n, coef_done);  // weights-stationary kernel for the 64 -> 64 convs
+  int r = try_launch_conv3x3_c64(L, s, n, coef_done);        // weights-stationary kernel for the 64 -> 64 convs
+  if (r == 0) r = try_launch_conv3x3_w256(L, s, n);          // 256-pixel x 128-channel tiles where the launch fills the chip
   return r != 0 ? r : try_launch_conv3x3_ws(L, s, n);
 }
 static inline int try_ws(const ConvLaunch<float>&, hipStream_t, int*, int*) { return 0; }

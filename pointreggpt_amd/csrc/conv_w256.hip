@@ -1,0 +1,519 @@
+// conv_w256.hip — wave-specialised 3x3 convolution with a 256-pixel x 128-channel workgroup tile (bf16 throughput path).
+//
+// The 128-pixel tiles of conv_ws.hip stage one 16 KB weight tile and meet one workgroup barrier per 512 MFMA cycles, and
+// their consumers read one LDS fragment per MFMA; measured, a third of that kernel's time is interference between the two
+// wave classes.  Here every ratio is halved: the workgroup (512 threads, two waves per SIMD, up to 256
+// VGPRs) computes 256 pixels x 128 output channels per tile,
+//
+//   waves 0-3  CONSUMERS (2 pixel halves x 2 channel halves): a wave owns 128 pixels x 64 channels = eight 32x32
+//              accumulators (128 VGPRs); per tap and 16-channel k-step it reads 4 pixel + 2 weight fragments for 8 MFMAs
+//              (0.75 ds_read_b128 per MFMA), prefetched one call (8 MFMAs) ahead, across the phase barrier included.
+//              A phase (one tap of one 64-channel chunk) is 32 MFMAs = 1024 cycles per wave.  Tile end: bias, GroupNorm
+//              partial sums (the halving butterfly of conv_ws.hip), bf16, and DIRECT stores — a v_permlane32_swap pairs
+//              the two lane halves' channel quads, so every lane stores 16 contiguous bytes; no LDS stage, no drain;
+//   waves 4-7  PRODUCERS: weight tile ph+2 from registers into a 3-slot LDS ring and the loads of tile ph+5 (three
+//              register sets, three phases = ~3000 cycles between a load and its use); the halo of step s+1 written
+//              during step s from registers loaded a whole step earlier (optional fused GroupNorm + (scale+1, shift) +
+//              SiLU prologue of the previous Block, sd:690-696), each register re-issued at once for halo s+2.
+//              Plain loads: a step is straight-line code (no branch between a load and its use), so the compiler's
+//              s_waitcnt vmcnt(N) counts are exact; the barrier waits for LDS only, never for VMEM.
+//
+// LDS: 2 halos x 352 rows x 144 B (padded rows: conflict-free ds_read_b128, immediate tap offsets; 12 spare rows take the
+// writes of the units past the halo end) + 3 weight slots x 128 rows x 144 B + bias = 157 KB, one workgroup per CU.
+// Covers the 3x3 / stride 1 / pad 1 convs with Cout % 128 == 0 and 64-channel sources whose launch has at least one tile
+// per CU: tiles of 8 x 32 pixels (image widths 32, 64, 128, ...) or 16 x 16 (the 16 x 16 level).
+#include <cstdlib>
+
+#include "conv.h"
+
+namespace prg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 w2_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float w2_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int w2_u32x4;
+
+namespace {
+
+// Timing experiments only (results become garbage): 1 consumers skip reads + MFMAs, 2 producers skip the halo, 4 no
+// epilogue, 8 producers skip the weights, 16 no prologue arithmetic.
+#ifndef PRG_W256_EXP
+#define PRG_W256_EXP 0
+#endif
+
+constexpr int kCH = 64, BN = 128, ROWB = 144;
+
+template <int TW>
+struct W2Geom {
+  static constexpr int TH = 256 / TW, HP = TW + 2, HALO = (TH + 2) * HP;
+  static constexpr int NPT = 256, RPP = NPT / 8;             // producer threads; halo rows per pass
+  static constexpr int KU = (HALO + RPP - 1) / RPP;          // halo units per producer thread
+  static constexpr int HROWS = KU * RPP;                     // LDS rows per halo buffer (units past HALO land in the spare rows)
+  static constexpr size_t AH_BYTES = (size_t)HROWS * ROWB;
+  static constexpr size_t BW_BYTES = (size_t)BN * ROWB;
+  static constexpr size_t LDS = 2 * AH_BYTES + 3 * BW_BYTES + BN * sizeof(float);
+  static_assert(KU == 11, "unit schedule below");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+__device__ inline float w2_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ inline float w2_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ inline uint32_t w2_pack(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ inline float w2_silu(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+template <int CTRL>
+__device__ inline float w2_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int XOR>
+__device__ inline float w2_swz(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1F));
+}
+
+// barrier that never waits for VMEM; LDS_DONE: this wave's LDS writes are complete first (producers)
+template <bool LDS_DONE>
+__device__ __forceinline__ void w2_barrier() {
+  if constexpr (LDS_DONE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Tile schedule of one workgroup (workgroup b runs on XCD b % 8: observed placement, speed only).  With several output
+// channel tiles every XCD is pinned to ONE of them: its CUs stream the same weight slice, which stays in the XCD's L2.
+struct W2Tiles {
+  int tiles_x, tiles_y, first, stride, count, tn;
+  __device__ __forceinline__ void init(int bid, int GR, int tx, int ty, int tiles_n, int nb) {
+    tiles_x = tx;
+    tiles_y = ty;
+    const int npix = tx * ty * nb, per_xcd = GR >> 3, xcd = bid & 7, idx = bid >> 3;
+    tn = xcd % tiles_n;
+    const int gx = 8 / tiles_n, member = xcd / tiles_n;
+    first = member * per_xcd + idx;
+    stride = gx * per_xcd;
+    count = first < npix ? (npix - first + stride - 1) / stride : 0;
+  }
+  __device__ __forceinline__ void decode(int it, int& b, int& y0, int& x0, int TH, int TW) const {
+    int t = first + it * stride;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    b = t / tiles_y;
+    y0 = ty * TH;
+    x0 = tx * TW;
+  }
+};
+
+template <int TW, bool PRO>
+__global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
+                                                           const int tiles_n, const int fuse_stats) {
+  using G = W2Geom<TW>;
+  constexpr int TH = G::TH, HP = G::HP, KU = G::KU, RPP = G::RPP;
+  constexpr int AH = (int)G::AH_BYTES, BW = (int)G::BW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const bias_lds = reinterpret_cast<float*>(smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES);
+  const ConvDesc& d = L.d;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nchunks = (d.C0 + d.C1) / kCH;
+  W2Tiles tm;
+  tm.init((int)blockIdx.x, (int)gridDim.x, tiles_x, tiles_y, tiles_n, d.B);
+  const int nsteps = tm.count * nchunks;
+  if (nsteps == 0) return;
+
+  // ---------------------------------------------------------------------------------------------------
+  if (wave < 4) {
+    __builtin_amdgcn_s_setprio(3);
+    const int wm = wave >> 1, wn = wave & 1;                // pixel half, channel half of the tile
+    const int l31 = lane & 31, hi = lane >> 5;
+    // pixel of the wave's 32-pixel group `pt` that this lane owns.  16-pixel tile rows: a group spans two halo rows; the
+    // second row's columns are rotated by two so that every ds_read_b128 lane group stays bank-conflict free (conv_ws.hip).
+    const int lpx = (TW == 16 && l31 >= 16) ? 16 + ((l31 - 2) & 15) : l31;
+    constexpr int GROWS = 32 / TW;                          // tile rows per 32-pixel group
+    const int prow = wm * (TH / 2) + (TW == 16 ? (lpx >> 4) : 0), pcol = TW == 16 ? (lpx & 15) : lpx;
+    constexpr int PTB = GROWS * HP * ROWB;                  // LDS bytes between the wave's pixel groups
+    const char* xa = smem + (prow * HP + pcol) * ROWB + hi * 16;
+    const char* xn = xa + AH;
+    const char* const wr = smem + 2 * AH + (wn * 64 + l31) * ROWB + hi * 16;
+    if (tid < BN) bias_lds[tid] = L.bias[tm.tn * BN + tid];
+    const int gn_per = fuse_stats ? (d.Cout / L.gn_groups) >> 3 : 1;   // 8-channel chunks per GroupNorm group
+    const int gn_per_sh = 31 - __builtin_clz(gn_per);
+    w2_f32x16 acc[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
+    w2_bf16x8 fw[2][2], fx[2][4];
+#define W2_LW(SET, CT, RING, CALL) fw[SET][CT] = *reinterpret_cast<const w2_bf16x8*>(wr + (RING) * BW + (CT) * 32 * ROWB + (CALL) * 32)
+#define W2_LX(SET, PT, BASE, TOFF, CALL) fx[SET][PT] = *reinterpret_cast<const w2_bf16x8*>(BASE + (PT) * PTB + (TOFF) * ROWB + (CALL) * 32)
+#define W2_MM(SET, CT, PT) acc[CT][PT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[SET][CT], fx[SET][PT], acc[CT][PT], 0, 0, 0)
+#define W2_SB() __builtin_amdgcn_sched_barrier(0)
+    w2_barrier<true>();                                      // halo 0 and weight tiles 0, 1 are in LDS; the bias too
+    W2_LW(0, 0, 0, 0); W2_LX(0, 0, xa, 0, 0); W2_LX(0, 1, xa, 0, 0); W2_LX(0, 2, xa, 0, 0); W2_LX(0, 3, xa, 0, 0); W2_LW(0, 1, 0, 0);
+    int chunk = 0, it = 0;
+    for (int g = 0; g < nsteps; ++g) {
+      const bool tile_end = chunk == nchunks - 1;
+#pragma unroll
+      for (int p = 0; p < 9; ++p) {
+        const int toff = (p / 3) * HP + (p % 3);
+        const int pn = p == 8 ? 0 : p + 1;
+        const int toffN = (pn / 3) * HP + (pn % 3);
+#pragma unroll
+        for (int call = 0; call < ((PRG_W256_EXP & 1) ? 0 : 4); ++call) {
+          const int cur = call & 1, nxt = cur ^ 1;           // 36 calls per step: the set parity is the call parity
+          // the next call's six fragments, one load between two MFMAs, earliest-needed first
+          if (call < 3) {
+            W2_LW(nxt, 0, p % 3, call + 1); W2_MM(cur, 0, 0); W2_SB();
+            W2_LX(nxt, 0, xa, toff, call + 1); W2_MM(cur, 0, 1); W2_SB();
+            W2_LX(nxt, 1, xa, toff, call + 1); W2_MM(cur, 0, 2); W2_SB();
+            W2_LX(nxt, 2, xa, toff, call + 1); W2_MM(cur, 0, 3); W2_SB();
+            W2_LX(nxt, 3, xa, toff, call + 1); W2_MM(cur, 1, 0); W2_SB();
+            W2_LW(nxt, 1, p % 3, call + 1); W2_MM(cur, 1, 1); W2_SB();
+          } else if (p < 8) {                                // next tap: its weight tile is in ring slot (p + 1) % 3 since the last barrier
+            W2_LW(nxt, 0, (p + 1) % 3, 0); W2_MM(cur, 0, 0); W2_SB();
+            W2_LX(nxt, 0, xa, toffN, 0); W2_MM(cur, 0, 1); W2_SB();
+            W2_LX(nxt, 1, xa, toffN, 0); W2_MM(cur, 0, 2); W2_SB();
+            W2_LX(nxt, 2, xa, toffN, 0); W2_MM(cur, 0, 3); W2_SB();
+            W2_LX(nxt, 3, xa, toffN, 0); W2_MM(cur, 1, 0); W2_SB();
+            W2_LW(nxt, 1, (p + 1) % 3, 0); W2_MM(cur, 1, 1); W2_SB();
+          } else {                                           // next step: the other halo buffer (complete since barrier 7), ring slot 0
+            W2_LW(nxt, 0, 0, 0); W2_MM(cur, 0, 0); W2_SB();
+            W2_LX(nxt, 0, xn, toffN, 0); W2_MM(cur, 0, 1); W2_SB();
+            W2_LX(nxt, 1, xn, toffN, 0); W2_MM(cur, 0, 2); W2_SB();
+            W2_LX(nxt, 2, xn, toffN, 0); W2_MM(cur, 0, 3); W2_SB();
+            W2_LX(nxt, 3, xn, toffN, 0); W2_MM(cur, 1, 0); W2_SB();
+            W2_LW(nxt, 1, 0, 0); W2_MM(cur, 1, 1); W2_SB();
+          }
+          W2_MM(cur, 1, 2);
+          W2_MM(cur, 1, 3);
+          W2_SB();
+        }
+        if (p == 8 && tile_end) {
+          // tile finished.  Lane holds pixel (group pt, lpx), channels ct*32 + 8q + 4hi + {0..3} of the wave's 64.
+          int tb, ty0, tx0;
+          tm.decode(it, tb, ty0, tx0, TH, TW);
+          if (PRG_W256_EXP & 4) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt) asm volatile("" ::"v"(acc[ct][pt]));
+          } else {
+            char* const obase = reinterpret_cast<char*>(L.out) +
+                                ((((size_t)tb * d.Hout + ty0 + prow) * d.Wout + tx0 + pcol) * d.Cout + tm.tn * BN + wn * 64 + 8 * hi) * 2;
+            const size_t optb = (size_t)GROWS * d.Wout * d.Cout * 2;   // bytes between the wave's pixel groups
+            float V[16];                                     // [sum | sum of squares][ct][q]
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              float bv[4][4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + wn * 64 + ct * 32 + 8 * q + 4 * hi);
+                bv[q][0] = b4.x; bv[q][1] = b4.y; bv[q][2] = b4.z; bv[q][3] = b4.w;
+                V[ct * 4 + q] = 0.0f;
+                V[8 + ct * 4 + q] = 0.0f;
+              }
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  float v[4];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[ct][pt][4 * q + r] + bv[q][r];
+                    V[ct * 4 + q] += v[r];
+                    V[8 + ct * 4 + q] = fmaf(v[r], v[r], V[8 + ct * 4 + q]);
+                    acc[ct][pt][4 * q + r] = 0.0f;
+                  }
+                  pk[2 * q] = w2_pack(v[0], v[1]);
+                  pk[2 * q + 1] = w2_pack(v[2], v[3]);
+                }
+                // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: swapping the upper
+                // half of chunk 2m with the lower half of chunk 2m+1 leaves lane half 0 with all 8 channels of chunk 2m and
+                // half 1 with those of chunk 2m+1 — one 16-byte store each.
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                  const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * m], pk[4 * m + 2], false, false);
+                  const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * m + 1], pk[4 * m + 3], false, false);
+                  const w2_u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+                  *reinterpret_cast<w2_u32x4*>(obase + pt * optb + ct * 64 + m * 32) = o;
+                }
+              }
+            }
+            if (fuse_stats) {
+              // 16 full-wave sums with 17 lane exchanges (the halving butterfly of conv_ws.hip): fixed order, deterministic
+              const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+              float A8[8], B4[4], C2[2];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) A8[j] = (b0 ? V[8 + j] : V[j]) + w2_dpp<0xB1>(b0 ? V[j] : V[8 + j]);          // lane ^ 1
+#pragma unroll
+              for (int j = 0; j < 4; ++j) B4[j] = (b1 ? A8[4 + j] : A8[j]) + w2_dpp<0x4E>(b1 ? A8[j] : A8[4 + j]);    // lane ^ 2
+#pragma unroll
+              for (int j = 0; j < 2; ++j) C2[j] = (b2 ? B4[2 + j] : B4[j]) + w2_swz<4>(b2 ? B4[j] : B4[2 + j]);
+              float D = (b3 ? C2[1] : C2[0]) + w2_swz<8>(b3 ? C2[0] : C2[1]);
+              D += w2_swz<16>(D);
+              D += __shfl_xor(D, 32, 64);
+              // lane (< 16) holds the wave total of value i = 8 b0 + 4 b1 + 2 b2 + b3 = [sq][ct][q]
+              if (gn_per >= 2) D += w2_swz<8>(D);
+              if (gn_per >= 4) D += w2_swz<4>(D);
+              if (gn_per >= 8) D += w2_dpp<0x4E>(D);
+              const int i = (lane & 1) * 8 + (lane & 2) * 2 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
+              const int cc = i & 7;
+              if (lane < 16 && (cc & (gn_per - 1)) == 0) {
+                const int nsplit = tiles_x * tiles_y * 2;
+                const int slab = ((ty0 / TH) * tiles_x + tx0 / TW) * 2 + wm;
+                const int grp = (((tm.tn * BN + wn * 64) >> 3) + cc) >> gn_per_sh;
+                L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
+              }
+            }
+          }
+        }
+        w2_barrier<false>();   // every LDS read of this phase has been consumed by an MFMA above
+      }
+      { const char* t = xa; xa = xn; xn = t; }
+      if (++chunk == nchunks) {
+        chunk = 0;
+        ++it;
+      }
+    }
+#undef W2_LW
+#undef W2_LX
+#undef W2_MM
+#undef W2_SB
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  {
+    const int ptid = tid - 256, slot = ptid & 7, row = ptid >> 3;   // 16-byte unit of a 128-byte row; rows row + 32 k
+    char* const Ah0 = smem + row * ROWB + slot * 16;
+    char* const Bw0 = smem + 2 * AH + row * ROWB + slot * 16;
+    const int Hl = d.Hout, Wl = d.Wout;
+    // tile-independent part of every halo unit's address and validity
+    unsigned hpix[KU], hedge[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int hp = k * RPP + row;
+      const int hy = hp / HP, hx = hp - hy * HP;
+      int ry = hy - 1, rx = hx - 1;                          // tile origins are even: the x2 gather is (origin / 2) + (r >> 1)
+      if (d.ups) { ry >>= 1; rx >>= 1; }
+      hpix[k] = (unsigned)((ry + 1) * d.Win + (rx + 1));
+      hedge[k] = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) |
+                 (hp >= G::HALO ? 16u : 0u);
+    }
+    // this thread's first unit of a weight tile inside a tap's [2][CoutPad][32] slab; rows row + 32 j are 2048 bytes apart
+    const unsigned w_voff = (unsigned)((((slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8) * 2);
+    const unsigned ld_dummy = (unsigned)(d.Win + 1);         // the tile origin: always mapped, stand-in for padding taps
+    struct StepInfo { int chunk, it, b, y0, x0; };
+    int gC = 0;
+    auto advance = [&](StepInfo& si) {                       // past the last step it stays there: harmless reloads
+      if (gC + 1 < nsteps) {
+        ++gC;
+        if (++si.chunk == nchunks) {
+          si.chunk = 0;
+          ++si.it;
+          tm.decode(si.it, si.b, si.y0, si.x0, TH, TW);
+        }
+      }
+    };
+    StepInfo sA;
+    sA.chunk = 0;
+    sA.it = 0;
+    tm.decode(0, sA.b, sA.y0, sA.x0, TH, TW);
+    StepInfo sB = sA;
+    advance(sB);
+    StepInfo sC = sB;
+    advance(sC);
+
+    w2_u32x4 wset[3][4], hreg[KU];
+    float4 cf[4], nf[4];                                     // a0..3, a4..7, b0..3, b4..7 of the halo being written / issued
+    unsigned hvalid = 0, hvalid_nxt = 0;
+    const char* ld_base = nullptr;
+    unsigned ld_cs2 = 0, ld_tedge = 0;
+    const float* ld_ca = nullptr;
+    const float* ld_cb = nullptr;
+    auto issue_setup = [&](const StepInfo& si) {
+      const int c = si.chunk * kCH;
+      const bool first = c < d.C0;
+      const bf16_t* src = first ? L.src0 : L.src1;
+      const int cs = first ? d.C0 : d.C1;
+      const int cc = first ? c : c - d.C0;
+      ld_cs2 = (unsigned)(cs * 2);
+      ld_tedge = (si.y0 == 0 ? 1u : 0u) | (si.y0 + TH == Hl ? 2u : 0u) | (si.x0 == 0 ? 4u : 0u) | (si.x0 + TW == Wl ? 8u : 0u) | 16u;
+      const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> d.ups)) * d.Win + (si.x0 >> d.ups) - (d.Win + 1);
+      ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
+      if constexpr (PRO) {
+        const size_t o = (size_t)si.b * d.C0 + si.chunk * kCH + slot * 8;
+        ld_ca = L.pro_a + o;
+        ld_cb = L.pro_b + o;
+      }
+      hvalid_nxt = 0;
+    };
+    auto issue_coeffs = [&](float4* dst) {
+      if constexpr (PRO) {
+        dst[0] = *reinterpret_cast<const float4*>(ld_ca);
+        dst[1] = *reinterpret_cast<const float4*>(ld_ca + 4);
+        dst[2] = *reinterpret_cast<const float4*>(ld_cb);
+        dst[3] = *reinterpret_cast<const float4*>(ld_cb + 4);
+      }
+    };
+    auto issue_unit = [&](int k) {                           // k is a compile-time constant at every call site
+      const bool ok = (hedge[k] & ld_tedge) == 0 && !(PRG_W256_EXP & 2);
+      const unsigned pix = ok ? hpix[k] : ld_dummy;
+      const unsigned voff = __umul24(pix, ld_cs2) + (unsigned)(slot * 16);
+      hreg[k] = *reinterpret_cast<const w2_u32x4*>(ld_base + voff);
+      hvalid_nxt |= (ok ? 1u : 0u) << k;
+    };
+    auto write_unit = [&](int k, int bufoff) {
+      w2_u32x4 v = hreg[k];
+      if constexpr (PRO && !(PRG_W256_EXP & 16)) {
+        const float a8[8] = {cf[0].x, cf[0].y, cf[0].z, cf[0].w, cf[1].x, cf[1].y, cf[1].z, cf[1].w};
+        const float b8[8] = {cf[2].x, cf[2].y, cf[2].z, cf[2].w, cf[3].x, cf[3].y, cf[3].z, cf[3].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = w2_silu(fmaf(w2_lo(v[j]), a8[2 * j], b8[2 * j]));
+          const float hh = w2_silu(fmaf(w2_hi(v[j]), a8[2 * j + 1], b8[2 * j + 1]));
+          v[j] = w2_pack(lo, hh);
+        }
+      }
+      if (!((hvalid >> k) & 1u)) v = w2_u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<w2_u32x4*>(Ah0 + bufoff + k * RPP * ROWB) = v;
+    };
+    auto w_tile = [&](int tap, int chunk) -> const char* {
+      return reinterpret_cast<const char*>(L.w) + ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tm.tn * BN) * 64 + w_voff;
+    };
+    auto w_issue = [&](int set, const char* p) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wset[set][j] = *reinterpret_cast<const w2_u32x4*>(p + ((PRG_W256_EXP & 8) ? 0 : j * 2048));
+    };
+    auto w_write = [&](int set, int ring) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<w2_u32x4*>(Bw0 + ring * BW + j * 32 * ROWB) = wset[set][j];
+    };
+
+    // ---- prologue: halo 0 and weight tiles 0, 1 into LDS; halo 1 and tiles 2, 3, 4 into registers
+    issue_setup(sA);
+    issue_coeffs(cf);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) issue_unit(k);
+    hvalid = hvalid_nxt;
+    w_issue(0, w_tile(0, 0));
+    w_issue(1, w_tile(1, 0));
+#pragma unroll
+    for (int k = 0; k < KU; ++k) write_unit(k, 0);
+    w_write(0, 0);
+    w_write(1, 1);
+    issue_setup(sB);
+    issue_coeffs(nf);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) issue_unit(k);
+    hvalid = hvalid_nxt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+    w_issue(2, w_tile(2, 0));
+    w_issue(0, w_tile(3, 0));
+    w_issue(1, w_tile(4, 0));
+    issue_setup(sC);
+    w2_barrier<true>();
+
+    // units of halo s+1 written (and re-issued for halo s+2) in phases 0..7: 2 2 2 1 1 1 1 1
+    constexpr int US[10] = {0, 2, 4, 6, 7, 8, 9, 10, 11, 11};
+#pragma unroll 1
+    for (int g = 0; g < nsteps; ++g) {
+      const int bufoff = ((g + 1) & 1) * AH;
+      const int ch0 = sA.chunk, ch1 = sB.chunk;
+#pragma unroll
+      for (int p = 0; p < 9; ++p) {
+        const int set = (p + 2) % 3;
+        w_write(set, set);                                   // weight tile 9g + p + 2 (loaded three phases ago)
+#pragma unroll
+        for (int k = US[p]; k < US[p + 1]; ++k) write_unit(k, bufoff);
+        if (p == 0) issue_coeffs(nf);                        // coefficients of halo g + 2
+        const int tapn = (p + 5) % 9;                        // weight tile 9g + p + 5: this step's or the next one's chunk
+        w_issue(set, w_tile(tapn, p + 5 < 9 ? ch0 : ch1));
+#pragma unroll
+        for (int k = US[p]; k < US[p + 1]; ++k) issue_unit(k);
+        if (p == 8) {                                        // step bookkeeping (wave-uniform) in the phase without halo work
+          hvalid = hvalid_nxt;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+          sA = sB;
+          sB = sC;
+          advance(sC);
+          issue_setup(sC);
+        }
+        w2_barrier<true>();
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
+int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+  static const int enabled = [] {
+    const char* e = std::getenv("PRG_CONV_W256");
+    return e ? std::atoi(e) : 1;
+  }();
+  if (!enabled) return 0;
+  const ConvDesc& d = L.d;
+  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
+  if (d.C0 % kCH || d.C1 % kCH || d.C0 == 0 || d.Cout % BN || d.CoutPad != d.Cout) return 0;
+  if (L.residual || !L.bias) return 0;
+  if (L.pro_a && d.C1) return 0;                            // the fused prologue is defined for a single source
+  const int tiles_n = d.Cout / BN;
+  if (tiles_n != 1 && tiles_n != 2 && tiles_n != 4 && tiles_n != 8) return 0;   // an XCD is pinned to one channel tile
+  const int H = d.Hout, W = d.Wout;
+  int tw = 0;
+  if (W % 32 == 0 && H % 8 == 0) tw = 32;
+  else if (W % 16 == 0 && H % 16 == 0) tw = 16;
+  else return 0;
+  if (d.ups && ((H | W) & 1)) return 0;
+  const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
+  const long total = (long)tiles_x * tiles_y * tiles_n * d.B;
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    num_cus = p.multiProcessorCount;
+  }
+  // fewer tiles than CUs: the 128-pixel tiles of conv_ws.hip fill the chip better
+  static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
+  const int grid = num_cus & ~7;
+  if (grid < 8 || total < (min_fill > 0 ? min_fill : grid)) return 0;
+  const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
+  const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
+                   tiles_x * tiles_y * 2 <= kGnMaxSplit;
+  if (L.gn_partials && !fuse) return 0;
+  const int pro = L.pro_a ? 1 : 0;
+  const void* fn = tw == 32 ? (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, true>)
+                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, false>))
+                            : (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, true>)
+                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, false>));
+  const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
+  static bool attr_done[2][2] = {{false, false}, {false, false}};
+  if (!attr_done[tw == 32][pro]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 conv): ") + hipGetErrorString(e));
+    attr_done[tw == 32][pro] = true;
+  }
+  if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
+  if (tw == 32) {
+    if (pro) conv3x3_w256_kernel<32, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256_kernel<32, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+  } else {
+    if (pro) conv3x3_w256_kernel<16, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256_kernel<16, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+  }
+  PRG_LAUNCH_CHECK();
+  return 1;
+}
+
+}  // namespace prg

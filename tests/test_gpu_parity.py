@@ -216,7 +216,10 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                 "no_kshift": {"PRG_LA_KSHIFT": "0"},       # measured column maxima instead of the static softmax shift
                 "no_c64": {"PRG_CONV_C64": "0"},           # 64 -> 64 convs through the wave-specialised kernel instead
                 "gn_fold": {"PRG_GN_FOLD": "1"},           # GroupNorm coefficients folded inside the c64 conv (per-image ticket)
-                "c64_contiguous": {"PRG_C64_INTERLEAVE": "0"}}   # contiguous instead of interleaved tile runs
+                "c64_contiguous": {"PRG_C64_INTERLEAVE": "0"},   # contiguous instead of interleaved tile runs
+                # 256-pixel x 128-channel tiles wherever the shape allows (at these batch sizes the default dispatch keeps
+                # the 128-pixel tiles): fused prologue, x2 gather, two sources, statistics, 8x32 and 16x16 tiles
+                "w256_all": {"PRG_W256_MIN_TILES": "1"}, "no_w256": {"PRG_CONV_W256": "0"}}
     for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
@@ -224,7 +227,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
-    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous"):
+    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256"):
         for k in ("y64", "y128", "y40"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()
@@ -661,9 +664,12 @@ CONV_SHAPES = [(2, 64, 64, 32, 64),     # 64 -> 64: the weights-stationary kerne
                (1, 128, 128, 8, 32),    # 4x32x128 tiles, two channel chunks
                (2, 64, 128, 16, 16),    # 8x16x128 tiles
                (1, 192, 64, 8, 32)]     # three chunks
+CONV_SHAPES_BF16 = CONV_SHAPES + [(16, 128, 128, 64, 64),  # 256 tiles of 8x32x128: the 256-pixel kernel, two chunks
+                                  (8, 64, 256, 64, 64),    # ... two output-channel tiles (XCDs pinned to one each)
+                                  (256, 64, 128, 16, 16)]  # ... 16x16 tiles
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,Wd", CONV_SHAPES)
+@pytest.mark.parametrize("B,Cin,Cout,H,Wd", CONV_SHAPES_BF16)
 def test_conv3x3_kernels_one_at_a_time(hip, B, Cin, Cout, H, Wd):
     """Each bf16 3x3 kernel of the dispatch against a float64 convolution of the SAME bf16-rounded operands: what remains
     is fp32 accumulation order and the bf16 rounding of the output (half an ulp = 2^-9 relative)."""
