@@ -12,15 +12,17 @@
 // ring, no per-tap barrier).  The workgroup (512 threads, 256 registers per lane) is
 //
 //   waves 0-3  CONSUMERS (2 pixel halves x 2 channel halves of a 8 x 32 pixel x 64 channel tile): 144 MFMAs per tile,
-//              fragments prefetched one call ahead; epilogue = bias, bf16, LDS stage, GroupNorm partial sums (the
-//              deterministic butterfly of conv_ws.hip);
+//              fragments prefetched one call ahead; epilogue = bias, GroupNorm partial sums (the deterministic butterfly
+//              of conv_ws.hip), bf16 and DIRECT stores: a v_permlane32_swap pairs the two lane halves' channel quads, so
+//              every lane stores 16 contiguous bytes (no LDS stage, nothing for the producers to drain);
 //   waves 4-7  PRODUCERS: write halo s+1 (loaded a whole step earlier; optional fused GroupNorm + (scale+1, shift) + SiLU
-//              prologue of the previous Block, sd:690-696), re-issue the registers for halo s+2, drain the finished tile
-//              from the stage to HBM in 128-byte rows.  A step is ~5000 cycles, so plain loads with compiler-managed waits
-//              are enough: every load has a full step to land.
+//              prologue of the previous Block, sd:690-696), re-issue the registers for halo s+2.  A step is ~5000 cycles,
+//              so plain loads with compiler-managed waits are enough: every load has a full step to land.
 //
-// Two barriers per tile: (1) "stage drained" before the consumers' epilogue, (2) "halo s+1 written, stage s written".
-// LDS: 2 halos x 340 rows x 144 B (padded rows: conflict-free ds_read_b128 with immediate tap offsets) + 32 KB stage.
+// ONE barrier per tile, between the consumers' MFMAs and their epilogue: "halo s+1 written; buffer s & 1 no longer read".
+// The epilogue of tile s therefore runs while the producers already write halo s+2 (round 2 had two barriers and an LDS
+// stage: producers idle during the epilogue, consumers idle during the drain — the two were additive, 81 / 122 us).
+// LDS: 2 halos x 340 rows x 144 B (padded rows: conflict-free ds_read_b128 with immediate tap offsets).
 #include <cstdlib>
 
 #include "conv.h"
@@ -34,20 +36,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int c64_u32x4;
 namespace {
 
 // Timing experiments only (results become garbage): -DPRG_C64_EXP=1 consumers skip fragment reads + MFMAs, 2 producers skip
-// the halo loads / writes, 4 no epilogue, 8 no priority raise, 16 producers skip the drain, 32 producers skip only the
-// prologue arithmetic.
+// the halo loads / writes, 4 no epilogue, 8 no priority raise, 32 producers skip only the prologue arithmetic.
 #ifndef PRG_C64_EXP
 #define PRG_C64_EXP 0
 #endif
 
 constexpr int TH = 8, TW = 32, HP = TW + 2, HALO = (TH + 2) * HP;   // 340 halo rows
 constexpr int ROWB = 144;                                              // padded LDS row (64 bf16 = 128 B + 16)
-constexpr size_t AH_BYTES = (size_t)HALO * ROWB;
-constexpr size_t STG_BYTES = 4 * 128 * 64;                             // per consumer wave: 128 pixels x 32 channels bf16
-constexpr size_t C64_LDS = 2 * AH_BYTES + STG_BYTES;
 constexpr int NPT = 256;                                               // producer threads
 constexpr int RPP = NPT / 8;                                           // halo rows per pass
 constexpr int KU = (HALO + RPP - 1) / RPP;                             // 11 units per producer thread
+constexpr size_t AH_BYTES = (size_t)KU * RPP * ROWB;                   // 352 rows: the units past the halo end land in spare rows
+constexpr size_t C64_LDS = 2 * AH_BYTES + 64 * sizeof(float);          // + the bias
 
 __device__ inline float c64_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ inline float c64_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
                                                           const int flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int fuse_stats = flags & 1;
-  char* const stage = smem + 2 * AH_BYTES;
   const ConvDesc& d = L.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int total = tiles_x * tiles_y * d.B;
@@ -180,11 +179,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         const bf16_t* p = L.w + ((size_t)(tap * d.kchunks + (c >> 1)) * d.CoutPad + wn * 32 + l31) * 32 + (c & 1) * 16 + hi * 8;
         wf[tap][c] = *reinterpret_cast<const c64_bf16x8*>(p);
       }
-    const float* const biasp = L.bias + wn * 32 + 4 * hi;
+    float* const bias_lds = reinterpret_cast<float*>(smem + 2 * AH_BYTES);
+    if (tid < 64) bias_lds[tid] = L.bias[tid];             // visible after the prologue barrier
+    const float* const biasp = bias_lds + wn * 32 + 4 * hi;
     const int gn_per = fuse_stats ? (64 / L.gn_groups) >> 3 : 1;   // 8-channel chunks per group (1, 2, 4 or 8)
     // LDS byte offset of pixel (row 4 wm + pt, column l31), tap (0,0), k-step 0: rows are HP * ROWB apart
     const unsigned x0off = (unsigned)(((wm * 4) * HP + l31) * ROWB + hi * 16);
-    char* const stg = stage + wave * (128 * 64);
     c64_barrier();                                         // halo 0 is in LDS (producers' prologue)
     for (int s = 0; s < nsteps; ++s) {
       const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
@@ -236,35 +236,52 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
       // ---- epilogue: lane holds pixel (row 4 wm + pt, col l31), channels wn*32 + 8 q + 4 hi + {0..3}
       int tb, ty0, tx0;
       c64_tile(first + s * stride, tiles_x, tiles_y, tb, ty0, tx0);
-      c64_barrier();                                       // (1) the producers have drained the previous tile's stage
+      // the partial sums of the previous tile have left this CU before the barrier its ticket is taken behind
+      if (fuse_stats && L.gn_tickets) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      c64_barrier();                                       // halo s+1 is written; nobody reads buffer s & 1 any more
       if (PRG_C64_EXP & 4) {                               // keep the accumulators live (no dead-code elimination of the MFMAs)
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) asm volatile("" ::"v"(acc[pt]));
       }
       float V[8];                                          // [sum | sumsq][q]
+      if (!(PRG_C64_EXP & 4)) {
+        float bv[4][4];
 #pragma unroll
-      for (int q = 0; q < ((PRG_C64_EXP & 4) ? 0 : 4); ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        float sm = 0.0f, sq = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
+          bv[q][0] = b4.x; bv[q][1] = b4.y; bv[q][2] = b4.z; bv[q][3] = b4.w;
+          V[q] = 0.0f;
+          V[4 + q] = 0.0f;
+        }
+        char* const obase = reinterpret_cast<char*>(L.out) +
+                            ((((size_t)tb * d.Hout + ty0 + wm * 4) * d.Wout + tx0 + l31) * 64 + wn * 32 + 8 * hi) * 2;
+        const size_t orow = (size_t)d.Wout * 128;          // output bytes per image row
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-          float v[4];
+          uint32_t pk[8];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[pt][4 * q + r] + bv[r];
-            sm += v[r];
-            sq = fmaf(v[r], v[r], sq);
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[pt][4 * q + r] + bv[q][r];
+              V[q] += v[r];
+              V[4 + q] = fmaf(v[r], v[r], V[4 + q]);
+            }
+            pk[2 * q] = c64_pack(v[0], v[1]);
+            pk[2 * q + 1] = c64_pack(v[2], v[3]);
           }
-          uint2 w;
-          w.x = c64_pack(v[0], v[1]);
-          w.y = c64_pack(v[2], v[3]);
-          // stage row = pixel pt*32 + l31 (64 B = 32 channels), 16-byte unit q (XOR-swizzled by the row), half hi
-          const int px = pt * 32 + l31;
-          *reinterpret_cast<uint2*>(stg + px * 64 + ((q ^ ((px >> 1) & 3)) << 4) + hi * 8) = w;
+          // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: swapping the upper half
+          // of chunk 2m with the lower half of chunk 2m+1 leaves lane half 0 with all 8 channels of chunk 2m, half 1 with
+          // those of chunk 2m+1: one 16-byte store each
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * m], pk[4 * m + 2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * m + 1], pk[4 * m + 3], false, false);
+            const c64_u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+            *reinterpret_cast<c64_u32x4*>(obase + pt * orow + m * 32) = o;
+          }
         }
-        V[q] = sm;
-        V[4 + q] = sq;
       }
       if (fuse_stats && !(PRG_C64_EXP & 4)) {
         // 8 full-wave sums with a halving butterfly (conv_ws.hip's, one level shorter): fixed order, deterministic
@@ -294,11 +311,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           __hip_atomic_store(&L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 2)], D,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (L.gn_tickets) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials have left this CU before barrier (2)
       }
-      c64_barrier();                                       // (2) stage written; halo s+1 written by the producers
     }
-    c64_barrier();                                         // matches the producers' final barrier
+    if (fuse_stats && L.gn_tickets) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsteps & 1) c64_barrier();                         // the producers' padding step
+    c64_barrier();                                         // matches the producers' final barrier (ticket of the last tile)
     return;
   }
 
@@ -315,14 +332,17 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
       hy[k] = hp / HP;
       hx[k] = hp - hy[k] * HP;
     }
-    c64_u32x4 hreg[KU];
+    // Two register sets: halo h lives in set h & 1.  The loads of halo s+2 are issued BEFORE halo s+1 is transformed and
+    // written, so HBM requests are in flight during the prologue arithmetic (with one set the re-issue had to wait for
+    // the transform: every CU computed while HBM idled, then every CU loaded — the two times added up).
+    c64_u32x4 hA[KU], hB[KU];
     const int tpi = tiles_x * tiles_y;                     // tiles per image
     int done_in_img = 0;                                   // tiles of the current image this workgroup has finished
     unsigned okmask = 0, okmask_nxt = 0;
     float4 ca[2], cb[2], ca_n[2], cb_n[2];
-    auto issue = [&](int s) {                              // loads of halo s into hreg
+    auto issue = [&](int s, c64_u32x4(&h)[KU]) {           // loads of halo s (clamped to the last tile: harmless reloads)
       int b, y0, x0;
-      c64_tile(first + s * stride, tiles_x, tiles_y, b, y0, x0);
+      c64_tile(first + min(s, nsteps - 1) * stride, tiles_x, tiles_y, b, y0, x0);
       okmask_nxt = 0;
       const bf16_t* src = L.src0 + (size_t)b * d.Hin * d.Win * 64 + slot * 8;
       const int yd = y0 >> d.ups, xd = x0 >> d.ups;        // the tile origin: always mapped (stand-in for padding taps)
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         x >>= d.ups;
         y = ok ? y : yd;                                   // every load is issued unconditionally (no branch per unit)
         x = ok ? x : xd;
-        hreg[k] = *reinterpret_cast<const c64_u32x4*>(src + ((size_t)y * d.Win + x) * 64);
+        h[k] = *reinterpret_cast<const c64_u32x4*>(src + ((size_t)y * d.Win + x) * 64);
         okmask_nxt |= (ok ? 1u : 0u) << k;
       }
       if constexpr (PRO) {
@@ -347,63 +367,37 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         cb_n[1] = *reinterpret_cast<const float4*>(pb + 4);
       }
     };
-    auto write = [&](int s) {                              // hreg (halo s) -> LDS buffer s & 1
+    auto write = [&](int s, c64_u32x4(&h)[KU]) {           // halo s -> LDS buffer s & 1
       char* dst = ah + (size_t)(s & 1) * AH_BYTES;
       const float a8[8] = {ca[0].x, ca[0].y, ca[0].z, ca[0].w, ca[1].x, ca[1].y, ca[1].z, ca[1].w};
       const float b8[8] = {cb[0].x, cb[0].y, cb[0].z, cb[0].w, cb[1].x, cb[1].y, cb[1].z, cb[1].w};
 #pragma unroll
       for (int k = 0; k < KU; ++k) {
-        const int hp = k * RPP + row;
-        if (hp < HALO) {
-          c64_u32x4 v = hreg[k];
-          if constexpr (PRO && !(PRG_C64_EXP & 32)) {
+        c64_u32x4 v = h[k];
+        if constexpr (PRO && !(PRG_C64_EXP & 32)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float lo = c64_silu(fmaf(c64_lo(v[j]), a8[2 * j], b8[2 * j]));
-              const float hh = c64_silu(fmaf(c64_hi(v[j]), a8[2 * j + 1], b8[2 * j + 1]));
-              v[j] = c64_pack(lo, hh);
-            }
+          for (int j = 0; j < 4; ++j) {
+            const float lo = c64_silu(fmaf(c64_lo(v[j]), a8[2 * j], b8[2 * j]));
+            const float hh = c64_silu(fmaf(c64_hi(v[j]), a8[2 * j + 1], b8[2 * j + 1]));
+            v[j] = c64_pack(lo, hh);
           }
-          if (!((okmask >> k) & 1u)) v = c64_u32x4{0u, 0u, 0u, 0u};
-          *reinterpret_cast<c64_u32x4*>(dst + k * RPP * ROWB) = v;
         }
+        if (!((okmask >> k) & 1u)) v = c64_u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<c64_u32x4*>(dst + k * RPP * ROWB) = v;
       }
     };
-    auto drain = [&](int s) {                              // stage (tile s) -> HBM: 8 lanes write one pixel's 128 bytes
-      int b, y0, x0;
-      c64_tile(first + s * stride, tiles_x, tiles_y, b, y0, x0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int u = ptid + 256 * j;                       // 2048 units: [wm][pixel 0..127][wn][unit q]
-        const int wm = u >> 10, px = (u >> 3) & 127, wn = (u >> 2) & 1, q = u & 3;
-        const c64_u32x4 v =
-            *reinterpret_cast<const c64_u32x4*>(stage + (wm * 2 + wn) * (128 * 64) + px * 64 + ((q ^ ((px >> 1) & 3)) << 4));
-        const int y = y0 + wm * 4 + (px >> 5), x = x0 + (px & 31);
-        *reinterpret_cast<c64_u32x4*>(L.out + (((size_t)b * Hl + y) * Wl + x) * 64 + wn * 32 + q * 8) = v;
-      }
-    };
-    auto adopt = [&]() {
+    auto adopt = [&]() {                                   // the validity mask and coefficients of the halo about to be written
       okmask = okmask_nxt;
       if constexpr (PRO) {
         ca[0] = ca_n[0]; ca[1] = ca_n[1]; cb[0] = cb_n[0]; cb[1] = cb_n[1];
       }
     };
-    issue(0);
+    issue(0, hA);
     adopt();
-    write(0);
-    if (nsteps > 1) issue(1);
+    write(0, hA);
+    issue(1, hB);
     c64_barrier();                                         // halo 0 ready
-    for (int s = 0; s < nsteps; ++s) {
-      // during the consumers' MFMAs of step s: halo s+1 into the buffer they left before barrier (1) of step s-1,
-      // the loads of halo s+2, and the drain of tile s-1 (in the stage since barrier (2) of step s-1)
-      if (s + 1 < nsteps && !(PRG_C64_EXP & 2)) {
-        adopt();
-        write(s + 1);
-        if (s + 2 < nsteps) issue(s + 2);
-      }
-      if (s > 0 && !(PRG_C64_EXP & 16)) drain(s - 1);
-      c64_barrier();                                       // (1) stage free
-      c64_barrier();                                       // (2) + the consumers' partial sums of tile s have left the CU
+    auto ticket = [&](int s) {                             // tile s is complete and its partial sums have left their CU
       if (fuse_stats && L.gn_tickets && ptid < 64) {       // first producer wave: per-image arrival ticket
         const int t = first + s * stride;
         const int img = t / tpi;
@@ -420,9 +414,28 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           done_in_img = 0;
         }
       }
+    };
+    // Two steps per iteration (the register set of a halo is a compile-time choice); an odd step count is padded with
+    // one step of clamped reloads that nobody reads, so the loop body stays branch-free between a load and its use and
+    // the compiler's s_waitcnt vmcnt(N) counts stay exact.
+    const int n2 = (nsteps + 1) & ~1;
+#pragma unroll 1
+    for (int s = 0; s < n2; s += 2) {
+      // during the consumers' MFMAs of step s and their epilogue of step s-1: the loads of halo s+2, then halo s+1 into
+      // the buffer they left before barrier s-1
+      adopt();
+      issue(s + 2, hA);
+      write(s + 1, hB);
+      c64_barrier();                                       // barrier s
+      if (s > 0) ticket(s - 1);                            // the consumers stored tile s-1's partial sums before this barrier
+      adopt();
+      issue(s + 3, hB);
+      write(s + 2, hA);
+      c64_barrier();                                       // barrier s+1
+      if (s < nsteps) ticket(s);
     }
-    drain(nsteps - 1);
     c64_barrier();
+    if (n2 == nsteps) ticket(nsteps - 1);
   }
 }
 
