@@ -31,7 +31,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mxfp8": 5000.0}   # dense, M
 def conv_sources_hash():
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv_ws.hip", "conv_c64.hip", "conv.hip", "conv.h", "common.h"):
+    for f in ("conv_ws.hip", "conv_c64.hip", "conv_w256.hip", "conv.hip", "conv.h", "common.h"):
         h.update(open(os.path.join(ROOT, "pointreggpt_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

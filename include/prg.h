@@ -156,6 +156,10 @@ int prg_unet_get_tap(prg_unet* h, const char* name, float* out, int64_t out_capa
  * (Cout) float32 HOST or NULL, out (B,Cout,H,W) float32 DEVICE (the bf16 result widened).  Synchronises.           */
 int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                       int dtype, void* stream);
+/* The same for Downsample's Conv2d(Cin, Cout, 4, stride 2, pad 1) (sd:596-597) in bf16: w (Cout,Cin,4,4),
+ * out (B,Cout,H/2,W/2).                                                                                             */
+int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler: GaussianDiffusion.sample / p_sample_loop / ddim_sample (sd:1283-1409), DDNM replacement included

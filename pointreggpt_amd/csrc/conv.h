@@ -58,7 +58,15 @@ struct ConvLaunch {
   // [tap][64-channel chunk][CoutPad][64] with one E8M0 scale per 32 input channels [tap][chunk][CoutPad][2]; null = bf16.
   const uint8_t* w_mx;
   const uint8_t* w_mx_scale;
+  // Conv2d(C, Cout, 4, stride 2, pad 1) only: the same weights as the 3 x 3 packing of the equivalent 2 x 2-tap
+  // convolution over the space-to-depth view of the shifted input ([Cout][4 C][3][3], taps (1..2, 1..2) non-zero; virtual
+  // channel (2 dy + dx) C + c, tap (1 + by, 1 + bx) = W[.][c][2 by + dy][2 bx + dx]); null = not available.  conv_w256.hip
+  const T* w_s2d;
+  int s2d_kchunks;
 };
+
+// OIHW weights of the equivalent convolution described at ConvLaunch::w_s2d, from Conv2d(Cin, Cout, 4, 2, 1) weights
+void s2d_equivalent_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>& out);
 
 // MX (OCP microscaling) fp8 packing of a conv weight: per (tap, output channel) the input channels are cut into blocks of
 // 32; block scale = 2^(floor(log2 max|w|) - 8) as an E8M0 byte (bias 127), elements = e4m3fn(w / scale), round to

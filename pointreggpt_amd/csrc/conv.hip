@@ -861,6 +861,9 @@ static int try_mx(const ConvLaunch<float>&, hipStream_t, int*) { return 0; }
 int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_ws.hip
 int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done);  // conv_c64.hip
 int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_w256.hip
+int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s);                       // conv_w256.hip
+static inline int try_down(const ConvLaunch<bf16_t>& L, hipStream_t s) { return try_launch_conv4x4s2_w256(L, s); }
+static inline int try_down(const ConvLaunch<float>&, hipStream_t) { return 0; }
 static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done) {
   int r = try_launch_conv3x3_c64(L, s, n, coef_done);        // weights-stationary kernel for the 64 -> 64 convs
   if (r == 0) r = try_launch_conv3x3_w256(L, s, n);          // 256-pixel x 128-channel tiles where the launch fills the chip
@@ -888,7 +891,8 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* 
     if (r == 1) return PRG_OK;
   }
   {
-    const int r = try_ws(L, s, gn_nsplit_out, coef_done);   // persistent kernels of the bf16 throughput path
+    int r = try_ws(L, s, gn_nsplit_out, coef_done);         // persistent kernels of the bf16 throughput path
+    if (r == 0 && !L.gn_partials) r = try_down(L, s);       // Downsample (4 x 4, stride 2) as a 2 x 2-tap conv of the same kernel
     if (r < 0) return r;
     if (r == 1) return PRG_OK;
   }
@@ -906,6 +910,18 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* 
   if (d.CoutPad % 128 == 0) return launch_igemm<T, 128, 128>(L, M, s, want_stats, gn_nsplit_out);
   if (M >= 256 * 64) return launch_igemm<T, 256, 64>(L, M, s, want_stats, gn_nsplit_out);
   return launch_igemm<T, 128, 64>(L, M, s, want_stats, gn_nsplit_out);
+}
+
+void s2d_equivalent_weights(const float* w, int Cout, int Cin, std::vector<float>& out) {
+  out.assign((size_t)Cout * 4 * Cin * 9, 0.0f);
+  for (int o = 0; o < Cout; ++o)
+    for (int c = 0; c < Cin; ++c)
+      for (int ky = 0; ky < 4; ++ky)
+        for (int kx = 0; kx < 4; ++kx) {
+          const int by = ky >> 1, dy = ky & 1, bx = kx >> 1, dx = kx & 1;
+          const int cv = (2 * dy + dx) * Cin + c;
+          out[(((size_t)o * 4 * Cin + cv) * 3 + 1 + by) * 3 + 1 + bx] = w[(((size_t)o * Cin + c) * 4 + ky) * 4 + kx];
+        }
 }
 
 template int launch_conv<float>(const ConvLaunch<float>&, hipStream_t, int*, int*);

@@ -22,7 +22,17 @@
 // writes of the units past the halo end) + 3 weight slots x 128 rows x 144 B + bias = 157 KB, one workgroup per CU.
 // Covers the 3x3 / stride 1 / pad 1 convs with Cout % 128 == 0 and 64-channel sources whose launch has at least one tile
 // per CU: tiles of 8 x 32 pixels (image widths 32, 64, 128, ...) or 16 x 16 (the 16 x 16 level).
+//
+// MODE 1 — Downsample, Conv2d(C, Cout, 4, stride 2, pad 1) (sd:596-597), as the same kernel: with the input shifted by
+// (1, 1) the 4 x 4 window of output pixel (oy, ox) is exactly the 2 x 2 block of 2 x 2-pixel blocks (oy + {0,1},
+// ox + {0,1}), i.e. a 2 x 2-tap convolution over the space-to-depth view [H/2][W/2][4 C] of the input.  Nothing is
+// rearranged in memory: a 64-channel chunk of the 4 C virtual channels is one sub-pixel (dy, dx) of every block, so the
+// producers gather "virtual pixel" (y', x') of chunk (dy, dx) from source pixel (2 y' + dy - 1, 2 x' + dx - 1) — a
+// constant stride of two source pixels — and the step has four taps ((1,1), (1,2), (2,1), (2,2) of the 3 x 3 frame)
+// instead of nine; the weights are the standard 3 x 3 packing of the equivalent [Cout][4 C][3][3] tensor.  Cout = 64
+// runs with the second channel half of the consumers idle (the shape is HBM-bound).
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv.h"
 
@@ -108,21 +118,32 @@ struct W2Tiles {
   }
 };
 
-template <int TW, bool PRO>
+// phase p of a step: LDS row offset of its tap inside the halo, and the tap's index in the packed 3 x 3 weights
+template <int MODE, int HP>
+__device__ constexpr int w2_toff(int p) { return MODE ? (1 + p / 2) * HP + 1 + p % 2 : (p / 3) * HP + p % 3; }
+template <int MODE>
+__device__ constexpr int w2_tapid(int p) { return MODE ? (1 + p / 2) * 3 + 1 + p % 2 : p; }
+
+template <int TW, bool PRO, int MODE>
 __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
                                                            const int tiles_n, const int fuse_stats) {
   using G = W2Geom<TW>;
   constexpr int TH = G::TH, HP = G::HP, KU = G::KU, RPP = G::RPP;
   constexpr int AH = (int)G::AH_BYTES, BW = (int)G::BW_BYTES;
+  // phases (taps) per step; steps per loop iteration: the weight ring slot / register set of global tile NPH g + p is
+  // (NPH g + p) % 3, a compile-time value once g % UNR is one (9 = 0, 4 = 1 mod 3)
+  constexpr int NPH = MODE ? 4 : 9, UNR = MODE ? 3 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const bias_lds = reinterpret_cast<float*>(smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES);
   const ConvDesc& d = L.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nchunks = (d.C0 + d.C1) / kCH;
+  const int nchunks = MODE ? 4 * d.C0 / kCH : (d.C0 + d.C1) / kCH;
+  const int nwn = d.Cout >= BN ? 2 : 1;                     // active channel halves (Cout = 64: the second half idles)
   W2Tiles tm;
   tm.init((int)blockIdx.x, (int)gridDim.x, tiles_x, tiles_y, tiles_n, d.B);
   const int nsteps = tm.count * nchunks;
   if (nsteps == 0) return;
+  const int nsteps_pad = (nsteps + UNR - 1) / UNR * UNR;    // the producers' loop body covers UNR steps (clamped reloads past the end)
 
   // ---------------------------------------------------------------------------------------------------
   if (wave < 4) {
@@ -138,9 +159,13 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     const char* xa = smem + (prow * HP + pcol) * ROWB + hi * 16;
     const char* xn = xa + AH;
     const char* const wr = smem + 2 * AH + (wn * 64 + l31) * ROWB + hi * 16;
-    if (tid < BN) bias_lds[tid] = L.bias[tm.tn * BN + tid];
+    if (tid < BN && tid < d.Cout) bias_lds[tid] = L.bias[tm.tn * BN + tid];
     const int gn_per = fuse_stats ? (d.Cout / L.gn_groups) >> 3 : 1;   // 8-channel chunks per GroupNorm group
     const int gn_per_sh = 31 - __builtin_clz(gn_per);
+    if (wn >= nwn) {                                         // idle channel half: only the barriers
+      for (int i = 0; i < 1 + nsteps_pad * NPH; ++i) w2_barrier<false>();
+      return;
+    }
     w2_f32x16 acc[2][4];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -154,46 +179,53 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
 #define W2_MM(SET, CT, PT) acc[CT][PT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[SET][CT], fx[SET][PT], acc[CT][PT], 0, 0, 0)
 #define W2_SB() __builtin_amdgcn_sched_barrier(0)
     w2_barrier<true>();                                      // halo 0 and weight tiles 0, 1 are in LDS; the bias too
-    W2_LW(0, 0, 0, 0); W2_LX(0, 0, xa, 0, 0); W2_LX(0, 1, xa, 0, 0); W2_LX(0, 2, xa, 0, 0); W2_LX(0, 3, xa, 0, 0); W2_LW(0, 1, 0, 0);
+    {
+      constexpr int t0 = w2_toff<MODE, HP>(0);
+      W2_LW(0, 0, 0, 0); W2_LX(0, 0, xa, t0, 0); W2_LX(0, 1, xa, t0, 0); W2_LX(0, 2, xa, t0, 0); W2_LX(0, 3, xa, t0, 0); W2_LW(0, 1, 0, 0);
+    }
     int chunk = 0, it = 0;
-    for (int g = 0; g < nsteps; ++g) {
+    // one step (NPH taps of one 64-channel chunk); GP = g % UNR fixes the ring slots at compile time
+    auto cstep = [&](auto GPc) {
+      constexpr int GP = decltype(GPc)::value;
       const bool tile_end = chunk == nchunks - 1;
 #pragma unroll
-      for (int p = 0; p < 9; ++p) {
-        const int toff = (p / 3) * HP + (p % 3);
-        const int pn = p == 8 ? 0 : p + 1;
-        const int toffN = (pn / 3) * HP + (pn % 3);
+      for (int p = 0; p < NPH; ++p) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ring = (GP * NPH + p) % 3, ringN = (ring + 1) % 3;
+        const int toff = w2_toff<MODE, HP>(p);
+        const int toffN = w2_toff<MODE, HP>(p == NPH - 1 ? 0 : p + 1);
 #pragma unroll
         for (int call = 0; call < ((PRG_W256_EXP & 1) ? 0 : 4); ++call) {
-          const int cur = call & 1, nxt = cur ^ 1;           // 36 calls per step: the set parity is the call parity
+          const int cur = call & 1, nxt = cur ^ 1;           // 4 NPH calls per step (even): the set parity is the call parity
           // the next call's six fragments, one load between two MFMAs, earliest-needed first
           if (call < 3) {
-            W2_LW(nxt, 0, p % 3, call + 1); W2_MM(cur, 0, 0); W2_SB();
+            W2_LW(nxt, 0, ring, call + 1); W2_MM(cur, 0, 0); W2_SB();
             W2_LX(nxt, 0, xa, toff, call + 1); W2_MM(cur, 0, 1); W2_SB();
             W2_LX(nxt, 1, xa, toff, call + 1); W2_MM(cur, 0, 2); W2_SB();
             W2_LX(nxt, 2, xa, toff, call + 1); W2_MM(cur, 0, 3); W2_SB();
             W2_LX(nxt, 3, xa, toff, call + 1); W2_MM(cur, 1, 0); W2_SB();
-            W2_LW(nxt, 1, p % 3, call + 1); W2_MM(cur, 1, 1); W2_SB();
-          } else if (p < 8) {                                // next tap: its weight tile is in ring slot (p + 1) % 3 since the last barrier
-            W2_LW(nxt, 0, (p + 1) % 3, 0); W2_MM(cur, 0, 0); W2_SB();
+            W2_LW(nxt, 1, ring, call + 1); W2_MM(cur, 1, 1); W2_SB();
+          } else if (p < NPH - 1) {                          // next tap: its weight tile is in the next ring slot since the last barrier
+            W2_LW(nxt, 0, ringN, 0); W2_MM(cur, 0, 0); W2_SB();
             W2_LX(nxt, 0, xa, toffN, 0); W2_MM(cur, 0, 1); W2_SB();
             W2_LX(nxt, 1, xa, toffN, 0); W2_MM(cur, 0, 2); W2_SB();
             W2_LX(nxt, 2, xa, toffN, 0); W2_MM(cur, 0, 3); W2_SB();
             W2_LX(nxt, 3, xa, toffN, 0); W2_MM(cur, 1, 0); W2_SB();
-            W2_LW(nxt, 1, (p + 1) % 3, 0); W2_MM(cur, 1, 1); W2_SB();
-          } else {                                           // next step: the other halo buffer (complete since barrier 7), ring slot 0
-            W2_LW(nxt, 0, 0, 0); W2_MM(cur, 0, 0); W2_SB();
+            W2_LW(nxt, 1, ringN, 0); W2_MM(cur, 1, 1); W2_SB();
+          } else {                                           // next step: the other halo buffer (complete since the previous barrier)
+            W2_LW(nxt, 0, ringN, 0); W2_MM(cur, 0, 0); W2_SB();
             W2_LX(nxt, 0, xn, toffN, 0); W2_MM(cur, 0, 1); W2_SB();
             W2_LX(nxt, 1, xn, toffN, 0); W2_MM(cur, 0, 2); W2_SB();
             W2_LX(nxt, 2, xn, toffN, 0); W2_MM(cur, 0, 3); W2_SB();
             W2_LX(nxt, 3, xn, toffN, 0); W2_MM(cur, 1, 0); W2_SB();
-            W2_LW(nxt, 1, 0, 0); W2_MM(cur, 1, 1); W2_SB();
+            W2_LW(nxt, 1, ringN, 0); W2_MM(cur, 1, 1); W2_SB();
           }
           W2_MM(cur, 1, 2);
           W2_MM(cur, 1, 3);
           W2_SB();
         }
-        if (p == 8 && tile_end) {
+        if (p == NPH - 1 && tile_end) {
           // tile finished.  Lane holds pixel (group pt, lpx), channels ct*32 + 8q + 4hi + {0..3} of the wave's 64.
           int tb, ty0, tx0;
           tm.decode(it, tb, ty0, tx0, TH, TW);
@@ -280,6 +312,15 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
         chunk = 0;
         ++it;
       }
+    };
+    for (int g = 0; g < nsteps_pad; g += UNR) {
+      cstep(std::integral_constant<int, 0>{});
+      if constexpr (UNR == 3) {
+        if (g + 1 < nsteps) cstep(std::integral_constant<int, 1>{});
+        else for (int i = 0; i < NPH; ++i) w2_barrier<false>();
+        if (g + 2 < nsteps) cstep(std::integral_constant<int, 2>{});
+        else for (int i = 0; i < NPH; ++i) w2_barrier<false>();
+      }
     }
 #undef W2_LW
 #undef W2_LX
@@ -301,14 +342,19 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
       const int hp = k * RPP + row;
       const int hy = hp / HP, hx = hp - hy * HP;
       int ry = hy - 1, rx = hx - 1;                          // tile origins are even: the x2 gather is (origin / 2) + (r >> 1)
-      if (d.ups) { ry >>= 1; rx >>= 1; }
-      hpix[k] = (unsigned)((ry + 1) * d.Win + (rx + 1));
+      if (!MODE && d.ups) { ry >>= 1; rx >>= 1; }
+      hpix[k] = (unsigned)((ry + 1) * d.Win + (rx + 1));     // MODE 1: in units of two source pixels (a virtual row = 2 Win pixels)
       hedge[k] = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) |
-                 (hp >= G::HALO ? 16u : 0u);
+                 (hp >= G::HALO ? 16u : 0u) | (hy == 1 ? 32u : 0u) | (hx == 1 ? 64u : 0u);
     }
+    const bf16_t* const wbase = MODE ? L.w_s2d : L.w;
+    const int wkch = MODE ? L.s2d_kchunks : d.kchunks;
     // this thread's first unit of a weight tile inside a tap's [2][CoutPad][32] slab; rows row + 32 j are 2048 bytes apart
     const unsigned w_voff = (unsigned)((((slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8) * 2);
-    const unsigned ld_dummy = (unsigned)(d.Win + 1);         // the tile origin: always mapped, stand-in for padding taps
+    const int wj_mask = nwn == 2 ? 3 : 1;                    // Cout = 64: only 64 weight rows exist (the upper ones are re-read)
+    // an always-mapped stand-in for padding taps: the tile origin; MODE 1: one virtual pixel further in (its sub-pixel
+    // (0,0) at the image's top-left tile would be source pixel (-1,-1))
+    const unsigned ld_dummy = (unsigned)(MODE ? 2 * d.Win + 2 : d.Win + 1);
     struct StepInfo { int chunk, it, b, y0, x0; };
     int gC = 0;
     auto advance = [&](StepInfo& si) {                       // past the last step it stays there: harmless reloads
@@ -338,15 +384,28 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     const float* ld_ca = nullptr;
     const float* ld_cb = nullptr;
     auto issue_setup = [&](const StepInfo& si) {
-      const int c = si.chunk * kCH;
-      const bool first = c < d.C0;
-      const bf16_t* src = first ? L.src0 : L.src1;
-      const int cs = first ? d.C0 : d.C1;
-      const int cc = first ? c : c - d.C0;
-      ld_cs2 = (unsigned)(cs * 2);
-      ld_tedge = (si.y0 == 0 ? 1u : 0u) | (si.y0 + TH == Hl ? 2u : 0u) | (si.x0 == 0 ? 4u : 0u) | (si.x0 + TW == Wl ? 8u : 0u) | 16u;
-      const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> d.ups)) * d.Win + (si.x0 >> d.ups) - (d.Win + 1);
-      ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
+      if constexpr (MODE == 1) {
+        // chunk = sub-pixel (dy, dx) of the 2 x 2 blocks, then 64 of its C0 channels.  Virtual pixel (y', x') of the chunk
+        // is source pixel (2 y' + dy - 1, 2 x' + dx - 1): outside the image for y' = 0 with dy = 0 and for y' = Hout
+        // with dy = 1 (x alike); halo row / column 0 is never multiplied (its taps carry zero weights) and written as zeros
+        const int nsub = d.C0 / kCH, sp = si.chunk / nsub, cc = (si.chunk - sp * nsub) * kCH;
+        const int dy = sp >> 1, dx = sp & 1;
+        ld_cs2 = (unsigned)(d.C0 * 4);
+        ld_tedge = 1u | 4u | 16u | (dy == 0 && si.y0 == 0 ? 32u : 0u) | (dy == 1 && si.y0 + TH == Hl ? 2u : 0u) |
+                   (dx == 0 && si.x0 == 0 ? 64u : 0u) | (dx == 1 && si.x0 + TW == Wl ? 8u : 0u);
+        const int64_t horg = ((int64_t)si.b * d.Hin + 2 * si.y0 + dy - 3) * d.Win + 2 * si.x0 + dx - 3;   // halo position (0, 0)
+        ld_base = reinterpret_cast<const char*>(L.src0) + (horg * d.C0 + cc) * 2;
+      } else {
+        const int c = si.chunk * kCH;
+        const bool first = c < d.C0;
+        const bf16_t* src = first ? L.src0 : L.src1;
+        const int cs = first ? d.C0 : d.C1;
+        const int cc = first ? c : c - d.C0;
+        ld_cs2 = (unsigned)(cs * 2);
+        ld_tedge = (si.y0 == 0 ? 1u : 0u) | (si.y0 + TH == Hl ? 2u : 0u) | (si.x0 == 0 ? 4u : 0u) | (si.x0 + TW == Wl ? 8u : 0u) | 16u;
+        const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> d.ups)) * d.Win + (si.x0 >> d.ups) - (d.Win + 1);
+        ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
+      }
       if constexpr (PRO) {
         const size_t o = (size_t)si.b * d.C0 + si.chunk * kCH + slot * 8;
         ld_ca = L.pro_a + o;
@@ -384,17 +443,20 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
       if (!((hvalid >> k) & 1u)) v = w2_u32x4{0u, 0u, 0u, 0u};
       *reinterpret_cast<w2_u32x4*>(Ah0 + bufoff + k * RPP * ROWB) = v;
     };
-    auto w_tile = [&](int tap, int chunk) -> const char* {
-      return reinterpret_cast<const char*>(L.w) + ((size_t)(tap * d.kchunks + 2 * chunk) * d.CoutPad + tm.tn * BN) * 64 + w_voff;
+    // weight tile of phase `ph` (its tap in the packed 3 x 3 layout) and 64-channel chunk
+    auto w_tile = [&](int ph, int chunk) -> const char* {
+      return reinterpret_cast<const char*>(wbase) + ((size_t)(w2_tapid<MODE>(ph) * wkch + 2 * chunk) * d.CoutPad + tm.tn * BN) * 64 + w_voff;
     };
     auto w_issue = [&](int set, const char* p) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wset[set][j] = *reinterpret_cast<const w2_u32x4*>(p + ((PRG_W256_EXP & 8) ? 0 : j * 2048));
+      for (int j = 0; j < 4; ++j) wset[set][j] = *reinterpret_cast<const w2_u32x4*>(p + ((PRG_W256_EXP & 8) ? 0 : (j & wj_mask) * 2048));
     };
     auto w_write = [&](int set, int ring) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<w2_u32x4*>(Bw0 + ring * BW + j * 32 * ROWB) = wset[set][j];
     };
+    // global weight tile t (t < 3 NPH) belongs to step t / NPH of (sA, sB, sC)
+    auto chunk_of = [&](int t) { return t < NPH ? sA.chunk : t < 2 * NPH ? sB.chunk : sC.chunk; };
 
     // ---- prologue: halo 0 and weight tiles 0, 1 into LDS; halo 1 and tiles 2, 3, 4 into registers
     issue_setup(sA);
@@ -402,8 +464,8 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
 #pragma unroll
     for (int k = 0; k < KU; ++k) issue_unit(k);
     hvalid = hvalid_nxt;
-    w_issue(0, w_tile(0, 0));
-    w_issue(1, w_tile(1, 0));
+    w_issue(0, w_tile(0, chunk_of(0)));
+    w_issue(1, w_tile(1, chunk_of(1)));
 #pragma unroll
     for (int k = 0; k < KU; ++k) write_unit(k, 0);
     w_write(0, 0);
@@ -415,30 +477,30 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     hvalid = hvalid_nxt;
 #pragma unroll
     for (int j = 0; j < 4; ++j) cf[j] = nf[j];
-    w_issue(2, w_tile(2, 0));
-    w_issue(0, w_tile(3, 0));
-    w_issue(1, w_tile(4, 0));
+    w_issue(2, w_tile(2 % NPH, chunk_of(2)));
+    w_issue(0, w_tile(3 % NPH, chunk_of(3)));
+    w_issue(1, w_tile(4 % NPH, chunk_of(4)));
     issue_setup(sC);
     w2_barrier<true>();
 
-    // units of halo s+1 written (and re-issued for halo s+2) in phases 0..7: 2 2 2 1 1 1 1 1
-    constexpr int US[10] = {0, 2, 4, 6, 7, 8, 9, 10, 11, 11};
-#pragma unroll 1
-    for (int g = 0; g < nsteps; ++g) {
+    // units of halo s+1 written (and re-issued for halo s+2) in phases 0 .. NPH-2: 2 2 2 1 1 1 1 1 (nine taps), 4 4 3 (four)
+    constexpr int US9[10] = {0, 2, 4, 6, 7, 8, 9, 10, 11, 11};
+    constexpr int US4[5] = {0, 4, 8, 11, 11};
+    auto pstep = [&](auto GPc, int g) {
+      constexpr int GP = decltype(GPc)::value;
       const int bufoff = ((g + 1) & 1) * AH;
-      const int ch0 = sA.chunk, ch1 = sB.chunk;
 #pragma unroll
-      for (int p = 0; p < 9; ++p) {
-        const int set = (p + 2) % 3;
-        w_write(set, set);                                   // weight tile 9g + p + 2 (loaded three phases ago)
+      for (int p = 0; p < NPH; ++p) {
+        const int set = (GP * NPH + p + 2) % 3;
+        const int u0 = MODE ? US4[p] : US9[p], u1 = MODE ? US4[p + 1] : US9[p + 1];
+        w_write(set, set);                                   // weight tile NPH g + p + 2 (loaded three phases ago)
 #pragma unroll
-        for (int k = US[p]; k < US[p + 1]; ++k) write_unit(k, bufoff);
+        for (int k = u0; k < u1; ++k) write_unit(k, bufoff);
         if (p == 0) issue_coeffs(nf);                        // coefficients of halo g + 2
-        const int tapn = (p + 5) % 9;                        // weight tile 9g + p + 5: this step's or the next one's chunk
-        w_issue(set, w_tile(tapn, p + 5 < 9 ? ch0 : ch1));
+        w_issue(set, w_tile((p + 5) % NPH, chunk_of(p + 5)));   // weight tile NPH g + p + 5: this step's or a later one's chunk
 #pragma unroll
-        for (int k = US[p]; k < US[p + 1]; ++k) issue_unit(k);
-        if (p == 8) {                                        // step bookkeeping (wave-uniform) in the phase without halo work
+        for (int k = u0; k < u1; ++k) issue_unit(k);
+        if (p == NPH - 1) {                                  // step bookkeeping (wave-uniform) in the phase without halo work
           hvalid = hvalid_nxt;
 #pragma unroll
           for (int j = 0; j < 4; ++j) cf[j] = nf[j];
@@ -448,6 +510,14 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
           issue_setup(sC);
         }
         w2_barrier<true>();
+      }
+    };
+#pragma unroll 1
+    for (int g = 0; g < nsteps_pad; g += UNR) {
+      pstep(std::integral_constant<int, 0>{}, g);
+      if constexpr (UNR == 3) {
+        pstep(std::integral_constant<int, 1>{}, g + 1);
+        pstep(std::integral_constant<int, 2>{}, g + 2);
       }
     }
   }
@@ -493,10 +563,10 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
                    tiles_x * tiles_y * 2 <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
   const int pro = L.pro_a ? 1 : 0;
-  const void* fn = tw == 32 ? (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, true>)
-                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, false>))
-                            : (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, true>)
-                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, false>));
+  const void* fn = tw == 32 ? (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, true, 0>)
+                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, false, 0>))
+                            : (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, true, 0>)
+                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, false, 0>));
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
   static bool attr_done[2][2] = {{false, false}, {false, false}};
   if (!attr_done[tw == 32][pro]) {
@@ -506,12 +576,58 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
   if (tw == 32) {
-    if (pro) conv3x3_w256_kernel<32, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
-    else conv3x3_w256_kernel<32, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro) conv3x3_w256_kernel<32, true, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256_kernel<32, false, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
   } else {
-    if (pro) conv3x3_w256_kernel<16, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
-    else conv3x3_w256_kernel<16, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro) conv3x3_w256_kernel<16, true, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256_kernel<16, false, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
   }
+  PRG_LAUNCH_CHECK();
+  return 1;
+}
+
+// Conv2d(C, Cout, 4, stride 2, pad 1) through the same kernel (MODE 1).  Returns 1 / 0 / negative like the entry above.
+int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
+  static const int enabled = [] {
+    const char* e = std::getenv("PRG_CONV_DOWN_W256");
+    return e ? std::atoi(e) : 1;
+  }();
+  if (!enabled || !L.w_s2d) return 0;
+  const ConvDesc& d = L.d;
+  if (!(d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 1 && d.ups == 0 && d.C1 == 0)) return 0;
+  if (d.C0 % kCH || d.C0 == 0 || d.C0 > 128 || (d.Cout != 64 && d.Cout % BN) || d.CoutPad != d.Cout) return 0;
+  if (L.residual || !L.bias || L.pro_a || L.gn_partials) return 0;
+  if (d.Hin != 2 * d.Hout || d.Win != 2 * d.Wout) return 0;
+  const int tiles_n = d.Cout == 64 ? 1 : d.Cout / BN;
+  if (tiles_n != 1 && tiles_n != 2 && tiles_n != 4 && tiles_n != 8) return 0;
+  const int H = d.Hout, W = d.Wout;
+  int tw = 0;
+  if (W % 32 == 0 && H % 8 == 0) tw = 32;
+  else if (W % 16 == 0 && H % 16 == 0) tw = 16;
+  else return 0;
+  const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
+  const long total = (long)tiles_x * tiles_y * tiles_n * d.B;
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    num_cus = p.multiProcessorCount;
+  }
+  const int grid = num_cus & ~7;
+  static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
+  if (grid < 8 || total < (min_fill > 0 ? min_fill : grid / 2)) return 0;   // the generic kernel for tiny launches
+  const void* fn = tw == 32 ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, false, 1>)
+                            : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, false, 1>);
+  const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[tw == 32]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 downsample): ") + hipGetErrorString(e));
+    attr_done[tw == 32] = true;
+  }
+  if (tw == 32) conv3x3_w256_kernel<32, false, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
+  else conv3x3_w256_kernel<16, false, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
   PRG_LAUNCH_CHECK();
   return 1;
 }

@@ -80,6 +80,8 @@ struct ConvP {
   bool ws = false;         // weight-standardised (Block.proj)
   int64_t mx_off = -1;     // byte offset of the MX-fp8 copy of the weights (-1: none) and of its block scales
   int64_t mx_soff = -1;
+  int64_t s2d_off = -1;    // 4x4 / stride 2 convs (bf16): element offset of the equivalent 2x2-tap packing (ConvLaunch::w_s2d)
+  int s2d_kchunks = 0;
 };
 struct ResP {
   int cin = 0, cout = 0;
@@ -300,6 +302,8 @@ struct UnetImpl : prg_unet {
     L.gn_partials = o.gn_partials; L.gn_groups = lay.cfg.groups; L.pro_a = o.pro_a; L.pro_b = o.pro_b;
     L.w_mx = (d_mx && p.mx_off >= 0) ? d_mx + p.mx_off : nullptr;
     L.w_mx_scale = (d_mx_scale && p.mx_soff >= 0) ? d_mx_scale + p.mx_soff : nullptr;
+    L.w_s2d = (p.s2d_off >= 0 && stride == 2 && pad == 1) ? reinterpret_cast<const T*>(d_packed) + p.s2d_off : nullptr;
+    L.s2d_kchunks = p.s2d_kchunks;
     L.gn = o.gn ? *o.gn : GnApply{};
     L.gn_coef_a = o.gn ? o.coef_a : nullptr; L.gn_coef_b = o.gn ? o.coef_b : nullptr;
     L.gn_tickets = (o.gn && gn_fold_enabled()) ? d_tickets : nullptr;
@@ -665,6 +669,17 @@ static void pack_all(Layout& L, const float* flat, std::vector<T>& packed) {
     packed.resize(off + one.size());
     std::memcpy(packed.data() + off, one.data(), one.size() * sizeof(T));
     p->w_off = off;
+    if (std::is_same<T, bf16_t>::value && p->KH == 4 && p->KW == 4 && p->Cin % 64 == 0 && p->Cout % 64 == 0) {
+      // Downsample: second packing for the 256-pixel kernel's 2 x 2-tap mode (conv_w256.hip)
+      std::vector<float> eq;
+      s2d_equivalent_weights(w, p->Cout, p->Cin, eq);
+      int cp = 0;
+      pack_conv_weight<T>(eq.data(), p->Cout, 4 * p->Cin, 3, 3, one, &cp, &p->s2d_kchunks);
+      off = (packed.size() + 127) / 128 * 128;
+      packed.resize(off + one.size());
+      std::memcpy(packed.data() + off, one.data(), one.size() * sizeof(T));
+      p->s2d_off = (int64_t)off;
+    }
   }
 }
 
@@ -1018,16 +1033,26 @@ int prg_maskunet_forward(prg_unet* h, const float* depth, float* prob, int B, in
 }
 
 // ---------------------------------------------------------------------------------------------
-int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
-                      int dtype, void* stream) {
+static int debug_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                      int dtype, int K, int stride, void* stream) {
   PRG_CHECK(x && w && out, "prg_debug_conv3x3: null pointer");
   PRG_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0, "prg_debug_conv3x3: bad shape");
   PRG_CHECK(dtype == PRG_BF16 || dtype == PRG_MXFP8, "prg_debug_conv3x3: dtype must be PRG_BF16 or PRG_MXFP8");
   hipStream_t s = (hipStream_t)stream;
   const size_t M = (size_t)B * H * W;
+  const int Ho = H / stride, Wo = W / stride;
+  const size_t Mo = (size_t)B * Ho * Wo;
   std::vector<bf16_t> packed;
   int cp = 0, kc = 0;
-  pack_conv_weight<bf16_t>(w, Cout, Cin, 3, 3, packed, &cp, &kc);
+  pack_conv_weight<bf16_t>(w, Cout, Cin, K, K, packed, &cp, &kc);
+  std::vector<bf16_t> packed_s2d;
+  int kc_s2d = 0;
+  if (K == 4 && Cin % 64 == 0 && Cout % 64 == 0) {
+    std::vector<float> eq;
+    int cp2 = 0;
+    s2d_equivalent_weights(w, Cout, Cin, eq);
+    pack_conv_weight<bf16_t>(eq.data(), Cout, 4 * Cin, 3, 3, packed_s2d, &cp2, &kc_s2d);
+  }
   std::vector<uint8_t> mxd, mxs;
   if (dtype == PRG_MXFP8) {
     PRG_CHECK(Cin % 64 == 0 && Cout % 64 == 0, "prg_debug_conv3x3: MX-fp8 needs 64-channel multiples");
@@ -1035,15 +1060,17 @@ int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* 
     pack_conv_weight_mxfp8(w, Cout, Cin, 3, 3, mxd, mxs, &cp2, &kc2);
   }
   std::vector<float> zb(Cout, 0.0f);
-  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_mxd = nullptr, *d_mxs = nullptr;
-  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_mxd, d_mxs}) if (p) hipFree(p); };
-  if (hipMalloc(&d_in, M * Cin * 2) != hipSuccess || hipMalloc(&d_out, M * Cout * 2) != hipSuccess ||
+  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_mxd = nullptr, *d_mxs = nullptr, *d_w2 = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_mxd, d_mxs, d_w2}) if (p) hipFree(p); };
+  if (hipMalloc(&d_in, M * Cin * 2) != hipSuccess || hipMalloc(&d_out, Mo * Cout * 2) != hipSuccess ||
+      (!packed_s2d.empty() && hipMalloc(&d_w2, packed_s2d.size() * 2) != hipSuccess) ||
       hipMalloc(&d_w, packed.size() * 2) != hipSuccess || hipMalloc(&d_b, Cout * 4) != hipSuccess ||
       (dtype == PRG_MXFP8 && (hipMalloc(&d_mxd, mxd.size()) != hipSuccess || hipMalloc(&d_mxs, mxs.size()) != hipSuccess))) {
     cleanup();
     return fail(PRG_E_NOMEM, "prg_debug_conv3x3: hipMalloc failed");
   }
   hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+  if (d_w2) hipMemcpy(d_w2, packed_s2d.data(), packed_s2d.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(d_b, bias ? bias : zb.data(), Cout * 4, hipMemcpyHostToDevice);
   if (dtype == PRG_MXFP8) {
     hipMemcpy(d_mxd, mxd.data(), mxd.size(), hipMemcpyHostToDevice);
@@ -1052,18 +1079,30 @@ int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* 
   int rc = launch_nchw_f32_to_nhwc<bf16_t>(x, reinterpret_cast<bf16_t*>(d_in), B, H * W, Cin, s);
   if (rc == PRG_OK) {
     ConvLaunch<bf16_t> L{};
-    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = 0; L.d.KH = 3; L.d.KW = 3; L.d.stride = 1; L.d.pad = 1;
-    L.d.Hout = H; L.d.Wout = W; L.d.Cout = Cout; L.d.CoutPad = cp; L.d.kchunks = kc;
+    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = 0; L.d.KH = K; L.d.KW = K; L.d.stride = stride; L.d.pad = 1;
+    L.d.Hout = Ho; L.d.Wout = Wo; L.d.Cout = Cout; L.d.CoutPad = cp; L.d.kchunks = kc;
     L.src0 = reinterpret_cast<const bf16_t*>(d_in); L.w = reinterpret_cast<const bf16_t*>(d_w);
     L.bias = reinterpret_cast<const float*>(d_b); L.out = reinterpret_cast<bf16_t*>(d_out);
     L.gn_groups = 8;
+    L.w_s2d = reinterpret_cast<const bf16_t*>(d_w2); L.s2d_kchunks = kc_s2d;
     L.w_mx = reinterpret_cast<const uint8_t*>(d_mxd); L.w_mx_scale = reinterpret_cast<const uint8_t*>(d_mxs);
     rc = launch_conv<bf16_t>(L, s, nullptr);
   }
-  if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<bf16_t>(reinterpret_cast<const bf16_t*>(d_out), out, B, H * W, Cout, s);
+  if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<bf16_t>(reinterpret_cast<const bf16_t*>(d_out), out, B, Ho * Wo, Cout, s);
   hipStreamSynchronize(s);
   cleanup();
   return rc;
+}
+
+int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                      int dtype, void* stream) {
+  return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, dtype, 3, 1, stream);
+}
+
+int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                        void* stream) {
+  PRG_CHECK(H % 2 == 0 && W % 2 == 0, "prg_debug_conv4x4s2: odd image size");
+  return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, PRG_BF16, 4, 2, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

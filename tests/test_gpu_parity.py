@@ -219,7 +219,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                 "c64_contiguous": {"PRG_C64_INTERLEAVE": "0"},   # contiguous instead of interleaved tile runs
                 # 256-pixel x 128-channel tiles wherever the shape allows (at these batch sizes the default dispatch keeps
                 # the 128-pixel tiles): fused prologue, x2 gather, two sources, statistics, 8x32 and 16x16 tiles
-                "w256_all": {"PRG_W256_MIN_TILES": "1"}, "no_w256": {"PRG_CONV_W256": "0"}}
+                "w256_all": {"PRG_W256_MIN_TILES": "1"}, "no_w256": {"PRG_CONV_W256": "0", "PRG_CONV_DOWN_W256": "0"}}
     for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
@@ -683,6 +683,40 @@ def test_conv3x3_kernels_one_at_a_time(hip, B, Cin, Cout, H, Wd):
     err = (got.double() - ref).abs()
     tol = 2.0 ** -8 * ref.abs() + 1e-4 * float(ref.abs().max())
     assert bool((err <= tol).all()), float((err - tol).max())
+
+
+DOWN_SHAPES = [(64, 64, 64, 64, 64),     # Cout = 64: second channel half of the consumers idle; 8 x 32 tiles, 256 of them
+               (32, 64, 128, 64, 64),    # 128 tiles: half the CUs
+               (64, 128, 256, 32, 32),   # 16 x 16 tiles, two sub-pixel chunks per source pixel, two channel tiles
+               (2, 64, 128, 16, 32)]     # too small for it: the generic implicit-GEMM kernel
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,Wd", DOWN_SHAPES)
+def test_downsample_conv4x4s2(hip, B, Cin, Cout, H, Wd):
+    """Downsample = Conv2d(C, Cout, 4, 2, 1) (sd:596-597): the 256-pixel kernel's 2 x 2-tap mode over the space-to-depth
+    view of the shifted input (and the generic kernel for small launches) against a float64 strided convolution of the
+    same bf16-rounded operands."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(Cin * 77 + Cout + H)
+    x = torch.randn((B, Cin, H, Wd), generator=g) * torch.exp(torch.randn((1, Cin, 1, 1), generator=g))
+    w = torch.randn((Cout, Cin, 4, 4), generator=g) / (4.0 * Cin ** 0.5)
+    bias = torch.randn((Cout,), generator=g)
+    lib = hip.lib.load()
+    out = torch.empty((B, Cout, H // 2, Wd // 2), dtype=torch.float32, device="cuda")
+    wh = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    bh = np.ascontiguousarray(bias.numpy(), dtype=np.float32)
+    hip.lib.check(lib.prg_debug_conv4x4s2(hip.lib.ptr(x.cuda().contiguous()), wh.ctypes.data_as(C.c_void_p),
+                                          bh.ctypes.data_as(C.c_void_p), hip.lib.ptr(out), B, Cin, Cout, H, Wd,
+                                          hip.lib.stream_ptr()), "prg_debug_conv4x4s2")
+    xb, wb = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    ref = torch.nn.functional.conv2d(xb.double()[:8], wb.double(), bias.double(), stride=2, padding=1)   # float64 on a slice
+    ref32 = torch.nn.functional.conv2d(xb, wb, bias, stride=2, padding=1)                                   # float32 on all
+    got = out.cpu()
+    tol = 2.0 ** -8 * ref.abs() + 1e-4 * float(ref.abs().max())
+    err = (got[:8].double() - ref).abs()
+    assert bool((err <= tol).all()), float((err - tol).max())
+    tol32 = 2.0 ** -7 * ref32.abs() + 1e-3 * float(ref32.abs().max())
+    assert bool(((got - ref32).abs() <= tol32).all())
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,Wd", CONV_SHAPES)

@@ -14,7 +14,7 @@ def avg(path, counter):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if r["Counter_Name"] != counter or not ("conv3x3_ws_kernel" in k or "conv3x3_c64_kernel" in k or "conv_igemm_kernel" in k or "conv3x3_halo_kernel" in k):
+        if r["Counter_Name"] != counter or not ("conv3x3_ws_kernel" in k or "conv3x3_c64_kernel" in k or "conv3x3_w256_kernel" in k or "conv_igemm_kernel" in k or "conv3x3_halo_kernel" in k):
             continue
         tot += float(r["Counter_Value"])
         n += 1
@@ -24,7 +24,7 @@ def avg(path, counter):
 f, nf = avg(sys.argv[1], "FETCH_SIZE")
 w, nw = avg(sys.argv[2], "WRITE_SIZE")
 out = {
-    "kernel_class": "conv3x3_ws_kernel + conv3x3_c64_kernel + conv_igemm_kernel (all MFMA convolution launches)",
+    "kernel_class": "conv3x3_ws_kernel + conv3x3_c64_kernel + conv3x3_w256_kernel + conv_igemm_kernel (all MFMA convolution launches)",
     "launches": nf,
     "fetch_size_kb_avg": f,
     "write_size_kb_avg": w,
@@ -37,7 +37,7 @@ out = {
     "kernel_sources_sha256": __import__("hashlib").sha256(b"".join(
         open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..",
                                         "pointreggpt_amd", "csrc", f), "rb").read()
-        for f in ("conv_ws.hip", "conv_c64.hip", "conv.hip", "conv.h", "common.h"))).hexdigest(),
+        for f in ("conv_ws.hip", "conv_c64.hip", "conv_w256.hip", "conv.hip", "conv.h", "common.h"))).hexdigest(),
 }
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
