@@ -36,7 +36,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int c64_u32x4;
 namespace {
 
 // Timing experiments only (results become garbage): -DPRG_C64_EXP=1 consumers skip fragment reads + MFMAs, 2 producers skip
-// the halo loads / writes, 4 no epilogue, 8 no priority raise, 32 producers skip only the prologue arithmetic.
+// the halo loads / writes, 4 no epilogue, 8 no priority raise, 32 producers skip only the prologue arithmetic, 256 SiLU
+// without transcendentals.
 #ifndef PRG_C64_EXP
 #define PRG_C64_EXP 0
 #endif
@@ -57,6 +58,7 @@ __device__ inline uint32_t c64_pack(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ inline float c64_silu(float x) {
+  if (PRG_C64_EXP & 256) return x * fmaf(fmaf(x, -1.4426950408889634f, 1.0f), x, 0.5f);   // timing experiment: no transcendentals
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 template <int CTRL>
