@@ -29,6 +29,13 @@ namespace {
 constexpr int kTP = 64;              // pixels per tile
 constexpr int kHid = 128;            // heads x dim_head
 constexpr int kTilesPerBlock = 8;
+// Linear attention: tiles per block as a function of the image size ONLY (a batch-independent slab structure keeps a
+// scene's result identical for every batch size): 8 from 64 x 64 pixels up, fewer for the small levels, whose launches
+// otherwise fill a quarter of the CUs with blocks that walk four tiles in series (16 x 16: 64 blocks -> 256).
+__host__ __device__ inline int la_tpb(int ntiles) {
+  const int t = ntiles / 8;
+  return t < 1 ? 1 : (t > kTilesPerBlock ? kTilesPerBlock : t);
+}
 constexpr int kLdO = kHid + 8;       // LDS row stride of 128-wide rows (bf16 elements)
 constexpr int kLdP = kTP + 8;        // LDS row stride of the transposed p / v tiles
 constexpr float kLnEps = 1e-5f;
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int ntiles = (N + kTP - 1) / kTP;
-  const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
+  const int tpb = la_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
   bf16x8 wk[G::KK];                                    // k rows 32 wave .. + 32 of the projection
   load_wfrags<C>(wk, wqkv, kHid + 32 * wave, l31, hi);
   float m = -INFINITY;                                 // column 32 wave + l31, this lane's pixel rows
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
   __bf16* pT = pv + wave * 2 * 32 * kLdP;
   __bf16* vT = pT + 32 * kLdP;
   const int ntiles = (N + kTP - 1) / kTP;
-  const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
+  const int tpb = la_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
   bf16x8 wk[G::KK], wv[G::KK];                         // k and v rows of head `wave`
   load_wfrags<C>(wk, wqkv, kHid + 32 * wave, l31, hi);
   load_wfrags<C>(wv, wqkv, 2 * kHid + 32 * wave, l31, hi);
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int ntiles = (N + kTP - 1) / kTP;
-  const int t0 = slab * kTilesPerBlock, t1 = min(t0 + kTilesPerBlock, ntiles);
+  const int tpb = la_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
   bf16x8 wq[G::KK];                                    // q rows of head `wave`
   load_wfrags<C>(wq, wqkv, 32 * wave, l31, hi);
   // ctx^T rows e = l31 of head `wave`; k-slot s of half hi in k-step i is d = 16 i + 8 (s >> 2) + 4 hi + (s & 3):
@@ -620,7 +627,8 @@ int set_lds(K kernel, size_t bytes) {
   return PRG_OK;
 }
 
-int la_slabs(int N) { return ceil_div(ceil_div(N, kTP), kTilesPerBlock); }
+int la_slabs(int N) { const int nt = ceil_div(N, kTP); return ceil_div(nt, la_tpb(nt)); }
+int tail_slabs(int N) { return ceil_div(ceil_div(N, kTP), kTilesPerBlock); }
 
 // =====================================================================================================
 // ResnetBlock tail with the 1x1 res_conv folded in (sd:731-734):
@@ -735,7 +743,7 @@ int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* 
     if (rc) return rc;
     attr = true;
   }
-  resblock_tail_fused_kernel<CIN, COUT><<<dim3(la_slabs(N), B), 256, lds, s>>>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, N);
+  resblock_tail_fused_kernel<CIN, COUT><<<dim3(tail_slabs(N), B), 256, lds, s>>>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, N);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }

@@ -58,6 +58,7 @@ struct ConvLaunch {
   // [tap][64-channel chunk][CoutPad][64] with one E8M0 scale per 32 input channels [tap][chunk][CoutPad][2]; null = bf16.
   const uint8_t* w_mx;
   const uint8_t* w_mx_scale;
+  int mx_pure;           // 1: never fall back to bf16 operands for shapes the 256-pixel MX kernel does not cover (unit tests)
   // Conv2d(C, Cout, 4, stride 2, pad 1) only: the same weights as the 3 x 3 packing of the equivalent 2 x 2-tap
   // convolution over the space-to-depth view of the shifted input ([Cout][4 C][3][3], taps (1..2, 1..2) non-zero; virtual
   // channel (2 dy + dx) C + c, tap (1 + by, 1 + bx) = W[.][c][2 by + dy][2 bx + dx]); null = not available.  conv_w256.hip

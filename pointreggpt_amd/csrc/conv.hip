@@ -840,8 +840,18 @@ static int launch_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats,
   return PRG_OK;
 }
 // MX-fp8 operands: 1 = launched, 0 = shape not covered (bf16 kernels run instead)
+int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_w256.hip
 static int try_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
   if (!L.w_mx || !L.w_mx_scale) return 0;
+  {
+    const int r = try_launch_conv3x3_w256mx(L, s, gn_nsplit_out);   // 256-pixel x 128-channel tiles with MX operands
+    if (r != 0) return r;
+  }
+  // Shapes the 256-pixel MX kernel does not cover (the 64-channel convs, launches with few tiles): by default the bf16
+  // kernels run them (those shapes are HBM- / VALU-bound: fp8 operands buy nothing there); PRG_MX_PURE=1 keeps every 3x3
+  // conv on MX operands through the simple halo-tile kernel below.
+  static const int pure = [] { const char* e = std::getenv("PRG_MX_PURE"); return e ? std::atoi(e) : 0; }();
+  if (!pure && !L.mx_pure) return 0;
   const ConvDesc& d = L.d;
   HaloPick<bf16_t> hp;
   if (!pick_halo<bf16_t>(d, &hp) || L.residual) return 0;

@@ -523,6 +523,399 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
   }
 }
 
+// =====================================================================================================================
+// MX-fp8 operands (BASELINE configs[4]) on the same 256-pixel x 128-channel structure.
+// Both MFMA operands are OCP e4m3 with one E8M0 scale per 32 channels; v_mfma_scale_f32_32x32x64_f8f6f4 contracts a whole
+// 64-channel chunk of a tap per instruction (64 cycles for four times the MACs of the bf16 instruction's 32: measured
+// 3.7-3.9 PFLOP/s on random data against 1.45-1.65 for bf16, tools/micro/mfma_power_fp8.hip).  A phase = 8 MFMAs = 512
+// cycles per consumer wave; its six operands (two 16-byte reads + one scale byte each) are prefetched during the previous
+// phase.  The producers quantise the bf16 activations while they write the halo (after the optional fused prologue, whose
+// result is rounded to bf16 first, like the tensor it replaces): the four lanes that hold one pixel's 32 consecutive channels
+// agree on the block maximum with two DPP exchanges, scale = 2^(floor(log2 max) - 8), elements by v_cvt_pk_fp8_f32
+// (arithmetic of conv3x3_mx_kernel in conv.hip and of oracle/mx.py).  Weights arrive quantised (pack_conv_weight_mxfp8).
+// LDS rows are 64 bytes padded to 80 (conflict-free ds_read_b128), scales sit in byte arrays beside them: 90 KB.
+// Operand layout (probed, tools/micro/mx_layout_probe.hip): lane l holds row / column l & 31; its 32 bytes are
+// k = 16 h + (0..15) and 32 + 16 h + (0..15), h = l >> 5; its scale covers k in [32 h, 32 h + 32).
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(8))) int w2_i32x8;
+constexpr int MXROW = 80;
+
+template <int TW>
+struct W2MxGeom {
+  static constexpr int TH = 256 / TW, HP = TW + 2, HALO = (TH + 2) * HP;
+  static constexpr int RPP = 32, KU = (HALO + RPP - 1) / RPP, HROWS = KU * RPP;
+  static constexpr int AH = HROWS * MXROW, BW = BN * MXROW, HS = HROWS * 2, WS = BN * 2;
+  static constexpr int OFF_B = 2 * AH, OFF_HS = OFF_B + 3 * BW, OFF_WS = OFF_HS + 2 * HS, OFF_BIAS = OFF_WS + 3 * WS;
+  static constexpr size_t LDS = OFF_BIAS + BN * sizeof(float);
+  static_assert(KU == 11 && HS % 16 == 0 && WS % 16 == 0, "layout");
+};
+
+__device__ inline uint32_t w2_cvt4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+
+template <int TW, bool PRO>
+__global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
+                                                             const int tiles_n, const int fuse_stats) {
+  using G = W2MxGeom<TW>;
+  constexpr int TH = G::TH, HP = G::HP, KU = G::KU, RPP = G::RPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const bias_lds = reinterpret_cast<float*>(smem + G::OFF_BIAS);
+  const ConvDesc& d = L.d;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nchunks = (d.C0 + d.C1) / kCH;
+  W2Tiles tm;
+  tm.init((int)blockIdx.x, (int)gridDim.x, tiles_x, tiles_y, tiles_n, d.B);
+  const int nsteps = tm.count * nchunks;
+  if (nsteps == 0) return;
+
+  // ---------------------------------------------------------------------------------------------------
+  if (wave < 4) {
+    __builtin_amdgcn_s_setprio(3);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int lpx = (TW == 16 && l31 >= 16) ? 16 + ((l31 - 2) & 15) : l31;
+    constexpr int GROWS = 32 / TW;
+    const int prow = wm * (TH / 2) + (TW == 16 ? (lpx >> 4) : 0), pcol = TW == 16 ? (lpx & 15) : lpx;
+    constexpr int PTB = GROWS * HP * MXROW, PTS = GROWS * HP * 2;
+    const char* xa = smem + (prow * HP + pcol) * MXROW + hi * 16;          // data of halo buffer 0 / 1
+    const char* xn = xa + G::AH;
+    const char* sa = smem + G::OFF_HS + (prow * HP + pcol) * 2 + hi;       // its block scales
+    const char* sn = sa + G::HS;
+    const char* const wr = smem + G::OFF_B + (wn * 64 + l31) * MXROW + hi * 16;
+    const char* const ws = smem + G::OFF_WS + (wn * 64 + l31) * 2 + hi;
+    if (tid < BN) bias_lds[tid] = L.bias[tm.tn * BN + tid];
+    const int gn_per = fuse_stats ? (d.Cout / L.gn_groups) >> 3 : 1;
+    const int gn_per_sh = 31 - __builtin_clz(gn_per);
+    w2_f32x16 acc[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
+    // ONE operand set: an operand's registers are reloaded for the next phase right after its last MFMA of this phase was
+    // issued (weights of channel half 0 after four MFMAs, pixel group i after MFMA (1, i)): every operand still has at
+    // least three MFMAs = 192 cycles to arrive, and the wave stays under 256 registers
+    w2_i32x8 fw[2], fx[4];
+    int sw[2], sx[4];
+    auto ldw = [&](int ct, int ring) {
+      const char* p = wr + ring * G::BW + ct * 32 * MXROW;
+      const uint4 lo = *reinterpret_cast<const uint4*>(p), up = *reinterpret_cast<const uint4*>(p + 32);
+      fw[ct] = w2_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
+      sw[ct] = *reinterpret_cast<const unsigned char*>(ws + ring * G::WS + ct * 64);
+    };
+    auto ldx = [&](int pt, const char* bd, const char* bs, int toff) {
+      const char* p = bd + pt * PTB + toff * MXROW;
+      const uint4 lo = *reinterpret_cast<const uint4*>(p), up = *reinterpret_cast<const uint4*>(p + 32);
+      fx[pt] = w2_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
+      sx[pt] = *reinterpret_cast<const unsigned char*>(bs + pt * PTS + toff * 2);
+    };
+#define W2X_MM(CT, PT) \
+  acc[CT][PT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[CT], fx[PT], acc[CT][PT], 0, 0, 0, sw[CT], 0, sx[PT])
+#define W2X_SB() __builtin_amdgcn_sched_barrier(0)
+    w2_barrier<true>();                                      // halo 0, weight tiles 0 and 1, the bias
+    ldw(0, 0); ldx(0, xa, sa, 0); ldx(1, xa, sa, 0); ldx(2, xa, sa, 0); ldx(3, xa, sa, 0); ldw(1, 0);
+    int chunk = 0, it = 0;
+    for (int g = 0; g < nsteps; ++g) {
+      const bool tile_end = chunk == nchunks - 1;
+#pragma unroll
+      for (int p = 0; p < 9; ++p) {
+        const int ringN = (p + 1) % 3;
+        const int toffN = p == 8 ? 0 : ((p + 1) / 3) * HP + (p + 1) % 3;
+        const char* const bd = p == 8 ? xn : xa;
+        const char* const bs = p == 8 ? sn : sa;
+        if (!(PRG_W256_EXP & 1)) {
+          W2X_MM(0, 0); W2X_MM(0, 1); W2X_MM(0, 2); W2X_MM(0, 3); W2X_SB();
+          ldw(0, ringN); W2X_MM(1, 0); W2X_SB();
+          ldx(0, bd, bs, toffN); W2X_MM(1, 1); W2X_SB();
+          ldx(1, bd, bs, toffN); W2X_MM(1, 2); W2X_SB();
+          ldx(2, bd, bs, toffN); W2X_MM(1, 3); W2X_SB();
+          ldx(3, bd, bs, toffN); ldw(1, ringN); W2X_SB();
+        }
+        if (p == 8 && tile_end) {
+          // tile finished.  Lane holds pixel (group pt, lpx), channels ct*32 + 8q + 4hi + {0..3} of the wave's 64.
+          int tb, ty0, tx0;
+          tm.decode(it, tb, ty0, tx0, TH, TW);
+          if (PRG_W256_EXP & 4) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt) asm volatile("" ::"v"(acc[ct][pt]));
+          } else {
+            char* const obase = reinterpret_cast<char*>(L.out) +
+                                ((((size_t)tb * d.Hout + ty0 + prow) * d.Wout + tx0 + pcol) * d.Cout + tm.tn * BN + wn * 64 + 8 * hi) * 2;
+            const size_t optb = (size_t)GROWS * d.Wout * d.Cout * 2;   // bytes between the wave's pixel groups
+            float V[16];                                     // [sum | sum of squares][ct][q]
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              float bv[4][4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + wn * 64 + ct * 32 + 8 * q + 4 * hi);
+                bv[q][0] = b4.x; bv[q][1] = b4.y; bv[q][2] = b4.z; bv[q][3] = b4.w;
+                V[ct * 4 + q] = 0.0f;
+                V[8 + ct * 4 + q] = 0.0f;
+              }
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  float v[4];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[ct][pt][4 * q + r] + bv[q][r];
+                    V[ct * 4 + q] += v[r];
+                    V[8 + ct * 4 + q] = fmaf(v[r], v[r], V[8 + ct * 4 + q]);
+                    acc[ct][pt][4 * q + r] = 0.0f;
+                  }
+                  pk[2 * q] = w2_pack(v[0], v[1]);
+                  pk[2 * q + 1] = w2_pack(v[2], v[3]);
+                }
+                // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: swapping the upper
+                // half of chunk 2m with the lower half of chunk 2m+1 leaves lane half 0 with all 8 channels of chunk 2m and
+                // half 1 with those of chunk 2m+1 — one 16-byte store each.
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                  const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * m], pk[4 * m + 2], false, false);
+                  const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * m + 1], pk[4 * m + 3], false, false);
+                  const w2_u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+                  *reinterpret_cast<w2_u32x4*>(obase + pt * optb + ct * 64 + m * 32) = o;
+                }
+              }
+            }
+            if (fuse_stats) {
+              // 16 full-wave sums with 17 lane exchanges (the halving butterfly of conv_ws.hip): fixed order, deterministic
+              const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+              float A8[8], B4[4], C2[2];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) A8[j] = (b0 ? V[8 + j] : V[j]) + w2_dpp<0xB1>(b0 ? V[j] : V[8 + j]);          // lane ^ 1
+#pragma unroll
+              for (int j = 0; j < 4; ++j) B4[j] = (b1 ? A8[4 + j] : A8[j]) + w2_dpp<0x4E>(b1 ? A8[j] : A8[4 + j]);    // lane ^ 2
+#pragma unroll
+              for (int j = 0; j < 2; ++j) C2[j] = (b2 ? B4[2 + j] : B4[j]) + w2_swz<4>(b2 ? B4[j] : B4[2 + j]);
+              float D = (b3 ? C2[1] : C2[0]) + w2_swz<8>(b3 ? C2[0] : C2[1]);
+              D += w2_swz<16>(D);
+              D += __shfl_xor(D, 32, 64);
+              // lane (< 16) holds the wave total of value i = 8 b0 + 4 b1 + 2 b2 + b3 = [sq][ct][q]
+              if (gn_per >= 2) D += w2_swz<8>(D);
+              if (gn_per >= 4) D += w2_swz<4>(D);
+              if (gn_per >= 8) D += w2_dpp<0x4E>(D);
+              const int i = (lane & 1) * 8 + (lane & 2) * 2 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
+              const int cc = i & 7;
+              if (lane < 16 && (cc & (gn_per - 1)) == 0) {
+                const int nsplit = tiles_x * tiles_y * 2;
+                const int slab = ((ty0 / TH) * tiles_x + tx0 / TW) * 2 + wm;
+                const int grp = (((tm.tn * BN + wn * 64) >> 3) + cc) >> gn_per_sh;
+                L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
+              }
+            }
+          }
+        }
+        w2_barrier<false>();
+      }
+      { const char* t = xa; xa = xn; xn = t; t = sa; sa = sn; sn = t; }
+      if (++chunk == nchunks) {
+        chunk = 0;
+        ++it;
+      }
+    }
+#undef W2X_MM
+#undef W2X_SB
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------------
+  {
+    const int ptid = tid - 256, slot = ptid & 7, row = ptid >> 3;
+    char* const Ah0 = smem + row * MXROW + slot * 8;                       // 8 fp8 bytes of halo row `row`
+    unsigned char* const Hs0 = reinterpret_cast<unsigned char*>(smem) + G::OFF_HS + row * 2 + (slot >> 2);
+    const int Hl = d.Hout, Wl = d.Wout;
+    unsigned hpix[KU], hedge[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int hp = k * RPP + row;
+      const int hy = hp / HP, hx = hp - hy * HP;
+      int ry = hy - 1, rx = hx - 1;
+      if (d.ups) { ry >>= 1; rx >>= 1; }
+      hpix[k] = (unsigned)((ry + 1) * d.Win + (rx + 1));
+      hedge[k] = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) |
+                 (hp >= G::HALO ? 16u : 0u);
+    }
+    // weight tile = 128 rows x 64 bytes: unit u = ptid + 256 j -> row u >> 2, 16-byte piece u & 3; scales: 256 bytes
+    const unsigned w_voff = (unsigned)((ptid >> 2) * 64 + (ptid & 3) * 16);
+    char* const Bw0 = smem + G::OFF_B + (ptid >> 2) * MXROW + (ptid & 3) * 16;
+    char* const Ws0 = smem + G::OFF_WS + (ptid & 15) * 16;
+    const unsigned ld_dummy = (unsigned)(d.Win + 1);
+    struct StepInfo { int chunk, it, b, y0, x0; };
+    int gC = 0;
+    auto advance = [&](StepInfo& si) {
+      if (gC + 1 < nsteps) {
+        ++gC;
+        if (++si.chunk == nchunks) {
+          si.chunk = 0;
+          ++si.it;
+          tm.decode(si.it, si.b, si.y0, si.x0, TH, TW);
+        }
+      }
+    };
+    StepInfo sA;
+    sA.chunk = 0;
+    sA.it = 0;
+    tm.decode(0, sA.b, sA.y0, sA.x0, TH, TW);
+    StepInfo sB = sA;
+    advance(sB);
+    StepInfo sC = sB;
+    advance(sC);
+
+    w2_u32x4 wset[3][2], wsc[3], hreg[KU];
+    float4 cf[4], nf[4];
+    unsigned hvalid = 0, hvalid_nxt = 0;
+    const char* ld_base = nullptr;
+    unsigned ld_cs2 = 0, ld_tedge = 0;
+    const float* ld_ca = nullptr;
+    const float* ld_cb = nullptr;
+    auto issue_setup = [&](const StepInfo& si) {
+      const int c = si.chunk * kCH;
+      const bool first = c < d.C0;
+      const bf16_t* src = first ? L.src0 : L.src1;
+      const int cs = first ? d.C0 : d.C1;
+      const int cc = first ? c : c - d.C0;
+      ld_cs2 = (unsigned)(cs * 2);
+      ld_tedge = (si.y0 == 0 ? 1u : 0u) | (si.y0 + TH == Hl ? 2u : 0u) | (si.x0 == 0 ? 4u : 0u) | (si.x0 + TW == Wl ? 8u : 0u) | 16u;
+      const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> d.ups)) * d.Win + (si.x0 >> d.ups) - (d.Win + 1);
+      ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
+      if constexpr (PRO) {
+        const size_t o = (size_t)si.b * d.C0 + si.chunk * kCH + slot * 8;
+        ld_ca = L.pro_a + o;
+        ld_cb = L.pro_b + o;
+      }
+      hvalid_nxt = 0;
+    };
+    auto issue_coeffs = [&](float4* dst) {
+      if constexpr (PRO) {
+        dst[0] = *reinterpret_cast<const float4*>(ld_ca);
+        dst[1] = *reinterpret_cast<const float4*>(ld_ca + 4);
+        dst[2] = *reinterpret_cast<const float4*>(ld_cb);
+        dst[3] = *reinterpret_cast<const float4*>(ld_cb + 4);
+      }
+    };
+    auto issue_unit = [&](int k) {
+      const bool ok = (hedge[k] & ld_tedge) == 0;
+      const unsigned pix = ok ? hpix[k] : ld_dummy;
+      const unsigned voff = __umul24(pix, ld_cs2) + (unsigned)(slot * 16);
+      hreg[k] = *reinterpret_cast<const w2_u32x4*>(ld_base + voff);
+      hvalid_nxt |= (ok ? 1u : 0u) << k;
+    };
+    // one unit = 8 channels of one halo pixel: optional prologue (its result rounded to bf16, like the tensor it replaces),
+    // then everything on the packed bf16 words: block maximum of the 15-bit magnitudes (integer order = magnitude order)
+    // over the pixel's 32 channels (four lanes, two DPP exchanges), E8M0 scale from the maximum's exponent field, and
+    // v_cvt_scalef32_pk_fp8_bf16 (divides by the scale, rounds to nearest even; MODE.FP16_OVFL makes it saturate at +-448
+    // instead of returning NaN for the (448, 512) part of a block — probed, tools/micro/cvt_probe.hip).
+    __builtin_amdgcn_s_setreg((1 | (23 << 6) | (0 << 11)), 1);          // hwreg(MODE, offset 23, 1 bit) = FP16_OVFL
+    auto write_unit = [&](int k, int buf) {
+      w2_u32x4 v = hreg[k];
+      if constexpr (PRO && !(PRG_W256_EXP & 16)) {
+        const float a8[8] = {cf[0].x, cf[0].y, cf[0].z, cf[0].w, cf[1].x, cf[1].y, cf[1].z, cf[1].w};
+        const float b8[8] = {cf[2].x, cf[2].y, cf[2].z, cf[2].w, cf[3].x, cf[3].y, cf[3].z, cf[3].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = w2_pack(w2_silu(fmaf(w2_lo(v[j]), a8[2 * j], b8[2 * j])), w2_silu(fmaf(w2_hi(v[j]), a8[2 * j + 1], b8[2 * j + 1])));
+      }
+      if (!((hvalid >> k) & 1u)) v = w2_u32x4{0u, 0u, 0u, 0u};
+      uint32_t m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t a = v[j] & 0x7fff7fffu;
+        m = max(m, max(a & 0xffffu, a >> 16));
+      }
+      m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));   // lane ^ 1
+      m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));   // lane ^ 2: the block's four lanes agree
+      const int E = (int)(m >> 7);                           // exponent field of the block maximum
+      const int S = E > 8 ? E - 8 : 0;                       // E8M0 scale 2^(S - 127); an all-zero block has S = 0
+      // (S = 0 means a maximum below 2^-118: the divisor is taken as 2^-126, the smallest normal float — such elements
+      // contribute nothing either way)
+      const float scale = __uint_as_float((uint32_t)(S > 1 ? S : 1) << 23);
+      // (inline asm: hipcc 7.2 folds the chained __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16 calls onto the first source word)
+      uint2 w = make_uint2(0u, 0u);
+      asm("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w.x) : "v"(v[0]), "v"(scale));
+      asm("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w.x) : "v"(v[1]), "v"(scale));
+      asm("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w.y) : "v"(v[2]), "v"(scale));
+      asm("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w.y) : "v"(v[3]), "v"(scale));
+      *reinterpret_cast<uint2*>(Ah0 + buf * G::AH + k * RPP * MXROW) = w;
+      Hs0[buf * G::HS + k * RPP * 2] = (unsigned char)S;    // the block's four lanes store the same byte
+    };
+    auto w_issue = [&](int set, int tap, int chunk) {
+      const size_t tile = ((size_t)(tap * nchunks + chunk) * d.CoutPad + (size_t)tm.tn * BN);
+      const char* p = reinterpret_cast<const char*>(L.w_mx) + tile * 64 + w_voff;
+      wset[set][0] = *reinterpret_cast<const w2_u32x4*>(p);
+      wset[set][1] = *reinterpret_cast<const w2_u32x4*>(p + 64 * 64);                     // rows 64 .. 127
+      wsc[set] = *reinterpret_cast<const w2_u32x4*>(reinterpret_cast<const char*>(L.w_mx_scale) + tile * 2 + (ptid & 15) * 16);
+    };
+    auto w_write = [&](int set, int ring) {
+      *reinterpret_cast<w2_u32x4*>(Bw0 + ring * G::BW) = wset[set][0];
+      *reinterpret_cast<w2_u32x4*>(Bw0 + ring * G::BW + 64 * MXROW) = wset[set][1];
+      *reinterpret_cast<w2_u32x4*>(Ws0 + ring * G::WS) = wsc[set];   // 16 copies of the same 256 bytes: no branch
+    };
+
+    issue_setup(sA);
+    issue_coeffs(cf);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) issue_unit(k);
+    hvalid = hvalid_nxt;
+    w_issue(0, 0, sA.chunk);
+    w_issue(1, 1, sA.chunk);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) write_unit(k, 0);
+    w_write(0, 0);
+    w_write(1, 1);
+    issue_setup(sB);
+    issue_coeffs(nf);
+#pragma unroll
+    for (int k = 0; k < KU; ++k) issue_unit(k);
+    hvalid = hvalid_nxt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+    w_issue(2, 2, sA.chunk);
+    w_issue(0, 3, sA.chunk);
+    w_issue(1, 4, sA.chunk);
+    issue_setup(sC);
+    w2_barrier<true>();
+
+    constexpr int US[10] = {0, 2, 4, 6, 7, 8, 9, 10, 11, 11};
+#pragma unroll 1
+    for (int g = 0; g < nsteps; ++g) {
+      const int buf = (g + 1) & 1;
+      const int ch0 = sA.chunk, ch1 = sB.chunk;
+#pragma unroll
+      for (int p = 0; p < 9; ++p) {
+        const int set = (p + 2) % 3;
+        w_write(set, set);
+#pragma unroll
+        for (int k = US[p]; k < US[p + 1]; ++k) write_unit(k, buf);
+        if (p == 0) issue_coeffs(nf);
+        w_issue(set, (p + 5) % 9, p + 5 < 9 ? ch0 : ch1);
+#pragma unroll
+        for (int k = US[p]; k < US[p + 1]; ++k) issue_unit(k);
+        if (p == 8) {
+          hvalid = hvalid_nxt;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+          sA = sB;
+          sB = sC;
+          advance(sC);
+          issue_setup(sC);
+        }
+        w2_barrier<true>();
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
@@ -581,6 +974,66 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
   } else {
     if (pro) conv3x3_w256_kernel<16, true, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
     else conv3x3_w256_kernel<16, false, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+  }
+  PRG_LAUNCH_CHECK();
+  return 1;
+}
+
+// MX-fp8 operands (handles of dtype PRG_MXFP8): same shapes as the bf16 entry.  Returns 1 / 0 / negative.
+int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+  static const int enabled = [] {
+    const char* e = std::getenv("PRG_CONV_W256MX");
+    return e ? std::atoi(e) : 1;
+  }();
+  if (!enabled || !L.w_mx || !L.w_mx_scale) return 0;
+  const ConvDesc& d = L.d;
+  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
+  if (d.C0 % kCH || d.C1 % kCH || d.C0 == 0 || d.Cout % BN || d.CoutPad != d.Cout) return 0;
+  if (L.residual || !L.bias) return 0;
+  if (L.pro_a && d.C1) return 0;
+  const int tiles_n = d.Cout / BN;
+  if (tiles_n != 1 && tiles_n != 2 && tiles_n != 4 && tiles_n != 8) return 0;
+  const int H = d.Hout, W = d.Wout;
+  int tw = 0;
+  if (W % 32 == 0 && H % 8 == 0) tw = 32;
+  else if (W % 16 == 0 && H % 16 == 0) tw = 16;
+  else return 0;
+  if (d.ups && ((H | W) & 1)) return 0;
+  const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
+  const long total = (long)tiles_x * tiles_y * tiles_n * d.B;
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    num_cus = p.multiProcessorCount;
+  }
+  static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
+  const int grid = num_cus & ~7;
+  if (grid < 8 || total < (min_fill > 0 ? min_fill : grid / 2)) return 0;
+  const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
+  const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
+                   tiles_x * tiles_y * 2 <= kGnMaxSplit;
+  if (L.gn_partials && !fuse) return 0;
+  const int pro = L.pro_a ? 1 : 0;
+  const void* fn = tw == 32 ? (pro ? reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, true>)
+                                   : reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, false>))
+                            : (pro ? reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<16, true>)
+                                   : reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<16, false>));
+  const size_t lds = tw == 32 ? W2MxGeom<32>::LDS : W2MxGeom<16>::LDS;
+  static bool attr_done[2][2] = {{false, false}, {false, false}};
+  if (!attr_done[tw == 32][pro]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 mx conv): ") + hipGetErrorString(e));
+    attr_done[tw == 32][pro] = true;
+  }
+  if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
+  if (tw == 32) {
+    if (pro) conv3x3_w256mx_kernel<32, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256mx_kernel<32, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+  } else {
+    if (pro) conv3x3_w256mx_kernel<16, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256mx_kernel<16, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
   }
   PRG_LAUNCH_CHECK();
   return 1;

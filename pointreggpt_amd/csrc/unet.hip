@@ -302,6 +302,7 @@ struct UnetImpl : prg_unet {
     L.gn_partials = o.gn_partials; L.gn_groups = lay.cfg.groups; L.pro_a = o.pro_a; L.pro_b = o.pro_b;
     L.w_mx = (d_mx && p.mx_off >= 0) ? d_mx + p.mx_off : nullptr;
     L.w_mx_scale = (d_mx_scale && p.mx_soff >= 0) ? d_mx_scale + p.mx_soff : nullptr;
+    L.mx_pure = 0;
     L.w_s2d = (p.s2d_off >= 0 && stride == 2 && pad == 1) ? reinterpret_cast<const T*>(d_packed) + p.s2d_off : nullptr;
     L.s2d_kchunks = p.s2d_kchunks;
     L.gn = o.gn ? *o.gn : GnApply{};
@@ -1086,6 +1087,7 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
     L.gn_groups = 8;
     L.w_s2d = reinterpret_cast<const bf16_t*>(d_w2); L.s2d_kchunks = kc_s2d;
     L.w_mx = reinterpret_cast<const uint8_t*>(d_mxd); L.w_mx_scale = reinterpret_cast<const uint8_t*>(d_mxs);
+    L.mx_pure = 1;
     rc = launch_conv<bf16_t>(L, s, nullptr);
   }
   if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<bf16_t>(reinterpret_cast<const bf16_t*>(d_out), out, B, Ho * Wo, Cout, s);

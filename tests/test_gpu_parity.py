@@ -719,7 +719,12 @@ def test_downsample_conv4x4s2(hip, B, Cin, Cout, H, Wd):
     assert bool(((got - ref32).abs() <= tol32).all())
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,Wd", CONV_SHAPES)
+CONV_SHAPES_MX = CONV_SHAPES + [(8, 64, 128, 64, 64),     # 128 tiles of 8x32x128: the 256-pixel MX kernel, one chunk
+                                (8, 128, 256, 32, 64),    # ... two chunks, two output-channel tiles
+                                (128, 64, 128, 16, 16)]   # ... 16x16 tiles
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,Wd", CONV_SHAPES_MX)
 def test_mxfp8_conv_matches_block_scaled_reference(hip, B, Cin, Cout, H, Wd):
     """v_mfma_scale_f32_32x32x64_f8f6f4 path: device-side quantisation of the activations (block maxima, E8M0 scales,
     e4m3 rounding) and host-side quantisation of the weights, against the numpy restatement of OCP MX (oracle/mx.py)."""
@@ -739,6 +744,46 @@ def test_mxfp8_conv_matches_block_scaled_reference(hip, B, Cin, Cout, H, Wd):
     # and the quantisation is not a no-op: the same conv on unquantised bf16 operands differs visibly
     plain = torch.nn.functional.conv2d(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), bias.double(), padding=1)
     assert float((plain - ref).abs().max()) > 3 * float(tol.max())
+
+
+_MX_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from pointreggpt_amd import weights as W
+from pointreggpt_amd.unet import Unet
+g = np.load({gold!r})
+sd = W.synth_state_dict(W.unet_config(64), 13)
+net = Unet(64, dtype="mxfp8").load_state_dict(sd)
+D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+tab = np.load({tables!r})
+net.set_time_freqs(tab["freqs_dim64"])
+y = net(D(g["x"]), D(g["t"]), D(g["pc"])).float().cpu().numpy()
+np.save({out!r}, y)
+"""
+
+
+def test_unet_mxfp8_kernel_variants(tmp_path, golden):
+    """The MX operand path has three dispatches: the default (256-pixel MX kernel where a launch fills the chip, bf16
+    kernels elsewhere), every eligible shape on the 256-pixel MX kernel (PRG_W256_MIN_TILES=1), and every 3x3 conv on MX
+    operands (PRG_MX_PURE=1: the simple halo-tile MX kernel for the rest).  All stay inside the reported MX drift bound
+    against the reference's fp32 output; the all-MX variants bound the format's worst case."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden", "G13_unet_dim64_128.npz")
+    tables = os.path.join(root, "tests", "golden", "G0_host_tables.npz")
+    ref = golden("G13_unet_dim64_128")["y"]
+    for name, env in {"default": {}, "w256mx_all": {"PRG_W256_MIN_TILES": "1"},
+                      "pure": {"PRG_W256_MIN_TILES": "1", "PRG_MX_PURE": "1"}, "pure_simple": {"PRG_MX_PURE": "1", "PRG_CONV_W256MX": "0"}}.items():
+        out = str(tmp_path / f"{name}.npy")
+        r = subprocess.run([sys.executable, "-c", _MX_SCRIPT.format(root=root, gold=gold, tables=tables, out=out)],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        y = np.load(out)
+        e, em = float(np.abs(y - ref).max()), float(np.abs(y - ref).mean())
+        print(f"mxfp8 [{name}]: max {e:.3e} mean {em:.3e}")
+        assert np.isfinite(y).all() and e <= MXFP8_MAX and em <= MXFP8_MEAN, (name, e, em)
 
 
 def test_unet_mxfp8_drift_reported(hip, golden):
