@@ -597,16 +597,16 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
       for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
-    // ONE operand set: an operand's registers are reloaded for the next phase right after its last MFMA of this phase was
-    // issued (weights of channel half 0 after four MFMAs, pixel group i after MFMA (1, i)): every operand still has at
-    // least three MFMAs = 192 cycles to arrive, and the wave stays under 256 registers
-    w2_i32x8 fw[2], fx[4];
-    int sw[2], sx[4];
-    auto ldw = [&](int ct, int ring) {
+    // Pixel operands: ONE set, MFMAs in pixel-group-major order, each group's registers reloaded for the next phase right
+    // after its second (last) MFMA of this phase: six MFMAs = 384 cycles until the next use.  Weight operands are needed by
+    // all eight MFMAs of a phase: TWO sets, the next phase's loaded at the start of this one.  (Two full sets spill.)
+    w2_i32x8 fw[2][2], fx[4];
+    int sw[2][2], sx[4];
+    auto ldw = [&](int set, int ct, int ring) {
       const char* p = wr + ring * G::BW + ct * 32 * MXROW;
       const uint4 lo = *reinterpret_cast<const uint4*>(p), up = *reinterpret_cast<const uint4*>(p + 32);
-      fw[ct] = w2_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
-      sw[ct] = *reinterpret_cast<const unsigned char*>(ws + ring * G::WS + ct * 64);
+      fw[set][ct] = w2_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
+      sw[set][ct] = *reinterpret_cast<const unsigned char*>(ws + ring * G::WS + ct * 64);
     };
     auto ldx = [&](int pt, const char* bd, const char* bs, int toff) {
       const char* p = bd + pt * PTB + toff * MXROW;
@@ -614,27 +614,30 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
       fx[pt] = w2_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
       sx[pt] = *reinterpret_cast<const unsigned char*>(bs + pt * PTS + toff * 2);
     };
-#define W2X_MM(CT, PT) \
-  acc[CT][PT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[CT], fx[PT], acc[CT][PT], 0, 0, 0, sw[CT], 0, sx[PT])
+#define W2X_MM(SET, CT, PT) \
+  acc[CT][PT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[SET][CT], fx[PT], acc[CT][PT], 0, 0, 0, sw[SET][CT], 0, sx[PT])
 #define W2X_SB() __builtin_amdgcn_sched_barrier(0)
     w2_barrier<true>();                                      // halo 0, weight tiles 0 and 1, the bias
-    ldw(0, 0); ldx(0, xa, sa, 0); ldx(1, xa, sa, 0); ldx(2, xa, sa, 0); ldx(3, xa, sa, 0); ldw(1, 0);
+    ldw(0, 0, 0); ldx(0, xa, sa, 0); ldw(0, 1, 0); ldx(1, xa, sa, 0); ldx(2, xa, sa, 0); ldx(3, xa, sa, 0);
     int chunk = 0, it = 0;
-    for (int g = 0; g < nsteps; ++g) {
+    // nine phases per step: the weight set of phase p alternates with the step parity GP -> two steps per loop iteration
+    auto cstep = [&](auto GPc) {
+      constexpr int GP = decltype(GPc)::value;
       const bool tile_end = chunk == nchunks - 1;
 #pragma unroll
       for (int p = 0; p < 9; ++p) {
+        const int cur = (GP + p) & 1, nxt = cur ^ 1;
         const int ringN = (p + 1) % 3;
         const int toffN = p == 8 ? 0 : ((p + 1) / 3) * HP + (p + 1) % 3;
         const char* const bd = p == 8 ? xn : xa;
         const char* const bs = p == 8 ? sn : sa;
         if (!(PRG_W256_EXP & 1)) {
-          W2X_MM(0, 0); W2X_MM(0, 1); W2X_MM(0, 2); W2X_MM(0, 3); W2X_SB();
-          ldw(0, ringN); W2X_MM(1, 0); W2X_SB();
-          ldx(0, bd, bs, toffN); W2X_MM(1, 1); W2X_SB();
-          ldx(1, bd, bs, toffN); W2X_MM(1, 2); W2X_SB();
-          ldx(2, bd, bs, toffN); W2X_MM(1, 3); W2X_SB();
-          ldx(3, bd, bs, toffN); ldw(1, ringN); W2X_SB();
+          ldw(nxt, 0, ringN); W2X_MM(cur, 0, 0); W2X_SB();
+          ldw(nxt, 1, ringN); W2X_MM(cur, 1, 0); W2X_SB();
+          ldx(0, bd, bs, toffN); W2X_MM(cur, 0, 1); W2X_MM(cur, 1, 1); W2X_SB();
+          ldx(1, bd, bs, toffN); W2X_MM(cur, 0, 2); W2X_MM(cur, 1, 2); W2X_SB();
+          ldx(2, bd, bs, toffN); W2X_MM(cur, 0, 3); W2X_MM(cur, 1, 3); W2X_SB();
+          ldx(3, bd, bs, toffN); W2X_SB();
         }
         if (p == 8 && tile_end) {
           // tile finished.  Lane holds pixel (group pt, lpx), channels ct*32 + 8q + 4hi + {0..3} of the wave's 64.
@@ -723,6 +726,10 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
         chunk = 0;
         ++it;
       }
+    };
+    for (int g = 0; g < nsteps; g += 2) {
+      cstep(std::integral_constant<int, 0>{});
+      if (g + 1 < nsteps) cstep(std::integral_constant<int, 1>{});
     }
 #undef W2X_MM
 #undef W2X_SB
