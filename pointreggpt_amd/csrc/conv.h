@@ -36,6 +36,11 @@ struct ConvLaunch {
   const T* w;            // packed
   const float* bias;     // [Cout] or null
   const T* residual;     // NHWC (M, Cout) added in the epilogue, or null
+  // Activated residual (1x1 convs on the implicit-GEMM kernel, bf16 mode): out = conv + bias + SiLU(residual * res_a[b][c]
+  // + res_b[b][c]) — the ResnetBlock tail `SiLU(GroupNorm(h)) + res_conv(x)` (sd:731-734) in the res_conv's epilogue, where
+  // `residual` is h and (res_a, res_b) are its folded GroupNorm coefficients.  out may alias residual.  null = plain add.
+  const float* res_a;
+  const float* res_b;
   T* out;                // NHWC (M, Cout)
   // fused GroupNorm statistics of the OUTPUT (before any activation): per (image, M-tile, group) (sum, sumsq)
   // written to gn_partials [B][gn_nsplit][gn_groups][2]; null = off.  launch_conv decides whether the shape

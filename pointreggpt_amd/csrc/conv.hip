@@ -167,11 +167,22 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
           else { gs += v[u]; gq = fmaf(v[u], v[u], gq); }
         }
         if (L.residual) {
+          float ra[8], rb[8];
+          if (L.res_a) {
+            const size_t cb = (size_t)((int)m / (L.d.Hout * L.d.Wout)) * L.d.Cout + col;   // this row's image
+            const float4 a0 = *reinterpret_cast<const float4*>(L.res_a + cb), a1 = *reinterpret_cast<const float4*>(L.res_a + cb + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(L.res_b + cb), b1 = *reinterpret_cast<const float4*>(L.res_b + cb + 4);
+            ra[0] = a0.x; ra[1] = a0.y; ra[2] = a0.z; ra[3] = a0.w; ra[4] = a1.x; ra[5] = a1.y; ra[6] = a1.z; ra[7] = a1.w;
+            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b0.z; rb[3] = b0.w; rb[4] = b1.x; rb[5] = b1.y; rb[6] = b1.z; rb[7] = b1.w;
+          }
 #pragma unroll
           for (int h = 0; h < 8 / VEC; ++h) {
             Vec16<T> rv = vec_load(L.residual + o + h * VEC);
 #pragma unroll
-            for (int u = 0; u < VEC; ++u) v[h * VEC + u] += Elem<T>::load(rv.e[u]);
+            for (int u = 0; u < VEC; ++u) {
+              const float r = Elem<T>::load(rv.e[u]);
+              v[h * VEC + u] += L.res_a ? Elem<T>::silu(fmaf(r, ra[h * VEC + u], rb[h * VEC + u])) : r;
+            }
           }
         }
 #pragma unroll
@@ -889,6 +900,8 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* 
   PRG_CHECK(L.src0 && L.w && L.out, "conv: null pointer");
   PRG_CHECK(d.C0 % VEC == 0 && d.C1 % VEC == 0, "conv: channel counts must be multiples of the 16-byte vector");
   PRG_CHECK(d.C1 == 0 || L.src1, "conv: second source missing");
+  PRG_CHECK(!L.res_a || (L.residual && L.res_b && d.KH == 1 && d.KW == 1 && d.Cout % 8 == 0),
+            "conv: the activated residual is a 1x1 (implicit-GEMM, wide epilogue) feature");
   PRG_CHECK(d.CoutPad % 64 == 0 && d.CoutPad >= d.Cout, "conv: bad CoutPad");
   const int64_t M64 = (int64_t)d.B * d.Hout * d.Wout;
   PRG_CHECK(M64 > 0 && M64 < (int64_t)1 << 31, "conv: M out of range");

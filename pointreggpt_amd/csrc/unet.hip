@@ -34,6 +34,10 @@ const char* last_error() { return g_err.c_str(); }
 // workgroup of an image, per-image ticket) instead of a gn_coeff_kernel launch.  Measured net-neutral (every workgroup of a
 // persistent launch finishes at the same time, so the fold lands on the kernel's tail: +5-6 us per conv against the 5 us
 // launch + 1.7 us boundary it removes): off by default, kept as a tested option.
+static bool res_epilogue_enabled() {
+  static const int on = [] { const char* e = std::getenv("PRG_RES_EPILOGUE"); return e ? std::atoi(e) : 1; }();
+  return on != 0;
+}
 static bool gn_fold_enabled() {
   static const int on = [] { const char* e = std::getenv("PRG_GN_FOLD"); return e ? std::atoi(e) : 0; }();
   return on != 0;
@@ -273,6 +277,8 @@ struct UnetImpl : prg_unet {
 
   struct ConvOpt {           // optional fusions of one conv launch
     const T* residual = nullptr;
+    const float* res_a = nullptr;   // activated residual: + SiLU(residual * res_a + res_b) (ConvLaunch::res_a)
+    const float* res_b = nullptr;
     float* gn_partials = nullptr;   // fused GroupNorm statistics of the output
     int* gn_nsplit = nullptr;       // out: slabs written (0 = not fused for this shape)
     const float* pro_a = nullptr;   // fused GroupNorm+cond+SiLU on the input (halo kernel)
@@ -299,6 +305,7 @@ struct UnetImpl : prg_unet {
     ConvLaunch<T> L;
     L.d = make_desc(p, C0, C1, B, Hin, Win, stride, pad, ups);
     L.src0 = s0; L.src1 = s1; L.w = W(p); L.bias = F(p.b_off); L.residual = o.residual; L.out = out;
+    L.res_a = o.res_a; L.res_b = o.res_b;
     L.gn_partials = o.gn_partials; L.gn_groups = lay.cfg.groups; L.pro_a = o.pro_a; L.pro_b = o.pro_b;
     L.w_mx = (d_mx && p.mx_off >= 0) ? d_mx + p.mx_off : nullptr;
     L.w_mx_scale = (d_mx_scale && p.mx_soff >= 0) ? d_mx_scale + p.mx_soff : nullptr;
@@ -395,7 +402,10 @@ struct UnetImpl : prg_unet {
     bool fused_tail = false;
     if constexpr (std::is_same<T, bf16_t>::value)
       fused_tail = r.has_res && r.fw_res >= 0 && d_attn && resblock_tail_fused_supported(C0, C1, r.cout);
-    if (fused_tail) {
+    // bf16: a res_conv the fused tail kernel does not cover (up levels 0-1: 768 -> 512, 384 -> 256) takes the tail into ITS
+    // epilogue instead: out = Wres . cat[s0, s1] + b + SiLU(GroupNorm(h)), one launch, `res` never materialised either
+    const bool epi_tail = std::is_same<T, bf16_t>::value && r.has_res && !fused_tail && r.cout % 8 == 0 && res_epilogue_enabled();
+    if (fused_tail || epi_tail) {
       // res_conv folded into the tail pass below: `res` is never materialised
     } else if (r.has_res) {
       if ((rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, ConvOpt(), res, s))) return rc;
@@ -414,7 +424,17 @@ struct UnetImpl : prg_unet {
           return rc;
         }
       }
+      if (epi_tail) {
+        ConvOpt ro;
+        ro.residual = out; ro.res_a = coefA2; ro.res_b = coefB2;
+        rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, ro, out, s);
+        arena.reset(m);
+        return rc;
+      }
       if ((rc = launch_affine_silu<T>(out, coefA2, coefB2, skip, out, B, HW, r.cout, s))) return rc;
+    } else if (epi_tail) {
+      ConvOpt ro;                                            // dry run (workspace sizing): the same conv call
+      if ((rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, ro, out, s))) return rc;
     }
     arena.reset(m);
     return PRG_OK;

@@ -219,7 +219,9 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                 "c64_contiguous": {"PRG_C64_INTERLEAVE": "0"},   # contiguous instead of interleaved tile runs
                 # 256-pixel x 128-channel tiles wherever the shape allows (at these batch sizes the default dispatch keeps
                 # the 128-pixel tiles): fused prologue, x2 gather, two sources, statistics, 8x32 and 16x16 tiles
-                "w256_all": {"PRG_W256_MIN_TILES": "1"}, "no_w256": {"PRG_CONV_W256": "0", "PRG_CONV_DOWN_W256": "0"}}
+                "w256_all": {"PRG_W256_MIN_TILES": "1"}, "no_w256": {"PRG_CONV_W256": "0", "PRG_CONV_DOWN_W256": "0"},
+                # ResnetBlock tail of up levels 0-1 as a separate pass instead of the res_conv's epilogue
+                "no_res_epilogue": {"PRG_RES_EPILOGUE": "0"}}
     for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
@@ -227,7 +229,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
-    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256"):
+    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256", "no_res_epilogue"):
         for k in ("y64", "y128", "y40"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()
