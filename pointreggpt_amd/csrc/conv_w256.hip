@@ -812,7 +812,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
       }
     };
     auto issue_unit = [&](int k) {
-      const bool ok = (hedge[k] & ld_tedge) == 0;
+      const bool ok = (hedge[k] & ld_tedge) == 0 && !(PRG_W256_EXP & 2);   // 2: timing experiment, every unit loads the tile origin
       const unsigned pix = ok ? hpix[k] : ld_dummy;
       const unsigned voff = __umul24(pix, ld_cs2) + (unsigned)(slot * 16);
       hreg[k] = *reinterpret_cast<const w2_u32x4*>(ld_base + voff);
@@ -834,6 +834,10 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
           v[j] = w2_pack(w2_silu(fmaf(w2_lo(v[j]), a8[2 * j], b8[2 * j])), w2_silu(fmaf(w2_hi(v[j]), a8[2 * j + 1], b8[2 * j + 1])));
       }
       if (!((hvalid >> k) & 1u)) v = w2_u32x4{0u, 0u, 0u, 0u};
+      if (PRG_W256_EXP & 32) {                               // timing experiment: no quantisation arithmetic
+        *reinterpret_cast<uint2*>(Ah0 + buf * G::AH + k * RPP * MXROW) = make_uint2(v[0], v[1]);
+        return;
+      }
       uint32_t m = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
     };
     auto w_issue = [&](int set, int tap, int chunk) {
       const size_t tile = ((size_t)(tap * nchunks + chunk) * d.CoutPad + (size_t)tm.tn * BN);
-      const char* p = reinterpret_cast<const char*>(L.w_mx) + tile * 64 + w_voff;
+      const char* p = reinterpret_cast<const char*>(L.w_mx) + ((PRG_W256_EXP & 8) ? 0 : tile * 64) + w_voff;   // 8: timing experiment, one L1-resident tile
       wset[set][0] = *reinterpret_cast<const w2_u32x4*>(p);
       wset[set][1] = *reinterpret_cast<const w2_u32x4*>(p + 64 * 64);                     // rows 64 .. 127
       wsc[set] = *reinterpret_cast<const w2_u32x4*>(reinterpret_cast<const char*>(L.w_mx_scale) + tile * 2 + (ptid & 15) * 16);
