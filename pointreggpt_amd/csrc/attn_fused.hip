@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
       }
     }
     const int valid = min(kTP, N - t * kTP);
+    const bool full = valid == kTP;                        // wave-uniform: whole tiles skip the 32 per-pixel masks
     // p and v, transposed to [channel][pixel] so that pixels become the MFMA k index
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
@@ -238,10 +239,18 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
       for (int g4 = 0; g4 < 4; ++g4) {
         const int px0 = pt * 32 + 8 * g4 + 4 * hi;
         float p[4];
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          p[j] = px0 + j < valid ? fast_exp(ka[pt][4 * g4 + j] - m) : 0.0f;
-          ssum += p[j];
+          for (int j = 0; j < 4; ++j) {
+            p[j] = __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j] - m);
+            ssum += p[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            p[j] = px0 + j < valid ? __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j] - m) : 0.0f;
+            ssum += p[j];
+          }
         }
         uint2 pw, vw;
         pw.x = pack2(p[0], p[1]);
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
       float sm = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        qa[pt][r] = fast_exp(qa[pt][r] - mx);
+        qa[pt][r] = __builtin_amdgcn_exp2f(qa[pt][r] - mx);   // q arrives times log2(e) (weights pre-scaled)
         sm += qa[pt][r];
       }
       sm += __shfl_xor(sm, 32, 64);

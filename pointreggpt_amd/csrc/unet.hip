@@ -791,10 +791,13 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       a.fw_qkv = (int64_t)aw.size();
       for (int o = 0; o < 3 * kHidden; ++o)
         for (int c = 0; c < a.C; ++c)
-          aw.push_back(f32_to_bf16(weights[a.qkv.w_flat + (size_t)o * a.C + c] * weights[a.norm_g + c]));
+          // q and k only ever enter a softmax: their rows carry log2(e), so the kernels exponentiate with a bare v_exp_f32
+          aw.push_back(f32_to_bf16(weights[a.qkv.w_flat + (size_t)o * a.C + c] * weights[a.norm_g + c] *
+                                   (o < 2 * kHidden ? 1.4426950408889634f : 1.0f)));
       // Softmax over pixels of k[n][d] = w_d . LN(x_n): a LayerNorm output has norm <= sqrt(C), so |k| <= ||w_d|| sqrt(C)
       // (Cauchy-Schwarz; w_d = the bf16 weights the kernel multiplies with, 2 % slack for the bf16 rounding of LN(x)).
       // exp(k - bound) >= exp(-2 bound): with bound <= 40 nothing underflows and the column maxima need not be measured.
+      // (k, hence the bound, in units of 1 / log2(e): the rows above are pre-scaled.)
       float shifts[kHidden];
       bool ok = kshift_on != 0;
       for (int d = 0; d < kHidden; ++d) {
@@ -804,7 +807,7 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
           n2 += w * w;
         }
         shifts[d] = (float)(1.02 * std::sqrt(n2 * a.C));
-        ok = ok && shifts[d] <= 40.0f;
+        ok = ok && shifts[d] <= 40.0f * 1.4426950408889634f;
       }
       if (ok) {
         a.kshift = (int64_t)ks.size();
