@@ -236,3 +236,26 @@ def test_real_data_input_side(tmp_path, monkeypatch):
     depth2, _ = gen._real_scene(PAIRS_PER_LAP, {k: v * PAIRS_PER_LAP for k, v in lst.items()}, tmp_path)
     assert np.array_equal(depth2, (raw[::-1][ys][:, xs][:, left:left + S].astype(np.float32) * np.float32(1e-4)) *
                           ((raw[::-1][ys][:, xs][:, left:left + S].astype(np.float32) * np.float32(1e-4)) <= 1))
+
+
+def test_downsample_equals_two_by_two_taps_over_space_to_depth():
+    """The identity conv_w256.hip's Downsample mode rests on (csrc/conv.hip: s2d_equivalent_weights): Conv2d(C, Co, 4, 2, 1)
+    (sd:596-597) of x equals a 3x3 / pad 1 convolution, with only taps (1..2, 1..2) non-zero, of the space-to-depth view
+    [4C, H/2, W/2] of x shifted by (1, 1) — virtual channel (2 dy + dx) C + c of block (y', x') is x[c, 2y'+dy-1, 2x'+dx-1]
+    (zero outside), weight [co][(2 dy + dx) C + c][1 + by][1 + bx] = W[co][c][2 by + dy][2 bx + dx]."""
+    import torch
+    g = torch.Generator().manual_seed(42)
+    B, C, Co, H, Wd = 2, 3, 5, 8, 12
+    x = torch.randn((B, C, H, Wd), generator=g, dtype=torch.float64)
+    w = torch.randn((Co, C, 4, 4), generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(x, w, None, stride=2, padding=1)
+    xs = torch.nn.functional.pad(x, (1, 1, 1, 1))[:, :, :H + 1, :Wd + 1]      # xs[y, x] = x[y - 1, x - 1]; one extra block row / col
+    xs = torch.nn.functional.pad(xs, (0, 1, 0, 1))                              # even size: (H + 2, Wd + 2)
+    v = torch.stack([xs[:, :, dy::2, dx::2] for dy in (0, 1) for dx in (0, 1)], dim=1).reshape(B, 4 * C, H // 2 + 1, Wd // 2 + 1)
+    weq = torch.zeros((Co, 4 * C, 3, 3), dtype=torch.float64)
+    for ky in range(4):
+        for kx in range(4):
+            by, dy, bx, dx = ky >> 1, ky & 1, kx >> 1, kx & 1
+            weq[:, (2 * dy + dx) * C:(2 * dy + dx + 1) * C, 1 + by, 1 + bx] = w[:, :, ky, kx]
+    got = torch.nn.functional.conv2d(v, weq, None, padding=1)[:, :, :H // 2, :Wd // 2]
+    assert float((got - ref).abs().max()) < 1e-12
