@@ -652,7 +652,9 @@ __global__ __launch_bounds__(256) void resblock_tail_fused_kernel(const bf16_t* 
                                                                   const float* __restrict__ Bc, const bf16_t* __restrict__ s0,
                                                                   int C0, const bf16_t* __restrict__ s1, int C1,
                                                                   const bf16_t* __restrict__ wres, const float* __restrict__ bres,
-                                                                  bf16_t* __restrict__ out, int N) {
+                                                                  bf16_t* __restrict__ out, int N, const float* __restrict__ head_w,
+                                                                  const float* __restrict__ head_b, float* __restrict__ head_out,
+                                                                  int head_sigmoid) {
   constexpr int LDX = CIN + 8, LDH = COUT + 8;
   constexpr int RT = COUT / 32, NA = RT / 2;          // row tiles of 32 channels; accumulators per wave
   constexpr int XV = CIN / 32, HV = COUT / 32;        // 16-byte vectors per thread of the source / h tile
@@ -732,7 +734,27 @@ __global__ __launch_bounds__(256) void resblock_tail_fused_kernel(const bf16_t* 
       }
     }
     __syncthreads();                                                                            // (2) out tile in hs
-    if (row < valid) {
+    if (head_out) {
+      // the network's last layer (1x1 conv to one channel) on the tile: four lanes share a pixel's channels
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < HV; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(hs + row * LDH + (part + 4 * i) * 8);
+        const float* w = head_w + (part + 4 * i) * 8;
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc = fmaf(bf_lo(q[j]), w[2 * j], acc);
+          acc = fmaf(bf_hi(q[j]), w[2 * j + 1], acc);
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (part == 0 && row < valid) {
+        const float y = acc + head_b[0];
+        head_out[(int64_t)b * N + (int64_t)t * kTP + row] = head_sigmoid ? 1.0f / (1.0f + expf(-y)) : y;
+      }
+    } else if (row < valid) {
 #pragma unroll
       for (int i = 0; i < HV; ++i)
         *reinterpret_cast<uint4*>(out + ((int64_t)b * N + (int64_t)t * kTP + row) * COUT + (part + 4 * i) * 8) =
@@ -744,7 +766,8 @@ __global__ __launch_bounds__(256) void resblock_tail_fused_kernel(const bf16_t* 
 
 template <int CIN, int COUT>
 int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1, int C1,
-                const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, hipStream_t s) {
+                const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, hipStream_t s, const float* head_w = nullptr,
+                const float* head_b = nullptr, float* head_out = nullptr, int head_sigmoid = 0) {
   const size_t lds = (size_t)kTP * (CIN + 8 + COUT + 8) * 2;
   static bool attr = false;
   if (!attr) {
@@ -752,7 +775,8 @@ int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* 
     if (rc) return rc;
     attr = true;
   }
-  resblock_tail_fused_kernel<CIN, COUT><<<dim3(tail_slabs(N), B), 256, lds, s>>>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, N);
+  resblock_tail_fused_kernel<CIN, COUT><<<dim3(tail_slabs(N), B), 256, lds, s>>>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, N, head_w, head_b,
+                                                                                 head_out, head_sigmoid);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
@@ -828,9 +852,11 @@ bool resblock_tail_fused_supported(int C0, int C1, int Cout) {
 // out (B, N, Cout) <- SiLU(h * A + Bc) + wres [Cout][C0+C1] . cat[s0 (B,N,C0), s1 (B,N,C1)] + bres.  out may alias h.
 int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1,
                                int C1, const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, int Cout,
-                               hipStream_t s) {
+                               hipStream_t s,
+                               const float* head_w, const float* head_b, float* head_out, int head_sigmoid) {
   PRG_CHECK(resblock_tail_fused_supported(C0, C1, Cout) && bres, "fused resblock tail: unsupported shape");
-  if (Cout == 64) return launch_tail<128, 64>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
+  PRG_CHECK(!head_out || (Cout == 64 && head_w && head_b), "fused resblock tail: the head needs Cout = 64");
+  if (Cout == 64) return launch_tail<128, 64>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s, head_w, head_b, head_out, head_sigmoid);
   if (C0 + C1 == 192) return launch_tail<192, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);   // up level 2
   return launch_tail<256, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
 }

@@ -50,9 +50,13 @@ int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf1
 
 // ResnetBlock tail with the 1x1 res_conv folded in (attn_fused.hip), bf16 path.  wres: [Cout][C0+C1] bf16.
 bool resblock_tail_fused_supported(int C0, int C1, int Cout);
+// head_out != null (Cout = 64 only): the Unet's final 1x1 conv to one channel (+ optional sigmoid) is applied to the tile
+// in LDS and ONLY its float32 result (B, N) is written — the 64-channel tensor never reaches HBM.
 int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1,
                                int C1, const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, int Cout,
-                               hipStream_t s);
+                               hipStream_t s,
+                               const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr,
+                               int head_sigmoid = 0);
 
 // Attention core on MFMA (bf16 path, N in {64, 128, 256} tokens) (attn_fused.hip)
 bool full_attention_mfma_supported(int N);

@@ -34,6 +34,10 @@ const char* last_error() { return g_err.c_str(); }
 // workgroup of an image, per-image ticket) instead of a gn_coeff_kernel launch.  Measured net-neutral (every workgroup of a
 // persistent launch finishes at the same time, so the fold lands on the kernel's tail: +5-6 us per conv against the 5 us
 // launch + 1.7 us boundary it removes): off by default, kept as a tested option.
+static bool head_fuse_enabled() {
+  static const int on = [] { const char* e = std::getenv("PRG_HEAD_FUSE"); return e ? std::atoi(e) : 1; }();
+  return on != 0;
+}
 static bool res_epilogue_enabled() {
   static const int on = [] { const char* e = std::getenv("PRG_RES_EPILOGUE"); return e ? std::atoi(e) : 1; }();
   return on != 0;
@@ -275,6 +279,13 @@ struct UnetImpl : prg_unet {
   template <typename U>
   U* alloc(size_t n) { return reinterpret_cast<U*>(arena.alloc(n * sizeof(U))); }
 
+  // set around the final block only: its fused tail also applies the head (launch_resblock_tail_fused)
+  const float* head_w = nullptr;
+  const float* head_b = nullptr;
+  float* head_out = nullptr;
+  int head_sigmoid = 0;
+  bool head_done = false;
+
   struct ConvOpt {           // optional fusions of one conv launch
     const T* residual = nullptr;
     const float* res_a = nullptr;   // activated residual: + SiLU(residual * res_a + res_b) (ConvLaunch::res_a)
@@ -419,7 +430,8 @@ struct UnetImpl : prg_unet {
       if constexpr (std::is_same<T, bf16_t>::value) {
         if (fused_tail) {
           rc = launch_resblock_tail_fused(out, coefA2, coefB2, s0, C0, s1, C1, d_attn + r.fw_res, F(r.res.b_off), out, B, HW,
-                                          r.cout, s);
+                                          r.cout, s, head_w, head_b, head_out, head_sigmoid);
+          head_done = head_out != nullptr;
           arena.reset(m);
           return rc;
         }
@@ -583,10 +595,18 @@ struct UnetImpl : prg_unet {
       const size_t M = (size_t)B * H * H;
       T* fr = alloc<T>(M * d0);
       PRG_CHECK(arena.dry || fr, "workspace exhausted (final)");
-      if ((rc = resblock(L.fin, x, d0, x0, d0, cs, fr, B, H, H, s))) return rc;
+      // the final block's fused tail applies the 1x1 head to its LDS tile and writes only the network output (bf16 path,
+      // no taps requested): `fr` is then never written
+      head_done = false;
+      if (!taps_on && !arena.dry && d0 == 64 && head_fuse_enabled()) {
+        head_w = F(L.head_w); head_b = F(L.head_b); head_out = out; head_sigmoid = L.cfg.sigmoid_out;
+      }
+      rc = resblock(L.fin, x, d0, x0, d0, cs, fr, B, H, H, s);
+      head_w = head_b = nullptr; head_out = nullptr;
+      if (rc) return rc;
       tap("final_res", fr, B, d0, H, H);
-      if (!arena.dry && (rc = launch_head_conv<T>(fr, F(L.head_w), F(L.head_b), out, (int64_t)M, d0,
-                                                  L.cfg.sigmoid_out, s)))
+      if (!arena.dry && !head_done && (rc = launch_head_conv<T>(fr, F(L.head_w), F(L.head_b), out, (int64_t)M, d0,
+                                                                 L.cfg.sigmoid_out, s)))
         return rc;
     }
     return PRG_OK;

@@ -221,7 +221,8 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                 # the 128-pixel tiles): fused prologue, x2 gather, two sources, statistics, 8x32 and 16x16 tiles
                 "w256_all": {"PRG_W256_MIN_TILES": "1"}, "no_w256": {"PRG_CONV_W256": "0", "PRG_CONV_DOWN_W256": "0"},
                 # ResnetBlock tail of up levels 0-1 as a separate pass instead of the res_conv's epilogue
-                "no_res_epilogue": {"PRG_RES_EPILOGUE": "0"}}
+                "no_res_epilogue": {"PRG_RES_EPILOGUE": "0"},
+                "no_head_fuse": {"PRG_HEAD_FUSE": "0"}}            # the 1x1 head as its own launch instead of the final tail's epilogue
     for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
@@ -229,7 +230,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
-    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256", "no_res_epilogue"):
+    for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256", "no_res_epilogue", "no_head_fuse"):
         for k in ("y64", "y128", "y40"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()
