@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 UNET_GFLOP = {64: 14.744, 128: 58.976, 256: 236.282}      # per image, SURVEY.md §8d / BASELINE.md §2
 MASK_GFLOP = {64: 14.787, 128: 59.173, 256: 237.096}
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mxfp8": 5000.0}   # dense, MI355X_MICROARCH.md chip table
+CONV_CLASS = ("MFMA convolutions: conv3x3_w256_kernel (256-pixel x 128-channel tiles, also Downsample) + conv3x3_c64_kernel "
+              "(64 -> 64, weights-stationary) + conv3x3_ws_kernel (128-pixel wave-specialised tiles) + conv_igemm_kernel (1x1)")
 
 
 def conv_sources_hash():
@@ -39,9 +41,10 @@ def conv_sources_hash():
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=1, help="timed batches per rank")
-    p.add_argument("--warmup", type=int, default=1, help="untimed batches per rank")
+    p.add_argument("--steps", type=int, default=4, help="timed batches per rank")
+    p.add_argument("--warmup", type=int, default=2, help="untimed batches per rank")
     p.add_argument("--batch", type=int, default=64)
+    p.add_argument("--streams", type=int, default=2, help="independent pipelines (HIP stream + host thread each) sharing the GPU")
     p.add_argument("--size", type=int, default=128)
     p.add_argument("--timesteps", type=int, default=1000)
     p.add_argument("--sampling-steps", type=int, default=None, help="< timesteps selects DDIM (default: ancestral DDNM)")
@@ -53,9 +56,12 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--profile-transitions", type=int, default=40)
     p.add_argument("--no-e2e-files", action="store_true", help="skip the generate_dataset leg (files on disk)")
-    p.add_argument("--e2e-batches", type=int, default=2)
-    p.add_argument("--no-drift", action="store_true", help="skip the bf16-vs-fp32 end-to-end drift measurement")
-    p.add_argument("--drift-scenes", type=int, default=4)
+    p.add_argument("--e2e-batches", type=int, default=4)
+    p.add_argument("--no-drift", action="store_true", help="skip the drift-vs-reference legs (fixtures G19 / G20)")
+    p.add_argument("--no-configs4", action="store_true", help="skip the configs[4] leg (256x256, 250-step DDIM, mxfp8)")
+    p.add_argument("--c4-batch", type=int, default=16)
+    p.add_argument("--c4-steps", type=int, default=3, help="timed batches of the configs[4] leg")
+    p.add_argument("--uncalibrated", action="store_true", help="round-1/2 synthetic weights (98 %% of in-painted pixels saturate)")
     return p.parse_args()
 
 
@@ -158,7 +164,7 @@ def mem_rooflines(G, bt, S, B, pr):
                        "< 0.01 % of a 1000-step pair"}
 
 
-def e2e_files(a, unet, mask, diff, rank, world, B, S):
+def e2e_files(a, unet, mask, diff, rank, world, B, S, lanes=None):
     """generate_dataset.py's own loop (Generator.generate, synthetic scenes) for `e2e_batches` batches INCLUDING every file
     of the reference's layout (2 PLY + 5 PNG + 2 text files per pair): host post-processing runs on the library's C++
     writer pool while the GPU samples the next batch.  Returns pairs on disk / wall time of this rank."""
@@ -170,61 +176,162 @@ def e2e_files(a, unet, mask, diff, rank, world, B, S):
         gen = Generator(diff, None, batch_size=B, samples_folder=os.path.join(root, "data"), synthetic_seed=a.seed)
         first = 10_000_000 + rank * (a.e2e_batches + 1) * B
         st = {}
-        gen.generate(first, first + B, 1, depth_correction=mask, stats=st)          # warm-up batch (graph capture, pool start)
+        nl = 1 + len(lanes or [])
+        # warm-up: one batch per lane (graph capture, pool start)
+        gen.generate(first - (nl - 1) * B, first + B, 1, depth_correction=mask, stats=st, lanes=lanes)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        gen.generate(first + B, first + (a.e2e_batches + 1) * B, 1, depth_correction=mask, stats=st)
+        gen.generate(first + B, first + (a.e2e_batches + 1) * B, 1, depth_correction=mask, stats=st, lanes=lanes)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         nfiles = sum(len(f) for _d, _s, f in os.walk(os.path.join(root, "data")))
         nbytes = sum(os.path.getsize(os.path.join(d, f)) for d, _s, fs in os.walk(os.path.join(root, "data")) for f in fs)
+        # generate_gt.py on the same scenes (generate_gt.py:105-188): read both PLYs, 0.025 voxel grids (C++), all pairs in one
+        # prg_overlap_counts launch, per-scene gt.log, metadata/gt.log
+        from pointreggpt_amd.generator import gather_gt, generate_gt
+        t1 = time.perf_counter()
+        generate_gt("", first + B, first + (a.e2e_batches + 1) * B, 2, root=root)
+        gather_gt("", first + B, first + (a.e2e_batches + 1) * B, root=root)
+        dt_gt = time.perf_counter() - t1
+        gt_path = os.path.join(root, "metadata", "gt.log")
+        n_lines = sum(1 for _ in open(gt_path)) if os.path.exists(gt_path) else 0
         return {"pairs": a.e2e_batches * B, "seconds": dt, "files_written": nfiles, "bytes_written": nbytes,
-                "writer_threads": st.get("writer_threads"), "dir": "tmpfs/tmp (deleted)"}
+                "writer_threads": st.get("writer_threads"), "lanes": st.get("lanes"), "dir": "tmpfs/tmp (deleted)",
+                "gt_log": {"seconds": dt_gt, "pairs_per_s": a.e2e_batches * B / dt_gt, "lines": n_lines,
+                           "what": "generate_gt + gather_gt over the timed scenes, after generation (not overlapped)"}}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
 
-def bf16_drift(a, G, synthetic, S, n_trans_rows):
-    """How far the throughput mode (bf16) lands from the parity mode (fp32 HIP, pinned to the reference by the golden
-    tests) on the SAME scenes, Philox keys and full transition table: depth in metres over in-painted pixels and the
-    point-XYZ difference of the pixels both runs keep."""
+def drift_vs_reference(dtypes, dim):
+    """Distance of the library's precision modes from the REAL reference on chains of real length: the committed fixtures
+    G20 (250-step DDIM @128x128) and G19 (1000-step ancestral @64x64), both produced by the reference itself on the
+    calibrated synthetic denoiser (tools/make_goldens.py), re-run here through the C-ABI on the fixtures' stored condition
+    and regenerated noise.  Metres (normalised depth x 10); in-painted pixels only (known pixels are bit-exact)."""
+    import hashlib
+    from pointreggpt_amd import geometry as G
+    from pointreggpt_amd import weights as W
+    from pointreggpt_amd.diffusion import GaussianDiffusion
+    from pointreggpt_amd.unet import Unet
+    gold = os.path.join(ROOT, "tests", "golden")
+    g0 = np.load(os.path.join(gold, "G0_host_tables.npz"))
+    out = {}
+    for name, S, steps, tab in (("G20_ddim250_128", 128, 250, "ddim250"), ("G19_chain1000_ancestral_64", 64, None, "anc1000")):
+        path = os.path.join(gold, name + ".npz")
+        if not os.path.exists(path):
+            out[name] = "fixture missing"
+            continue
+        g = np.load(path)
+        st = torch.random.get_rng_state()
+        torch.manual_seed(int(g["noise_seed"]))
+        nz = torch.stack([torch.randn((1, 1, S, S)) for _ in range(int(g["n_draws"]))])
+        torch.random.set_rng_state(st)
+        if hashlib.sha256(nz.numpy().tobytes()).digest() != bytes(bytearray(g["noise_sha256"].tolist())):
+            out[name] = "torch.randn does not reproduce the fixture's noise on this build"
+            continue
+        known = (g["img_cond"][:, 1:2] + 1) * 0.5 > 0.5
+        ref = g["sampled"]
+        v_ref = ((ref[0, 0] * 10 > 0.5) & (ref[0, 0] * 10 < 10)).reshape(-1)
+        res = {"chain": f"{steps or 1000}-step {'DDIM' if steps else 'ancestral DDNM'} @{S}x{S}, B=1, dim {dim}, calibrated synthetic weights",
+               "reference_spread_1_vs_8_threads_xyz_m": float(g["xyz_spread_1_vs_8_threads_m"]),
+               "reference_to_float64_twin_xyz_m": float(g["xyz_ref_to_exact_m"]),
+               "inpainted_fraction": float(g["inpainted_fraction"]),
+               "saturated_fraction_reference": float(g["saturated_fraction_inpainted"])}
+        for dt in dtypes:
+            net = Unet(dim, dtype=dt).load_state_dict(W.synth_state_dict(W.unet_config(dim), int(g["wseed"]), calibrated=True))
+            net.set_time_freqs(g0[f"freqs_dim{dim}"])
+            d = GaussianDiffusion(net, image_size=S, timesteps=1000, sampling_timesteps=steps)
+            rows = d.step_table()
+            for r, v in zip(rows, g0[tab + "_rows"]):      # the fixtures' host's float32 coefficient table (DESIGN.md section 2)
+                for j, k in enumerate(("c_x0", "c_x", "c_eps", "sigma", "sqrt_recip", "sqrt_recipm1")):
+                    r[k] = float(v[j])
+            d.step_table = lambda rows=rows: rows
+            img_d = d.sample(param_cond=torch.from_numpy(g["pc"]).cuda(), img_cond=torch.from_numpy(g["img_cond"]).cuda(),
+                             noise=nz.cuda())
+            cloud = G.point_clouds(img_d, torch.from_numpy(g["K"]).cuda(), torch.from_numpy(g["pose"]).cuda())[0]
+            img = img_d.cpu().numpy()
+            dd = np.abs(img.astype(np.float64) - ref)[~known] * 10.0
+            v_hip = ((img[0, 0] * 10 > 0.5) & (img[0, 0] * 10 < 10)).reshape(-1)
+            ch = np.full((v_hip.size, 3), np.nan); ch[v_hip] = cloud
+            cr = np.full((v_ref.size, 3), np.nan); cr[v_ref] = g["cloud"]
+            both = v_hip & v_ref
+            res[dt] = {"known_pixels_bit_exact": bool(np.array_equal(img[known], ref[known])),
+                       "inpainted_depth_m": {"max": float(dd.max()), "mean": float(dd.mean()), "median": float(np.median(dd))},
+                       "xyz_linf_m": float(np.abs(ch[both] - cr[both]).max()),
+                       "valid_mask_identical": bool(np.array_equal(v_hip, v_ref)),
+                       "saturated_fraction": float(((img <= 0) | (img >= 1))[~known].mean())}
+            d.close(); net.close()
+        out[name] = res
+    return out
+
+
+def configs4_leg(a, G, synthetic, rank):
+    """BASELINE configs[4] on one GPU: 256x256 depth, 250-step DDIM (eta = 1, DDNM replacement: the setting
+    generate_dataset.py:34-49 ships), MX-fp8 operands for the 3x3 convolutions (v_mfma_scale_f32_32x32x64_f8f6f4), full
+    pipeline, B = 16 (= 64 x 128x128 pixels per batch).  Own roofline against the 5 PFLOP/s dense MX-fp8 peak."""
     from pointreggpt_amd.diffusion import GaussianDiffusion
     from pointreggpt_amd.unet import MaskUnet, Unet
-    n = a.drift_scenes
-    idx = list(range(20_000_000, 20_000_000 + n))
-    depth, K, pose = synthetic.synth_batch(a.seed, idx, S)
+    B, S, T, steps, dt = a.c4_batch, 256, 1000, 250, "mxfp8"
     dev = torch.device("cuda", torch.cuda.current_device())
-    d_depth, d_K, d_pose = (torch.from_numpy(x).to(dev) for x in (depth, K, pose))
-    seeds = [synthetic.noise_seed(a.seed, j) for j in idx]
-    res = {}
-    for dt in ("fp32", "bf16"):
-        unet = Unet(a.dim, dtype=dt).init_synthetic(seed=1)
-        mask = MaskUnet(a.dim, dtype=dt).init_synthetic(seed=2, final_bias=6.0)
-        diff = GaussianDiffusion(unet, image_size=S, timesteps=a.timesteps, sampling_timesteps=a.sampling_steps)
-        rpj, hit = G.reproject_tensor(d_depth, d_K, d_pose, clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+    unet = Unet(a.dim, dtype=dt).init_synthetic(seed=1, calibrated=True)
+    mask = MaskUnet(a.dim, dtype=dt).init_synthetic(seed=2, calibrated=True)
+    diff = GaussianDiffusion(unet, image_size=S, timesteps=T, sampling_timesteps=steps)
+    n_trans = len(diff.step_table())
+    batches = []
+    for i in range(1 + a.c4_steps):
+        first = 30_000_000 + (rank * (1 + a.c4_steps) + i) * B
+        idx = list(range(first, first + B))
+        depth, K, pose = synthetic.synth_batch(a.seed, idx, S)
+        batches.append(dict(depth=torch.from_numpy(depth).to(dev), K=torch.from_numpy(K).to(dev), pose=torch.from_numpy(pose).to(dev),
+                            seeds=[synthetic.noise_seed(a.seed, j) for j in idx]))
+
+    def one(bt):
+        rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
         _, hit_c, cond = G.apply_mask(mask(rpj), rpj, hit, 0.99)
-        img = diff.sample(param_cond=G.param_vector(d_K), img_cond=cond, seeds=seeds)
+        img = diff.sample(param_cond=G.param_vector(bt["K"]), img_cond=cond, seeds=bt["seeds"])
         out, _, _ = G.apply_mask(mask(img), img, None, 0.99, want_cond=False)
-        xyz, valid = G.unproject_f64(out, d_K, d_pose)
-        res[dt] = (img.cpu(), hit_c.cpu(), xyz.cpu(), valid.cpu())
-        diff.close(); unet.close(); mask.close()
-    (i32, k32, x32, v32), (i16, k16, x16, v16) = res["fp32"], res["bf16"]
-    same_known = bool(torch.equal(k32, k16))
-    free = ~(k32 | k16)
-    dd = (i32 - i16).abs()[free] * 10.0
-    both = v32 & v16
-    dx = (x32 - x16).abs().max(dim=-1).values[both]
-    return {"scenes": n, "image_size": S, "transitions": n_trans_rows, "reference": "this library's fp32 parity mode, same Philox keys",
-            "known_mask_identical": same_known, "inpainted_fraction": float(free.float().mean()),
-            "inpainted_depth_m": {"max": float(dd.max()) if dd.numel() else 0.0, "mean": float(dd.mean()) if dd.numel() else 0.0,
-                                  "median": float(dd.median()) if dd.numel() else 0.0},
-            "xyz_m_points_kept_by_both": {"max": float(dx.max()) if dx.numel() else 0.0, "mean": float(dx.mean()) if dx.numel() else 0.0},
-            "kept_by_only_one_fraction": float((v32 ^ v16).float().mean()),
-            "saturated_fraction_fp32": float(((i32 <= 0) | (i32 >= 1)).float().mean()),
-            "note": "synthetic (random) weights: most in-painted pixels end on the [-1,1] clamp in both modes (median 0); the "
-                    "rest sit in a chain that amplifies perturbations (tests/golden/G12b: half-ulp perturbations of the network "
-                    "output already move a 50-step result by 0.5-1.2e-4 m), so the maximum is not a precision statement",
-            "known_pixels": "bit-identical to the condition in both modes (DDNM replacement)"}
+        return G.unproject_f64(out, bt["K"], bt["pose"]), img, hit_c
+
+    one(batches[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for bt in batches[1:]:
+        _, img, hit_c = one(bt)
+    torch.cuda.synchronize()
+    dtm = time.perf_counter() - t0
+    value = a.c4_steps * B / dtm
+    tflop_pair = (n_trans * UNET_GFLOP[S] + 2 * MASK_GFLOP[S]) / 1e3
+    free = ~hit_c.bool()
+    res = {"metric": f"generated point-cloud pairs/sec (one GPU), {S}x{S} depth, {n_trans}-step DDIM (DDNM replacement, eta=1)",
+           "value": value, "unit": "pairs/s", "n_gpus": 1, "steps": a.c4_steps, "warmup": 1, "ms_per_step": dtm / a.c4_steps * 1e3,
+           "dtype": dt, "data": "synthetic",
+           "config": {"workload": "configs[4]: 256x256, 250-step DDIM, MX-fp8 U-Net operands, full pipeline", "batch_per_gpu": B,
+                      "image_size": S, "transitions": n_trans, "unet_dim": a.dim, "tflop_per_pair": tflop_pair,
+                      "weights": "synthetic, calibrated head", "operand_format": "OCP MX e4m3 + E8M0 per 32 channels on the 3x3 "
+                      "convolutions with Cout % 128 == 0; 64-channel convolutions, attention and 1x1 convs in bf16"},
+           "end_to_end_mfma_frac": value * tflop_pair / MFMA_PEAK_TFLOPS[dt],
+           "saturated_fraction_inpainted": float(((img <= 0) | (img >= 1))[free].float().mean()) if bool(free.any()) else None}
+    if not a.no_roofline:
+        pdiff = GaussianDiffusion(unet, image_size=S, timesteps=T, sampling_timesteps=steps)
+        nprof = min(20, n_trans)
+        rows = pdiff.step_table()[:nprof]
+        pdiff.step_table = lambda: rows
+        bt = batches[-1]
+        rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+        _, _, cond = G.apply_mask(torch.ones_like(rpj), rpj, hit, 0.5)
+        pdiff.sample(param_cond=G.param_vector(bt["K"]), img_cond=cond, seeds=bt["seeds"], profile=True)
+        torch.cuda.synchronize()
+        pr = pdiff.last_profile(B)
+        ach = pr["conv_flops"] / (pr["conv_ms"] * 1e-3) / 1e12
+        res["roofline"] = {"kernel": CONV_CLASS + " (MX-fp8 operands on the w256mx launches)", "bound": "mfma", "achieved": ach,
+                           "peak": MFMA_PEAK_TFLOPS[dt], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dt], "traffic": None,
+                           "launches": pr["conv_launches"], "avg_launch_us": pr["conv_ms"] * 1e3 / max(1, pr["conv_launches"]),
+                           "flop_per_launch": pr["conv_flops"] / max(1, pr["conv_launches"]),
+                           "share_of_step_time": pr["conv_ms"] / pr["total_ms"],
+                           "measured": f"HIP events around every conv launch, {nprof} transitions, batch {B}"}
+        pdiff.close()
+    diff.close(); unet.close(); mask.close()
+    return res
 
 
 def main():
@@ -249,8 +356,8 @@ def main():
 
     B, S = a.batch, a.size
     dev = torch.device("cuda", local)
-    unet = Unet(a.dim, dtype=a.dtype).init_synthetic(seed=1)
-    mask = None if a.sampler_only else MaskUnet(a.dim, dtype=a.dtype).init_synthetic(seed=2, final_bias=6.0)
+    unet = Unet(a.dim, dtype=a.dtype).init_synthetic(seed=1, calibrated=not a.uncalibrated)
+    mask = None if a.sampler_only else MaskUnet(a.dim, dtype=a.dtype).init_synthetic(seed=2, calibrated=True)
     diff = GaussianDiffusion(unet, image_size=S, timesteps=a.timesteps, sampling_timesteps=a.sampling_steps)
     n_trans = len(diff.step_table())
 
@@ -265,18 +372,62 @@ def main():
                             pose=torch.from_numpy(pose).to(dev),
                             seeds=[synthetic.noise_seed(a.seed, j) for j in idx]))
 
-    def one_batch(bt):
+    # `--streams N` (default 2): N independent pipelines (own network handles, workspaces, sampler graphs), one host thread
+    # and one HIP stream each, take the batches round-robin.  Every batch is still a B-scene launch of the same kernels; what
+    # changes is that one pipeline's launch boundaries, ramps and drains (139 per evaluation) are filled by the other's
+    # kernels instead of idling the chip.  N = 1 is the strictly serial loop of rounds 1-2.
+    pipes = [dict(unet=unet, mask=mask, diff=diff, stream=None)]
+    for k in range(1, max(1, a.streams)):
+        u2 = Unet(a.dim, dtype=a.dtype).init_synthetic(seed=1, calibrated=not a.uncalibrated)
+        m2 = None if a.sampler_only else MaskUnet(a.dim, dtype=a.dtype).init_synthetic(seed=2, calibrated=True)
+        pipes.append(dict(unet=u2, mask=m2, stream=None,
+                          diff=GaussianDiffusion(u2, image_size=S, timesteps=a.timesteps, sampling_timesteps=a.sampling_steps)))
+    if len(pipes) > 1:
+        for pp in pipes:
+            pp["stream"] = torch.cuda.Stream(device=dev)
+
+    def one_batch(bt, pp=None):
+        pp = pp or pipes[0]
+        mask_, diff_ = pp["mask"], pp["diff"]
         pc = G.param_vector(bt["K"])
         if a.sampler_only:
             rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
             _, _, cond = G.apply_mask(torch.ones_like(rpj), rpj, hit, 0.5)
-            return diff.sample(param_cond=pc, img_cond=cond, seeds=bt["seeds"])
+            return diff_.sample(param_cond=pc, img_cond=cond, seeds=bt["seeds"])
         rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
-        _, _, cond = G.apply_mask(mask(rpj), rpj, hit, 0.99)
-        img = diff.sample(param_cond=pc, img_cond=cond, seeds=bt["seeds"])
-        out, _, _ = G.apply_mask(mask(img), img, None, 0.99, want_cond=False)
+        _, hit_c, cond = G.apply_mask(mask_(rpj), rpj, hit, 0.99)
+        img = diff_.sample(param_cond=pc, img_cond=cond, seeds=bt["seeds"])
+        out, _, _ = G.apply_mask(mask_(img), img, None, 0.99, want_cond=False)
         xyz, valid = G.unproject_f64(out, bt["K"], bt["pose"])
+        last.update(img=img, known=hit_c, valid=valid)          # (references only: read after the clock stops)
         return xyz
+
+    last = {}
+
+    def run_batches(lo, hi):
+        if len(pipes) == 1:
+            for i in range(lo, hi):
+                one_batch(batches[i])
+            return
+        import threading
+        errs = []
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(pipes[k]["stream"]):
+                    for i in range(lo + k, hi, len(pipes)):
+                        one_batch(batches[i], pipes[k])
+            except BaseException as e:      # noqa: BLE001 — re-raised on the main thread
+                errs.append(e)
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(len(pipes))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -284,12 +435,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        one_batch(batches[i])
+    if len(pipes) > a.warmup and total_batches:
+        # setup, not a step: pipelines the W warm-up steps would not reach allocate their workspace and capture their graph
+        for k in range(a.warmup, len(pipes)):
+            with torch.cuda.stream(pipes[k]["stream"]):
+                one_batch(batches[0], pipes[k])
+        torch.cuda.synchronize()
+    run_batches(0, a.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(a.warmup, total_batches):
-        one_batch(batches[i])
+    run_batches(a.warmup, total_batches)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -312,16 +467,27 @@ def main():
                                 "configs[2]: full pipeline (SE(3) z-buffer reproject + MaskUnet + DDNM sampler + MaskUnet + f64 unproject)"),
                    "batch_per_gpu": B, "image_size": S, "transitions": n_trans,
                    "sampler": "ddim" if diff.is_ddim_sampling else "ancestral-ddnm", "unet_dim": a.dim,
-                   "noise": "on-device Philox4x32-10 keyed per scene", "weights": "synthetic (deterministic initialiser)",
+                   "noise": "on-device Philox4x32-10 keyed per scene",
+                   "weights": "synthetic (deterministic initialiser" + (")" if a.uncalibrated else ", calibrated 1x1 head: x0 predictions inside (-1, 1))"),
                    "parallelism": f"scene-sharded x{world}, no collectives",
                    "hipgraph": "one captured transition (U-Net + update), replayed per step",
+                   "streams": len(pipes),
                    "tflop_per_pair": tflop_pair},
         "end_to_end_mfma_frac": value / world * tflop_pair / MFMA_PEAK_TFLOPS[a.dtype],
     }
+    if last:
+        # the timed workload is not degenerate: how many in-painted pixels of the last timed batch ended on the [0,1] clamp,
+        # and how many pixels survive the second depth correction into the clouds
+        img, known = last["img"], last["known"].bool()
+        free = ~known
+        res["workload"] = {"saturated_fraction_inpainted": float(((img <= 0) | (img >= 1))[free].float().mean()),
+                           "inpainted_fraction": float(free.float().mean()),
+                           "inpainted_depth_m": {"mean": float(img[free].mean()) * 10, "std": float(img[free].std()) * 10},
+                           "points_kept_fraction": float(last["valid"].float().mean())}
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel = conv_igemm_kernel (implicit-GEMM convolution).  Its launches are timed live with HIP events
-        # on the sampler's own stream over `profile_transitions` transitions of the same workload (eager launches).
+        # dominant kernel class = the MFMA convolutions (w256 + c64 + ws + igemm).  Their launches are timed live with HIP
+        # events on the sampler's own stream over `profile_transitions` transitions of the same workload (eager launches).
         nprof = min(a.profile_transitions, n_trans)
         pdiff = GaussianDiffusion(unet, image_size=S, timesteps=a.timesteps, sampling_timesteps=a.sampling_steps)
         rows = pdiff.step_table()[:nprof]
@@ -346,7 +512,7 @@ def main():
             else:
                 traffic_src = "profiles/conv_hbm_traffic.json is stale (conv kernel sources changed since the PMC passes): not reported"
         res["roofline"] = {
-            "kernel": "MFMA convolutions: conv3x3_ws_kernel (3x3, wave-specialised persistent) + conv_igemm_kernel (1x1 / 4x4s2)",
+            "kernel": CONV_CLASS,
             "bound": "mfma", "achieved": ach,
             "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[a.dtype],
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE*2 + WRITE_SIZE)", "traffic_source": traffic_src,
@@ -362,7 +528,7 @@ def main():
         pdiff.close()
     if not a.no_e2e_files and not a.sampler_only:
         # every rank runs its own shard of the generate_dataset loop; aggregate like the headline metric
-        e2e = e2e_files(a, unet, mask, diff, rank, world, B, S)
+        e2e = e2e_files(a, unet, mask, diff, rank, world, B, S, lanes=[(pp["diff"], pp["mask"]) for pp in pipes[1:]])
         dt_e = e2e["seconds"]
         if dist is not None:
             tt = torch.tensor([dt_e], device=dev, dtype=torch.float64)
@@ -373,8 +539,10 @@ def main():
                    what="Generator.generate --synthetic: memory-cloud z-buffer + MaskUnet + sampler + MaskUnet + unprojection + "
                         "crop / 0.025 voxel grid / PLY + PNG + text files through the C++ writer pool, overlapped with the next batch")
         res["e2e_files"] = e2e
-    if rank == 0 and not a.no_drift and a.dtype == "bf16" and not a.sampler_only:
-        res["bf16_drift"] = bf16_drift(a, G, synthetic, S, n_trans)
+    if rank == 0 and not a.no_drift and a.dim == 64:
+        res["drift_vs_reference"] = drift_vs_reference([a.dtype] if a.dtype == "mxfp8" else [a.dtype, "mxfp8"], a.dim)
+    if rank == 0 and not a.no_configs4 and not a.sampler_only:
+        res["configs4"] = configs4_leg(a, G, synthetic, rank)
     if rank == 0 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(S, a.dim)
 

@@ -6,8 +6,12 @@
 writes ./<dataset_name>/data/scene-XXXXXX/{sample-000000.cloud.ply, sample-000001.cloud.ply, camera-intrinsics.txt,
 sample-*.pose.txt, *.png}.  The hot path runs on the MI355X HIP library.  Additive flags (defaults = the reference's
 hard-coded literals, generate_dataset.py:32-55):
-  --image_size 256  --timesteps 1000  --sampling_timesteps 250  --batch_size 4  --dim 64  --dtype bf16
+  --image_size 256  --timesteps 1000  --sampling_timesteps 250  --batch_size 4  --dim 64
+  --dtype fp32|bf16|mxfp8   fp32 (default: the reference runs with amp=False, generate_dataset.py:54) is the parity mode;
+                            bf16 = BASELINE configs[1-3] throughput mode; mxfp8 = configs[4] (3x3 convs on block-scaled fp8 MFMA)
   --data_root /path/to/3DMatch-RGBD/train
+  --streams 2         lanes per GPU: batches are dealt round-robin to N host threads / HIP streams with their own network
+                      handles, so one lane's launch gaps are filled by the other's kernels (+7 % pairs/s); files are identical
   --synthetic SEED    synthetic scenes instead of 3DMatch frames (no dataset needed)
   --noise_seed N      seed of the diffusion noise (default: fresh entropy, printed; synthetic runs default to SEED)
   --resume synthetic[:SEED]   deterministic synthetic weights instead of ./successive_ddnm_diffusion_results/model-<resume>.pt
@@ -31,7 +35,10 @@ def main():
     p.add_argument("--sampling_timesteps", default=250, type=int)
     p.add_argument("--batch_size", default=4, type=int)
     p.add_argument("--dim", default=64, type=int)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "mxfp8"],
+                   help="arithmetic of the two U-Nets: fp32 = parity mode (the reference's amp=False), bf16 / mxfp8 = throughput modes")
+    p.add_argument("--streams", default=2, type=int,
+                   help="concurrent lanes per GPU (own network handles + HIP stream + host thread each; batches dealt round-robin)")
     p.add_argument("--data_root", default="/path/to/3DMatch-RGBD/train", type=str)
     p.add_argument("--synthetic", default=None, type=int, help="seed of the synthetic scene generator")
     p.add_argument("--mask_threshold", default=0.99, type=float)
@@ -47,7 +54,7 @@ def main():
     from pointreggpt_amd.weights import maskunet_state_from_checkpoint
 
     rank, world, local = sharding.rank_world()
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # (more ranks than devices: ranks share, used by the tests)
     start, stop = sharding.shard_range(args.start_scene_index, args.stop_scene_index, rank, world, args.batch_size)
 
     model = Unet(dim=args.dim, param_cond_dim=4, dim_mults=(1, 2, 4, 8), channels=1, dtype=args.dtype)
@@ -58,25 +65,37 @@ def main():
     generator = Generator(diffusion, args.data_root, batch_size=args.batch_size,
                           results_folder="./successive_ddnm_diffusion_results",
                           samples_folder="./{}/data".format(args.dataset_name), synthetic_seed=args.synthetic)
-    if args.resume.startswith("synthetic"):
-        seed = int(args.resume.split(":")[1]) if ":" in args.resume else 0
-        model.init_synthetic(seed)
-        depth_correction.init_synthetic(seed + 1, final_bias=8.0)
-    else:
-        generator.load(args.resume)
-        ckpt = torch.load("./depth_correction_results/model-best.pt", map_location="cpu")
-        depth_correction.load_state_dict(maskunet_state_from_checkpoint(ckpt, depth_correction.cfg))
+
+    def load_weights(unet, mask):
+        if args.resume.startswith("synthetic"):
+            seed = int(args.resume.split(":")[1]) if ":" in args.resume else 0
+            unet.init_synthetic(seed)
+            mask.init_synthetic(seed + 1, final_bias=8.0)
+        else:
+            generator.load(args.resume, unet=unet)
+            ckpt = torch.load("./depth_correction_results/model-best.pt", map_location="cpu")
+            mask.load_state_dict(maskunet_state_from_checkpoint(ckpt, mask.cfg))
+
+    load_weights(model, depth_correction)
+    n_batches = (max(0, stop - start) + args.batch_size - 1) // args.batch_size
+    lanes = []
+    for _ in range(1, max(1, min(args.streams, n_batches))):
+        u2 = Unet(dim=args.dim, param_cond_dim=4, dim_mults=(1, 2, 4, 8), channels=1, dtype=args.dtype)
+        m2 = MaskUnet(dim=args.dim, dim_mults=(1, 2, 4, 8), dtype=args.dtype)
+        load_weights(u2, m2)
+        lanes.append((GaussianDiffusion(u2, image_size=args.image_size, timesteps=args.timesteps,
+                                        sampling_timesteps=args.sampling_timesteps, loss_type="l1", objective="pred_x0",
+                                        beta_schedule="sigmoid", ddim_sampling_eta=1.0, is_ddnm_sampling=True), m2))
     if args.noise_seed is None:
-        import secrets
-        args.noise_seed = secrets.randbits(63) if args.synthetic is None else int(args.synthetic)
-    print("noise seed: {}".format(args.noise_seed))
-    if args.synthetic is None:
-        import numpy as np
-        np.random.seed((args.noise_seed + start) % (2 ** 32))   # the reference's global pose stream (sd:417-443), per shard
+        # ONE seed for the whole job: every rank derives it from the launcher's run id (torchrun exports the same
+        # TORCHELASTIC_RUN_ID / MASTER_PORT to all ranks), so a multi-rank run is reproducible from the one logged value and a
+        # scene's noise key does not depend on the shard that produced it
+        args.noise_seed = sharding.job_seed() if args.synthetic is None else int(args.synthetic)
+    print("[rank {}/{}] noise seed: {}  scenes [{}, {})".format(rank, world, args.noise_seed, start, stop))
     if stop > start:
         generator.generate(start_scene_index=start, stop_scene_index=stop, num_samples=args.num_samples,
                            has_refine_step=False, depth_correction=depth_correction,
-                           mask_threshold=args.mask_threshold, noise_seed=args.noise_seed)
+                           mask_threshold=args.mask_threshold, noise_seed=args.noise_seed, lanes=lanes)
     torch.cuda.synchronize()
 
 

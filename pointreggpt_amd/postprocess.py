@@ -273,6 +273,28 @@ class WriterPool:
             self._lib.load().prg_pool_destroy(self._h)
             self._h = C.c_void_p()
 
+    # `with WriterPool() as pool:` — leaving the block normally waits for every file and raises the first worker error;
+    # leaving it on an exception lets the already queued jobs finish (nothing is half-written), reports a worker error
+    # on stderr without masking the original exception, and tears the pool down.  Callers submit a batch's resume marker
+    # only after `wait()` succeeded, so an aborted run never leaves a marker behind.
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        worker_error = None
+        try:
+            if self._h:
+                self.wait()
+        except Exception as e:          # noqa: BLE001 — surfaced below
+            worker_error = e
+        self.close()
+        if worker_error is not None:
+            if exc_type is None:
+                raise worker_error
+            import sys
+            print(f"writer pool: a queued job also failed while unwinding: {worker_error}", file=sys.stderr)
+        return False
+
     def __del__(self):
         try:
             self.close()

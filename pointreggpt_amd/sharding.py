@@ -26,3 +26,30 @@ def num_to_groups(num: int, divisor: int) -> List[int]:
     """[divisor]*k + [remainder] (sd:538-544)."""
     groups, rem = divmod(num, divisor)
     return [divisor] * groups + ([rem] if rem > 0 else [])
+
+
+def job_seed() -> int:
+    """A fresh 63-bit seed that is THE SAME on every rank of one launch (no collective needed): derived from the
+    launcher's run id when there is one (torchrun exports TORCHELASTIC_RUN_ID and MASTER_ADDR/PORT identically to all ranks;
+    `--standalone` run ids are random per launch), from fresh entropy in a single-process run.  PRG_JOB_SEED overrides."""
+    import hashlib
+    import secrets
+    if os.environ.get("PRG_JOB_SEED"):
+        return int(os.environ["PRG_JOB_SEED"]) & ((1 << 63) - 1)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        key = "|".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT",
+                                                        "TORCHELASTIC_RESTART_COUNT"))
+        run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+        if run_id in ("", "none"):
+            # a fixed run id ('none' is torchrun's default): mix in the launcher's pid, which all ranks share as their parent
+            key += "|ppid=%d" % os.getppid()
+        return int.from_bytes(hashlib.sha256(key.encode()).digest()[:8], "little") & ((1 << 63) - 1)
+    return secrets.randbits(63)
+
+
+def batch_pose_seed(job_seed_value: int, first_scene_index: int, sample_index: int) -> int:
+    """Seed of numpy's legacy global stream for one batch's `random_sample_pose` draw (sd:417-443): a function of the
+    job seed and the batch's first scene only, so re-sharding or resuming the same job reproduces the same poses."""
+    import numpy as np
+    return int(np.random.SeedSequence([int(job_seed_value) & 0xFFFFFFFFFFFFFFFF, int(first_scene_index),
+                                       int(sample_index), 0x706F7365]).generate_state(1, np.uint32)[0])

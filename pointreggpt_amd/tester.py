@@ -65,48 +65,47 @@ class Tester:
         """Returns, per batch, the (B, 1, S, S*num_samples) strip of all views (what the reference concatenates for its
         overview).  `noise[k]` = stored draws for view k (parity tests); default on-device Philox keyed per scene/view."""
         dev, S = self.device, self.image_size
-        pool = PP.WriterPool()
-        strips = []
-        first = 0
-        for batch in num_to_groups(num_scenes, self.batch_size):
-            ids = list(range(first, first + batch))
-            first += batch
-            K = self._intrinsics(batch)
-            K_dev = torch.from_numpy(K).to(dev)
-            absolute = np.stack([np.eye(4) for _ in range(batch)]).astype(np.float32)
-            param_cond = G.param_vector(K_dev)
-            images = self._sample(param_cond, None, ids, 0, noise)                       # unconditional (sd:1978)
-            views = [images]
-            clouds = G.point_clouds(images, K_dev, None, clip=(0.5, 3.5))
-            img_host = images.cpu().numpy()
-            zero = np.zeros((S, S), dtype=np.float32)
-            for j, i in enumerate(ids):
-                pool.image01(str(self.samples_folder / f"scene-{i}-sample-0.png"), self._strip(zero, zero, img_host[j, 0]))
-                pool.cloud(str(self.samples_folder / f"scene-{i}-sample-0.ply"), clouds[j], None, crop=False, voxel=0.0)
-                pool.text(str(self.samples_folder / f"scene-{i}-camera-intrinsics.txt"), K[j])
-            for k in range(1, num_samples):
-                relative = np.stack([np.eye(4) for _ in range(batch)])
-                relative[..., :3, 3] = np.asarray(step, dtype=np.float64)
-                relative = relative.astype(np.float32)
-                absolute = relative @ absolute
-                rel_dev = torch.from_numpy(relative).to(dev)
-                rpj, hit = G.reproject_tensor(images, K_dev, rel_dev, clip=(0, 10), depth_unit=10.0, out_scale=1.0)
-                if np.sum(absolute[..., :3, 3] ** 2) != 0:
-                    rpj, hit = G.occlusion_filter(rpj, hit)
-                rpj = rpj * 0.1
-                cond = torch.cat([rpj, hit.to(rpj.dtype)], dim=1) * 2 - 1
-                last = images
-                images = self._sample(param_cond, cond, ids, k, noise, has_refine_step)
-                views.append(images)
-                clouds = G.point_clouds(images, K_dev, torch.from_numpy(absolute).to(dev), clip=(0.5, 3.5))
-                l_h, r_h, n_h = last.cpu().numpy(), rpj.cpu().numpy(), images.cpu().numpy()
+        with PP.WriterPool() as pool:
+            strips = []
+            first = 0
+            for batch in num_to_groups(num_scenes, self.batch_size):
+                ids = list(range(first, first + batch))
+                first += batch
+                K = self._intrinsics(batch)
+                K_dev = torch.from_numpy(K).to(dev)
+                absolute = np.stack([np.eye(4) for _ in range(batch)]).astype(np.float32)
+                param_cond = G.param_vector(K_dev)
+                images = self._sample(param_cond, None, ids, 0, noise)                       # unconditional (sd:1978)
+                views = [images]
+                clouds = G.point_clouds(images, K_dev, None, clip=(0.5, 3.5))
+                img_host = images.cpu().numpy()
+                zero = np.zeros((S, S), dtype=np.float32)
                 for j, i in enumerate(ids):
-                    pool.image01(str(self.samples_folder / f"scene-{i}-sample-{k}.png"),
-                                 self._strip(l_h[j, 0], r_h[j, 0], n_h[j, 0]))
-                    pool.cloud(str(self.samples_folder / f"scene-{i}-sample-{k}.ply"), clouds[j], None, crop=False, voxel=0.0)
-            strips.append(torch.cat(views, dim=-1))
-        pool.wait()
-        pool.close()
+                    pool.image01(str(self.samples_folder / f"scene-{i}-sample-0.png"), self._strip(zero, zero, img_host[j, 0]))
+                    pool.cloud(str(self.samples_folder / f"scene-{i}-sample-0.ply"), clouds[j], None, crop=False, voxel=0.0)
+                    pool.text(str(self.samples_folder / f"scene-{i}-camera-intrinsics.txt"), K[j])
+                for k in range(1, num_samples):
+                    relative = np.stack([np.eye(4) for _ in range(batch)])
+                    relative[..., :3, 3] = np.asarray(step, dtype=np.float64)
+                    relative = relative.astype(np.float32)
+                    absolute = relative @ absolute
+                    rel_dev = torch.from_numpy(relative).to(dev)
+                    rpj, hit = G.reproject_tensor(images, K_dev, rel_dev, clip=(0, 10), depth_unit=10.0, out_scale=1.0)
+                    if np.sum(absolute[..., :3, 3] ** 2) != 0:
+                        rpj, hit = G.occlusion_filter(rpj, hit)
+                    rpj = rpj * 0.1
+                    cond = torch.cat([rpj, hit.to(rpj.dtype)], dim=1) * 2 - 1
+                    last = images
+                    images = self._sample(param_cond, cond, ids, k, noise, has_refine_step)
+                    views.append(images)
+                    clouds = G.point_clouds(images, K_dev, torch.from_numpy(absolute).to(dev), clip=(0.5, 3.5))
+                    l_h, r_h, n_h = last.cpu().numpy(), rpj.cpu().numpy(), images.cpu().numpy()
+                    for j, i in enumerate(ids):
+                        pool.image01(str(self.samples_folder / f"scene-{i}-sample-{k}.png"),
+                                     self._strip(l_h[j, 0], r_h[j, 0], n_h[j, 0]))
+                        pool.cloud(str(self.samples_folder / f"scene-{i}-sample-{k}.ply"), clouds[j], None, crop=False, voxel=0.0)
+                strips.append(torch.cat(views, dim=-1))
+            pool.wait()
         return strips
 
     # -- Tester.generate (sd:2095-2247) ------------------------------------------------------------------------------
@@ -117,41 +116,40 @@ class Tester:
         (The reference hands pc2depth_tensor the whole batch's intrinsics next to ONE scene's cloud, sd:2177-2184; the
         evident intent — each scene with its own intrinsics — is what runs here.)"""
         dev, S = self.device, self.image_size
-        pool = PP.WriterPool()
-        out = []
-        first = 0
-        for batch in num_to_groups(num_scenes, self.batch_size):
-            ids = list(range(first, first + batch))
-            first += batch
-            K = self._intrinsics(batch)
-            K_dev = torch.from_numpy(K).to(dev)
-            absolute = np.stack([np.eye(4) for _ in range(batch)]).astype(np.float32)
-            param_cond = G.param_vector(K_dev)
-            images = self._sample(param_cond, None, ids, 0, noise)
-            scene = [PP.native_voxel_down_sample(c, voxel_size).astype(np.float32)
-                     for c in G.point_clouds(images, K_dev, None, clip=(0.5, 3.5))]
-            img_host = images.cpu().numpy()
-            zero = np.zeros((S, S), dtype=np.float32)
-            for j, i in enumerate(ids):
-                pool.image01(str(self.samples_folder / f"scene-{i}-sample-0.png"), self._strip(zero, zero, img_host[j, 0]))
-            for k in range(1, num_samples):
-                relative = G.random_sample_transform(K, image_size=S)
-                absolute = relative @ absolute
-                # the accumulated clouds moved into the new cameras and z-buffered: one ragged launch (sd:2168-2190)
-                rpj, hit = G.project_clouds(scene, absolute, K, S, dev, depth_scale=0.1)
-                cond = torch.cat([rpj, hit.to(rpj.dtype)], dim=1) * 2 - 1
-                last = images
-                images = self._sample(param_cond, cond, ids, k, noise, has_refine_step)
-                new = G.point_clouds(images, K_dev, torch.from_numpy(absolute).to(dev), clip=(0.5, 3.5))
-                l_h, r_h, n_h = last.cpu().numpy(), rpj.cpu().numpy(), images.cpu().numpy()
+        with PP.WriterPool() as pool:
+            out = []
+            first = 0
+            for batch in num_to_groups(num_scenes, self.batch_size):
+                ids = list(range(first, first + batch))
+                first += batch
+                K = self._intrinsics(batch)
+                K_dev = torch.from_numpy(K).to(dev)
+                absolute = np.stack([np.eye(4) for _ in range(batch)]).astype(np.float32)
+                param_cond = G.param_vector(K_dev)
+                images = self._sample(param_cond, None, ids, 0, noise)
+                scene = [PP.native_voxel_down_sample(c, voxel_size).astype(np.float32)
+                         for c in G.point_clouds(images, K_dev, None, clip=(0.5, 3.5))]
+                img_host = images.cpu().numpy()
+                zero = np.zeros((S, S), dtype=np.float32)
                 for j, i in enumerate(ids):
-                    pool.image01(str(self.samples_folder / f"scene-{i}-sample-{k}.png"),
-                                 self._strip(l_h[j, 0], r_h[j, 0], n_h[j, 0]))
-                    merged = np.concatenate([scene[j].astype(np.float64), new[j]], axis=0)
-                    scene[j] = PP.native_voxel_down_sample(merged, voxel_size).astype(np.float32)
-            for j, i in enumerate(ids):
-                pool.cloud(str(self.samples_folder / f"scene-{i}.ply"), scene[j], None, crop=False, voxel=0.025)
-            out.append(scene)
-        pool.wait()
-        pool.close()
+                    pool.image01(str(self.samples_folder / f"scene-{i}-sample-0.png"), self._strip(zero, zero, img_host[j, 0]))
+                for k in range(1, num_samples):
+                    relative = G.random_sample_transform(K, image_size=S)
+                    absolute = relative @ absolute
+                    # the accumulated clouds moved into the new cameras and z-buffered: one ragged launch (sd:2168-2190)
+                    rpj, hit = G.project_clouds(scene, absolute, K, S, dev, depth_scale=0.1)
+                    cond = torch.cat([rpj, hit.to(rpj.dtype)], dim=1) * 2 - 1
+                    last = images
+                    images = self._sample(param_cond, cond, ids, k, noise, has_refine_step)
+                    new = G.point_clouds(images, K_dev, torch.from_numpy(absolute).to(dev), clip=(0.5, 3.5))
+                    l_h, r_h, n_h = last.cpu().numpy(), rpj.cpu().numpy(), images.cpu().numpy()
+                    for j, i in enumerate(ids):
+                        pool.image01(str(self.samples_folder / f"scene-{i}-sample-{k}.png"),
+                                     self._strip(l_h[j, 0], r_h[j, 0], n_h[j, 0]))
+                        merged = np.concatenate([scene[j].astype(np.float64), new[j]], axis=0)
+                        scene[j] = PP.native_voxel_down_sample(merged, voxel_size).astype(np.float32)
+                for j, i in enumerate(ids):
+                    pool.cloud(str(self.samples_folder / f"scene-{i}.ply"), scene[j], None, crop=False, voxel=0.025)
+                out.append(scene)
+            pool.wait()
         return out

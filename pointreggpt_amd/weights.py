@@ -141,7 +141,24 @@ def num_params(cfg: UnetConfig) -> int:
 # deterministic initialiser
 # --------------------------------------------------------------------------------------------
 
+# Output calibration of the synthetic denoiser (`calibrated=True`).  The unit-gain initialiser ends in an O(5) network
+# output: every x0 prediction lands on the sampler's [-1,1] clamp and 98 % of the in-painted pixels of a chain finish
+# saturated — a constant image that hides precision drift and starves the kernels after the sampler.  Shrinking the
+# 1x1 head by CALIBRATED_FINAL_GAIN and centring it with CALIBRATED_FINAL_BIAS keeps the prediction inside the open
+# interval (measured with the reference on CPU: 0.1 % of the in-painted pixels saturate after a 50-step DDIM chain at
+# 64x64, depth 2-4 m with 0.7-1.5 m spread): the workload every round-3 fixture, test and bench.py use.
+CALIBRATED_FINAL_GAIN = 0.2
+CALIBRATED_FINAL_BIAS = -0.25
+# The same for the synthetic depth-correction net (MaskUnet, thresholded at 0.99 = logit 4.595 by its caller, sd:2564-2581):
+# an untrained head never crosses the threshold, a plain bias shift makes it keep everything or (round 2's final_bias=6:
+# 0.7 % kept) nothing.  Gain 0.2 / bias 5.4 puts the threshold inside the logit distribution of the seed-2 net bench.py uses
+# (raw logits -3.3 +- 0.8 on reprojected synthetic depth): ~85 % of the pixels are kept, in a spatially varying pattern.
+CALIBRATED_MASK_GAIN = 0.2
+CALIBRATED_MASK_BIAS = 5.4
+
+
 def synth_state_dict(cfg: UnetConfig, seed: int = 0, *, final_bias: float | None = None,
+                     final_gain: float | None = None, calibrated: bool = False,
                      dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
     """Counter-based synthetic weights: parameter i of the spec is drawn from Philox(key=seed, counter=i).
 
@@ -149,8 +166,13 @@ def synth_state_dict(cfg: UnetConfig, seed: int = 0, *, final_bias: float | None
     scaling, so activations neither vanish nor explode through ~100 layers); biases ~ U(-0.1, 0.1);
     norm gains ~ 1 + U(-0.2, 0.2) and norm biases ~ U(-0.1, 0.1) so that every affine term is exercised
     by the parity tests.  ``final_bias`` overrides the last conv's bias (MaskUnet thresholds at 0.99:
-    an untrained net never crosses it unless the logit is shifted).
+    an untrained net never crosses it unless the logit is shifted); ``final_gain`` multiplies the last conv's weight;
+    ``calibrated=True`` = the two CALIBRATED_* constants above (a denoiser whose x0 prediction stays inside (-1, 1)).
     """
+    if calibrated:
+        g0, b0 = (CALIBRATED_MASK_GAIN, CALIBRATED_MASK_BIAS) if cfg.sigmoid_out else (CALIBRATED_FINAL_GAIN, CALIBRATED_FINAL_BIAS)
+        final_gain = g0 if final_gain is None else final_gain
+        final_bias = b0 if final_bias is None else final_bias
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for i, (name, shape) in enumerate(param_spec(cfg).items()):
         g = np.random.Generator(np.random.Philox(key=int(seed) & 0xFFFFFFFFFFFFFFFF, counter=[0, 0, 0, i]))
@@ -164,9 +186,11 @@ def synth_state_dict(cfg: UnetConfig, seed: int = 0, *, final_bias: float | None
             fan_in = int(np.prod(shape[1:]))
             v = np.sqrt(3.0 / fan_in) * u
         out[name] = torch.from_numpy(v.astype(np.float32)).to(dtype)
+    fc = "final_conv.0" if cfg.sigmoid_out else "final_conv"
+    if final_gain is not None:
+        out[fc + ".weight"] = (out[fc + ".weight"].to(torch.float32) * np.float32(final_gain)).to(dtype)
     if final_bias is not None:
-        fc = "final_conv.0.bias" if cfg.sigmoid_out else "final_conv.bias"
-        out[fc] = torch.full_like(out[fc], float(final_bias))
+        out[fc + ".bias"] = torch.full_like(out[fc + ".bias"], float(final_bias))
     return out
 
 

@@ -534,6 +534,93 @@ def test_benchmark_batch_bf16_against_oracle(hip):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# chains of REAL length against the real reference, on the calibrated (non-saturating) synthetic denoiser:
+#   G19  1000-step ancestral DDNM chain @64x64 (sd:1283-1317)      G20  250-step DDIM chain @128x128 (sd:1319-1392)
+# fp32 mode is held to the north star: point-XYZ L-infinity <= max(1e-4 m, the REFERENCE's own 1-thread-vs-8-thread
+# spread on that chain).  bf16 and mxfp8 drift is reported in metres against the reference and bounded at <= 2x observed.
+# ------------------------------------------------------------------------------------------------------------------
+def golden_ancestral(hip, golden, net, S):
+    """GaussianDiffusion(timesteps=1000) with the fixtures' host's float32 table (sigma = exp(0.5 logvar) is a host exp)."""
+    d = hip.GaussianDiffusion(net, image_size=S, timesteps=1000)
+    g0 = golden("G0_host_tables")
+    rows = d.step_table()
+    assert [r["t"] for r in rows] == g0["anc1000_t"].tolist()
+    worst = 0.0
+    for r, v in zip(rows, g0["anc1000_rows"]):
+        for j, k in enumerate(("c_x0", "c_x", "c_eps", "sigma", "sqrt_recip", "sqrt_recipm1")):
+            if v[j] != 0:
+                worst = max(worst, abs(r[k] - float(v[j])) / abs(float(v[j])))
+            r[k] = float(v[j])
+    print(f"ancestral coefficients: this host vs the fixtures' host differ by up to {worst:.2e} (relative)")
+    d.step_table = lambda: rows
+    return d
+
+
+def _run_long_chain(hip, golden, name, dtype):
+    from conftest import LONG_CHAINS, regenerate_chain_noise
+    c = LONG_CHAINS[name]
+    g = golden(name)
+    sd = W.synth_state_dict(W.unet_config(64), int(g["wseed"]), calibrated=True)
+    net = golden_unet(hip, golden, 64, dtype, sd)
+    d = golden_ddim(hip, golden, net, c["S"], c["steps"]) if c["steps"] else golden_ancestral(hip, golden, net, c["S"])
+    nz = regenerate_chain_noise(g).reshape(-1, 1, 1, c["S"], c["S"])
+    out = d.sample(param_cond=D(g["pc"]), img_cond=D(g["img_cond"]), noise=nz.cuda())
+    K, pose = D(g["K"]), D(g["pose"])
+    cloud = hip.G.point_clouds(out, K, pose)[0]
+    img = out.cpu().numpy()
+    known = (g["img_cond"][:, 1:2] + 1) * 0.5 > 0.5
+    assert np.array_equal(img[known], g["sampled"][known]), "DDNM known pixels must be bit-exact in every precision mode"
+    valid = lambda a: (a[0, 0] * 10 > 0.5) & (a[0, 0] * 10 < 10)
+    v_hip, v_ref = valid(img), valid(g["sampled"])
+    free = ~known
+    dd = np.abs(img.astype(np.float64) - g["sampled"])[free] * 10.0          # metres, in-painted pixels
+    rep = {"depth_max_m": float(dd.max()), "depth_mean_m": float(dd.mean()), "depth_median_m": float(np.median(dd)),
+           "same_valid_mask": bool(np.array_equal(v_hip, v_ref)), "points": (len(cloud), len(g["cloud"]))}
+    if rep["same_valid_mask"]:
+        rep["xyz_linf_m"] = float(np.abs(cloud - g["cloud"]).max())
+    else:                                                                          # compare the points both keep
+        both = (v_hip & v_ref).reshape(-1)
+        ch = np.full((v_hip.size, 3), np.nan); ch[v_hip.reshape(-1)] = cloud
+        cr = np.full((v_ref.size, 3), np.nan); cr[v_ref.reshape(-1)] = g["cloud"]
+        rep["xyz_linf_m"] = float(np.abs(ch[both] - cr[both]).max())
+    rep["saturated_fraction"] = float(((img <= 0) | (img >= 1))[free].mean())
+    d.close(); net.close()
+    return g, rep, img
+
+
+@pytest.mark.parametrize("name", ["G19_chain1000_ancestral_64", "G20_ddim250_128"])
+def test_long_chain_fp32_north_star(hip, golden, name):
+    g, rep, img = _run_long_chain(hip, golden, name, "fp32")
+    spread = float(g["xyz_spread_1_vs_8_threads_m"])
+    print(f"{name} fp32: point-XYZ L-inf vs reference {rep['xyz_linf_m']:.3e} m (north star 1e-4 m; the reference moves by "
+          f"{spread:.3e} m between 1 and 8 threads and sits {float(g['xyz_ref_to_exact_m']):.3e} m from its float64 twin); "
+          f"in-painted depth max {rep['depth_max_m']:.3e} m mean {rep['depth_mean_m']:.3e} m; "
+          f"|hip - exact|max {maxerr(torch.from_numpy(img), g['sampled_exact']) * 10:.3e} m; saturated {rep['saturated_fraction']:.4f}")
+    assert rep["same_valid_mask"] and rep["points"][0] == rep["points"][1]
+    assert rep["saturated_fraction"] < 0.2
+    assert rep["xyz_linf_m"] <= max(1e-4, spread), rep
+
+
+# <= 2x observed on the driver-class box (printed by the test): (depth max, depth mean, xyz L-inf) in metres
+LONG_DRIFT_BOUNDS = {("G19_chain1000_ancestral_64", "bf16"): (None, None, None), ("G19_chain1000_ancestral_64", "mxfp8"): (None, None, None),
+                     ("G20_ddim250_128", "bf16"): (None, None, None), ("G20_ddim250_128", "mxfp8"): (None, None, None)}
+
+
+@pytest.mark.parametrize("name", ["G19_chain1000_ancestral_64", "G20_ddim250_128"])
+@pytest.mark.parametrize("dtype", ["bf16", "mxfp8"])
+def test_long_chain_reduced_precision_drift_in_metres(hip, golden, name, dtype):
+    """The throughput modes on the same chains, against the REFERENCE (not against this library's fp32 mode)."""
+    g, rep, _ = _run_long_chain(hip, golden, name, dtype)
+    print(f"{name} {dtype}: in-painted depth vs reference max {rep['depth_max_m']:.3e} m mean {rep['depth_mean_m']:.3e} m "
+          f"median {rep['depth_median_m']:.3e} m; point-XYZ L-inf {rep['xyz_linf_m']:.3e} m; same valid mask "
+          f"{rep['same_valid_mask']}; saturated {rep['saturated_fraction']:.4f}")
+    assert rep["saturated_fraction"] < 0.2
+    mx, mean, xyz = LONG_DRIFT_BOUNDS[(name, dtype)]
+    assert mx is not None, "bounds not recorded yet"
+    assert rep["depth_max_m"] <= mx and rep["depth_mean_m"] <= mean and rep["xyz_linf_m"] <= xyz, rep
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # successive multi-view generation (Tester.sample / Tester.generate, sd:1960-2247): refine step, occlusion filter
 # ------------------------------------------------------------------------------------------------------------------
 def test_refine_step_and_occlusion_filter(hip, golden):
@@ -804,6 +891,72 @@ def test_unet_mxfp8_drift_reported(hip, golden):
     assert e <= MXFP8_MAX and em <= MXFP8_MEAN
 
 
+def test_mxfp8_at_256_configs4_forward(hip, golden):
+    """BASELINE configs[4] in its own format: MX-fp8 3x3 convolutions at 256x256.  (a) the G16 fixture (B = 1: the small-launch
+    dispatch); (b) a B = 16 batch — the launch shape bench.py's configs4 leg times, where the 256-pixel MX kernel runs —
+    whose slot 0 is the fixture's input (reference = G16) and whose slot 15 is checked against the CPU oracle."""
+    from oracle import unet as OU
+    g = golden("G16_unet_dim64_256")
+    sd = W.synth_state_dict(W.unet_config(64), 16)
+    net = golden_unet(hip, golden, 64, "mxfp8", sd)
+    y1 = net(D(g["x"]), D(g["t"]), D(g["pc"]))
+    print(f"mxfp8 @256 B=1: max {maxerr(y1, g['y']):.3e} mean {meanerr(y1, g['y']):.3e}")
+    assert maxerr(y1, g["y"]) <= MXFP8_MAX and meanerr(y1, g["y"]) <= MXFP8_MEAN
+    gen = torch.Generator().manual_seed(256)
+    x = torch.randn((16, 1, 256, 256), generator=gen)
+    x[0] = torch.from_numpy(g["x"][0])
+    t = torch.randint(0, 1000, (16,), generator=gen)
+    t[0] = int(g["t"][0])
+    pc = torch.from_numpy(g["pc"]).repeat(16, 1) + torch.randn((16, 4), generator=gen)
+    pc[0] = torch.from_numpy(g["pc"][0])
+    y = net(x.cuda(), t.cuda(), pc.cuda()).cpu()
+    ref15 = OU.unet_forward(sd, x[15:16], t[15:16], pc[15:16])
+    e0, m0 = maxerr(y[0:1], g["y"]), meanerr(y[0:1], g["y"])
+    e15, m15 = maxerr(y[15:16], ref15.numpy()), meanerr(y[15:16], ref15.numpy())
+    print(f"mxfp8 @256 B=16: slot 0 vs G16 max {e0:.3e} mean {m0:.3e}; slot 15 vs oracle max {e15:.3e} mean {m15:.3e}")
+    assert np.isfinite(y.numpy()).all()
+    assert max(e0, e15) <= MXFP8_MAX and max(m0, m15) <= MXFP8_MEAN
+
+
+MX_CHAIN256_MAX_M, MX_CHAIN256_MEAN_M = None, None      # metres, in-painted pixels, <= 2x observed
+
+
+def test_mxfp8_ddim_chain_at_256_configs4(hip):
+    """configs[4]'s sampler at its resolution: a DDIM chain (1000 -> 6 steps, eta = 1, DDNM replacement) at 256x256, B = 16,
+    MX-fp8 operands, calibrated weights, stored noise, against the CPU oracle for two batch slots: known pixels bit-exact,
+    in-painted drift reported in metres and bounded."""
+    from oracle import diffusion as OD
+    from oracle import unet as OU
+    from pointreggpt_amd import synthetic
+    B, S, steps = 16, 256, 6
+    sd = W.synth_state_dict(W.unet_config(64), 256, calibrated=True)
+    depth, K, pose = synthetic.synth_batch(256, range(B), S)
+    Kd = D(K)
+    rpj, hit = hip.G.reproject_tensor(D(depth), Kd, D(pose), clip=(0, 10), depth_unit=10.0, out_scale=0.1)
+    _, _, cond = hip.G.apply_mask(torch.ones_like(rpj), rpj, hit, 0.5)
+    pc = hip.G.param_vector(Kd)
+    gen = torch.Generator().manual_seed(2560)
+    noise = torch.randn((steps, B, 1, S, S), generator=gen)
+    net = hip.Unet(64, dtype="mxfp8").load_state_dict(sd)
+    d = hip.GaussianDiffusion(net, image_size=S, timesteps=1000, sampling_timesteps=steps)
+    out = d.sample(param_cond=pc, img_cond=cond, noise=noise.cuda()).cpu()
+    sch = OD.schedule(1000)
+    den = lambda x, t, c: OU.unet_forward(sd, x, t, c)
+    cond_h, pc_h = cond.cpu(), pc.cpu()
+    worst_max = worst_mean = 0.0
+    for b in (0, 15):
+        ref = OD.sample(sch, den, pc_h[b:b + 1], cond_h[b:b + 1], S, OD.stored_noise(noise[:, b:b + 1]), sampling_steps=steps)
+        known = OD.cond_mask(cond_h[b:b + 1])
+        assert torch.equal(out[b:b + 1][known], ref[known])
+        dd = (out[b:b + 1] - ref).abs()[~known] * 10.0
+        print(f"mxfp8 DDIM-{steps} @256 slot {b}: in-painted depth vs oracle max {float(dd.max()):.3e} m mean {float(dd.mean()):.3e} m "
+              f"(saturated {float(((ref <= 0) | (ref >= 1))[~known].float().mean()):.4f})")
+        worst_max, worst_mean = max(worst_max, float(dd.max())), max(worst_mean, float(dd.mean()))
+    assert worst_max > 0.0
+    assert MX_CHAIN256_MAX_M is not None, "bounds not recorded yet"
+    assert worst_max <= MX_CHAIN256_MAX_M and worst_mean <= MX_CHAIN256_MEAN_M
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # CLI: generate_dataset.py + generate_gt.py keep the reference's command line and on-disk layout
 # ------------------------------------------------------------------------------------------------------------------
@@ -851,3 +1004,146 @@ def test_cli_generates_dataset_and_gt(tmp_path):
     for line in lines:
         name, s, t, o1, o2 = line.split("\t")
         assert name.startswith("scene-") and (int(s), int(t)) == (0, 1) and 0 <= float(o1) <= 1 and 0 <= float(o2) <= 1
+
+
+def _files_of(root):
+    import os
+    out = {}
+    for d, _s, fs in os.walk(root):
+        for f in fs:
+            out[os.path.relpath(os.path.join(d, f), root)] = open(os.path.join(d, f), "rb").read()
+    return out
+
+
+def test_two_ranks_produce_the_single_rank_files_byte_for_byte(tmp_path):
+    """BASELINE configs[3]'s mechanism on one device: `torchrun --nproc-per-node 2 generate_dataset.py` (both ranks on this
+    GPU, scene range split in contiguous batch-aligned blocks, no collective) followed by generate_gt.py must leave exactly
+    the files of a single-process run of the same range — every PLY / PNG / text file and both gt.log levels, byte for
+    byte (sd:2369-2394, 2690; generate_gt.py:177-188)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--resume", "synthetic:5", "--synthetic", "9", "--image_size", "64", "--sampling_timesteps", "6", "--batch_size", "2",
+            "--dim", "16", "--dtype", "bf16", "--mask_threshold", "0.5", "--dataset_name", "ds", "-start", "10", "-stop", "18"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(root, "generate_dataset.py")] + args, cwd=one, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    port = 29500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "generate_dataset.py")] + args,
+                       cwd=two, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "scenes [10, 14)" in r.stdout and "scenes [14, 18)" in r.stdout          # the two shards
+    for d in (one, two):
+        g = subprocess.run([sys.executable, os.path.join(root, "generate_gt.py"), "--dataset_name", "ds", "-start", "10", "-stop",
+                            "18", "--disable_tqdm"], cwd=d, env=env, capture_output=True, text=True, timeout=600)
+        assert g.returncode == 0, g.stderr[-2000:]
+    f1, f2 = _files_of(one / "ds"), _files_of(two / "ds")
+    assert sorted(f1) == sorted(f2) and len(f1) == 8 * 10 + 1            # 9 files + gt.log per scene, metadata/gt.log
+    diff = [k for k in f1 if f1[k] != f2[k]]
+    assert not diff, diff[:10]
+    assert len(f1["metadata/gt.log"].splitlines()) >= 1
+
+
+def test_real_data_path_end_to_end(tmp_path):
+    """SURVEY 8(f) row 3 through the GPU once: a fake 3DMatch tree (640x480 uint16 depth PNGs, camera-intrinsics.txt,
+    <cloud>.info.txt, train_info.pkl), a diffusion checkpoint with `ema_model.`-prefixed keys next to decoy online weights
+    and a depth-correction checkpoint, then `generate_dataset.py --resume 1` WITHOUT --synthetic (sd:2307-2324, 2352-2361,
+    2397-2500).  Sample 0 must be the oracle's unprojection of the independently decoded frame; the EMA weights (not the
+    online ones) must be the ones sampled from (sd:2572); poses come from the seeded numpy stream of random_sample_pose."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    from PIL import Image
+    from oracle import geometry as OG
+    from pointreggpt_amd import geometry as G, postprocess as PP
+    from pointreggpt_amd.sharding import batch_pose_seed
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    S, dim = 64, 16
+    rng = np.random.default_rng(33)
+    data_root = tmp_path / "3dmatch"
+    Kraw = np.array([[585.0, 0, 320.0], [0, 585.0, 240.0], [0, 0, 1.0]])
+    raws, rels = [], []
+    for i, (scene, seq, f0) in enumerate((("sceneA", "seq-01", 12), ("sceneB", "seq-02", 7))):
+        yy, xx = np.mgrid[0:480, 0:640]
+        raw = (2500 + 2 * (xx - 320) * (0.5 - i) + 1.2 * (yy - 240) + rng.integers(0, 40, size=(480, 640))).astype(np.uint16)   # mm
+        raw[rng.random((480, 640)) < 0.03] = 0
+        raw[200:230, 300:360] = 12000                      # > 10 m: dropped by the (> 1 -> 0) rule
+        (data_root / scene / seq).mkdir(parents=True)
+        Image.fromarray(raw).save(data_root / scene / seq / "frame-{:0>6d}.depth.png".format(f0))
+        np.savetxt(data_root / scene / "camera-intrinsics.txt", Kraw)
+        (tmp_path / "dataset/indoor/data/train" / scene).mkdir(parents=True)
+        (tmp_path / "dataset/indoor/data/train" / scene / f"cloud_bin_{i}.info.txt").write_text(f"{scene} {seq} {f0} {f0 + 50}\n")
+        raws.append(raw)
+        rels.append(f"train/{scene}/cloud_bin_{i}.pth")
+    (tmp_path / "dataset/indoor/metadata").mkdir(parents=True)
+    with open(tmp_path / "dataset/indoor/metadata/train_info.pkl", "wb") as f:
+        pickle.dump({"src": rels, "tgt": rels[::-1], "rot": [np.eye(3)] * 2, "trans": [np.zeros((3, 1))] * 2, "overlap": [0.5, 0.5]}, f)
+    ema_sd = W.synth_state_dict(W.unet_config(dim), 41, calibrated=True)
+    online_sd = W.synth_state_dict(W.unet_config(dim), 42)          # decoy: must NOT be the weights sampled from
+    (tmp_path / "successive_ddnm_diffusion_results").mkdir()
+    ckpt = {"step": 1, "model": {"model." + k: v for k, v in online_sd.items()},
+            "ema": dict({"ema_model.model." + k: v for k, v in ema_sd.items()}, initted=torch.tensor([True]), step=torch.tensor([1]),
+                        **{"ema_model.betas": torch.zeros(1000), "online_model.model.init_conv.bias": online_sd["init_conv.bias"]}),
+            "opt": {}, "scaler": None}
+    ckpt["model"]["betas"] = torch.zeros(1000)
+    torch.save(ckpt, tmp_path / "successive_ddnm_diffusion_results" / "model-1.pt")
+    mask_sd = W.synth_state_dict(W.maskunet_config(dim), 43, final_bias=8.0)
+    (tmp_path / "depth_correction_results").mkdir()
+    torch.save({"epoch": 3, "model": mask_sd, "opt": {}, "metrics": {}}, tmp_path / "depth_correction_results" / "model-best.pt")
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, os.path.join(root, "generate_dataset.py"), "--resume", "1", "--data_root", str(data_root), "--image_size",
+           str(S), "--sampling_timesteps", "4", "--batch_size", "2", "--dim", str(dim), "--dtype", "fp32", "--mask_threshold", "0.5",
+           "--noise_seed", "77", "--dataset_name", "real", "-start", "0", "-stop", "2"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # independent decode of the source frames (torchvision's documented arithmetic: short side -> S, nearest source pixel
+    # floor((i + 0.5) * scale), centre crop at int(round((n - S) / 2)))
+    nw = int(S * 640 / 480)
+    xs = np.floor((np.arange(nw) + 0.5) * 640 / nw).astype(int)
+    ys = np.floor((np.arange(S) + 0.5) * 480 / S).astype(int)
+    left = int(round((nw - S) / 2.0))
+    K = OG.intrinsic_transform(Kraw, S, S).astype(np.float32)
+    np.random.seed(batch_pose_seed(77, 0, 0))
+    poses = OG.random_sample_pose(2).astype(np.float32)
+    depths = []
+    for i in range(2):
+        d = tmp_path / "real" / "data" / "scene-{:0>6d}".format(i)
+        depth = raws[i][ys][:, xs][:, left:left + S].astype(np.float32) * np.float32(1e-4)
+        depth[depth > 1] = 0
+        depths.append(depth)
+        assert np.allclose(np.loadtxt(d / "camera-intrinsics.txt"), K)
+        cloud0 = OG.point_cloud(depth * 10, K, (0.5, 10.0))
+        ref0 = PP.voxel_down_sample(PP.crop_aabb(cloud0.astype(np.float32)), 0.025)
+        got0 = PP.read_ply(str(d / "sample-000000.cloud.ply"))
+        assert got0.shape == ref0.shape and len(got0) > 300 and np.allclose(got0, ref0, atol=1e-12)
+        assert np.allclose(np.loadtxt(d / "sample-000001.pose.txt"), np.linalg.inv(poses[i]), atol=1e-6)
+        gen = PP.read_ply(str(d / "sample-000001.cloud.ply"))
+        assert len(gen) > 100 and np.isfinite(gen).all()
+    # the generated depth equals the oracle's chain on the same inputs with the EMA weights (and not with the decoy ones):
+    # rebuild the condition with the product's geometry, then sample with the same Philox keys through the library directly
+    from pointreggpt_amd import synthetic
+    from pointreggpt_amd.diffusion import GaussianDiffusion
+    from pointreggpt_amd.unet import MaskUnet, Unet
+    mem = [PP.crop_aabb(OG.point_cloud(depths[i] * 10, K, (0.5, 10.0)).astype(np.float32)).astype(np.float32) for i in range(2)]
+    rpj, hit = G.project_clouds(mem, poses, np.stack([K, K]), S, "cuda", depth_scale=0.1)
+    mask = MaskUnet(dim, dtype="fp32").load_state_dict(mask_sd)
+    _, _, cond = G.apply_mask(mask(rpj), rpj, hit, 0.5)
+    seeds = [synthetic.noise_seed(77, i, 0) for i in range(2)]
+    imgs = {}
+    for tag, sdict in (("ema", ema_sd), ("online", online_sd)):
+        net = Unet(dim, dtype="fp32").load_state_dict(sdict)
+        diff = GaussianDiffusion(net, image_size=S, timesteps=1000, sampling_timesteps=4)
+        img = diff.sample(param_cond=G.param_vector(torch.from_numpy(np.stack([K, K])).cuda()), img_cond=cond, seeds=seeds)
+        imgs[tag], _, _ = G.apply_mask(mask(img), img, None, 0.5, want_cond=False)
+        diff.close(); net.close()
+    for i in range(2):
+        d16 = np.asarray(Image.open(tmp_path / "real" / "data" / "scene-{:0>6d}".format(i) / "sample-000001.depth.png")).astype(np.int64)
+        e_ema = np.abs(d16 - np.round(imgs["ema"][i, 0].cpu().numpy().astype(np.float64) * 1e4)).max()
+        e_onl = np.abs(d16 - np.round(imgs["online"][i, 0].cpu().numpy().astype(np.float64) * 1e4)).max()
+        assert e_ema <= 1 and e_onl > 100, (e_ema, e_onl)

@@ -285,3 +285,27 @@ def test_G0_host_tables_are_this_hosts():
         f = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
         assert np.array_equal(f.numpy(), g[f"freqs_dim{dim}"])
         assert np.array_equal(OU.sinusoidal(torch.tensor([999.0]), dim)[0, :half].numpy(), (999.0 * f).sin().numpy())
+
+
+def test_G19_G20_long_chain_prefix_and_clouds(golden):
+    """Round-3 chains of real length (1000-step ancestral at 64x64, 250-step DDIM at 128x128, calibrated denoiser).
+    tools/make_goldens.py asserted the oracle bit-exact over the WHOLE chain when the fixture was made (minutes of CPU);
+    here: the regenerated noise matches its sha256, the oracle reproduces the reference's state after 20 transitions
+    bit-exactly, and the stored cloud is the oracle's unprojection of the stored image."""
+    from conftest import LONG_CHAINS, regenerate_chain_noise
+    sch = OD.schedule(1000)
+    for name, c in LONG_CHAINS.items():
+        g = golden(name)
+        nz = regenerate_chain_noise(g)
+        sd = W.synth_state_dict(W.unet_config(64), int(g["wseed"]), calibrated=True)
+        den = lambda x, t, cc: OU.unet_forward(sd, x, t, cc)
+        x20 = OD.sample(sch, den, T(g["pc"]), T(g["img_cond"]), c["S"], OD.stored_noise(nz), sampling_steps=c["steps"],
+                        stop_after=20)
+        assert np.array_equal(x20.numpy(), g["x20"]), name
+        cloud = OG.inverse_pose_apply(OG.point_cloud(g["sampled"][0, 0] * 10, g["K"][0], (0.5, 10.0)), g["pose"][0])
+        assert np.array_equal(cloud, g["cloud"])
+        # the fixture is a non-degenerate workload: the in-painted pixels do not sit on the clamp
+        assert float(g["saturated_fraction_inpainted"]) < 0.2 and float(g["inpainted_fraction"]) > 0.1
+        # known pixels are returned bit-exactly (DDNM replacement at the last transition)
+        known = OD.cond_mask(T(g["img_cond"])).numpy()
+        assert np.array_equal(g["sampled"][known], ((g["img_cond"][:, 0:1] + 1) * 0.5)[known])

@@ -5,7 +5,8 @@ Run:  python tools/make_goldens.py            (needs /root/reference; takes ~1-2
 Every fixture stores the inputs and the reference's outputs.  Network weights are NOT stored: they come from
 the build's deterministic initialiser (pointreggpt_amd.weights.synth_state_dict(cfg, seed)), loaded into the
 reference modules with load_state_dict, and are regenerated bit-identically by the tests.
-Fixture ids follow SURVEY.md §8c (G1..G12); G12b..G17 were added in round 2 (benchmarked 128x128 configuration,
+Fixture ids follow SURVEY.md §8c (G1..G12); G19/G20 (round 3: chains of real length on the calibrated denoiser,
+~40 minutes of CPU) and G12b..G18 (round 2) were added later; G12b..G17 cover (benchmarked 128x128 configuration,
 the reference's shipped 256x256 resolution, float64 "exact arithmetic" envelopes, DDIM with known pixels > 1).
 """
 import os
@@ -477,6 +478,11 @@ def g0_host_tables():
         out[f"ddim{steps}_rows"] = np.array([[r["c_x0"], r["c_x"], r["c_eps"], r["sigma"], r["sqrt_recip"], r["sqrt_recipm1"]]
                                              for r in rows], dtype=np.float32)
         out[f"ddim{steps}_t"] = np.array([r["t"] for r in rows], dtype=np.int32)
+    # the ancestral chain's per-step noise scale exp(0.5 * logvar) is a float32 exp evaluated on the host too (sd:1280)
+    rows = GaussianDiffusion(_Net(), image_size=32, timesteps=1000).step_table()
+    out["anc1000_rows"] = np.array([[r["c_x0"], r["c_x"], r["c_eps"], r["sigma"], r["sqrt_recip"], r["sqrt_recipm1"]]
+                                    for r in rows], dtype=np.float32)
+    out["anc1000_t"] = np.array([r["t"] for r in rows], dtype=np.int32)
     save("G0_host_tables", **out)
 
 
@@ -519,6 +525,104 @@ def g12b_envelope():
          **{k: np.float64(v) for k, v in rep.items()})
 
 
+# ------------------------------------------------------------------------------------------------
+# Round-3 fixtures: chains of REAL length on the calibrated (non-saturating) synthetic denoiser.
+#   G19  1000-step ancestral DDNM chain (p_sample_loop, sd:1283-1317) at 64x64, B=1, dim 64
+#   G20  250-step DDIM chain (ddim_sample, sd:1319-1392: the setting generate_dataset.py ships) at 128x128, B=1, dim 64
+# Each: a synthetic scene reprojected by the reference (sd:268-286) as the DDNM condition, the reference's result with 8
+# threads and with 1 thread (the reference's own reproducibility: the floor of the parity metric), the float64 twin, the
+# state after 20 transitions (so the CPU suite can check the oracle on a prefix in seconds), and the unprojected clouds.
+# The noise (16 MB per chain) is NOT stored: the reference draws it from torch's global CPU generator, so the fixture keeps
+# the seed and a sha256 of the draws; tests regenerate it with the same torch build and refuse to run on a mismatch.
+# ------------------------------------------------------------------------------------------------
+import hashlib  # noqa: E402
+
+
+def regenerate_noise(seed, n_draws, shape):
+    """The reference's draw order from torch's global CPU generator: randn(shape), then one randn_like per transition."""
+    torch.manual_seed(seed)
+    return torch.stack([torch.randn(shape) for _ in range(n_draws)])
+
+
+def long_chain_fixture(name, S, wseed, scene_seed, noise_seed, steps):
+    B, T = 1, 1000
+    depth, K, pose = synthetic.synth_batch(scene_seed, range(B), S)
+    Kt, Pt = torch.tensor(K), torch.tensor(pose)
+    d_rpj, hit = sd.reproject_tensor(torch.tensor(depth) * 10, Kt, Pt, clip=[0, 10])
+    img_cond = sd.normalize_to_neg_one_to_one(torch.cat([d_rpj * 0.1, hit], dim=1))
+    pc = sd.param_vector(Kt)
+    sdict = weights.synth_state_dict(weights.unet_config(64), wseed, calibrated=True)
+    m = sd.Unet(dim=64, param_cond_dim=4, dim_mults=(1, 2, 4, 8), channels=1)
+    m.load_state_dict(sdict)
+    m.eval()
+    d = ref_diffusion(m, S, T=T, steps=steps)
+    states = {}
+    calls = [0]
+
+    def pre(_m, args):
+        if calls[0] == 20:
+            states["x20"] = args[0].detach().clone()
+        calls[0] += 1
+
+    hnd = m.register_forward_pre_hook(pre)
+    import time
+    t0 = time.time()
+    torch.set_num_threads(8)
+    img8, nz = recorded_noise(lambda: d.sample(param_cond=pc, img_cond=img_cond, disable_tqdm=True), noise_seed)
+    hnd.remove()
+    print(f"  {name}: reference, 8 threads: {time.time() - t0:.0f} s ({len(nz)} draws)")
+    assert torch.equal(nz, regenerate_noise(noise_seed, len(nz), tuple(nz.shape[1:]))), "noise is not regenerable"
+    sha = hashlib.sha256(nz.numpy().tobytes()).hexdigest()
+    t0 = time.time()
+    torch.set_num_threads(1)
+    torch.manual_seed(noise_seed)
+    img1 = d.sample(param_cond=pc, img_cond=img_cond, disable_tqdm=True)
+    torch.set_num_threads(8)
+    print(f"  {name}: reference, 1 thread: {time.time() - t0:.0f} s; |8thr - 1thr|max = {(img8 - img1).abs().max().item():.3e}")
+    # the oracle must reproduce the whole chain bit-exactly (the CPU suite re-checks only the 20-transition prefix)
+    sch = OD.schedule(T)
+    den32 = lambda x, t, c: OU.unet_forward(sdict, x, t, c)
+    t0 = time.time()
+    o32 = OD.sample(sch, den32, pc, img_cond, S, OD.stored_noise(nz), sampling_steps=steps)
+    assert torch.equal(o32, img8), "oracle fp32 chain must reproduce the reference bit-exactly"
+    print(f"  {name}: oracle fp32 == reference over the whole chain ({time.time() - t0:.0f} s)")
+    s64 = f64(sdict)
+    den64 = lambda x, t, c: OU.unet_forward(s64, x.double(), t.double(), c.double())
+    t0 = time.time()
+    o64 = OD.sample(sch, den64, pc, img_cond.double(), S, lambda k: nz[k].double(), sampling_steps=steps)
+    print(f"  {name}: float64 twin {time.time() - t0:.0f} s; |ref - exact|max = {(img8.double() - o64).abs().max().item():.3e}")
+
+    def cloud_of(img):
+        c = sd.point_cloud(img[0, 0].numpy() * 10, K[0], clip=[0.5, 10])
+        return (c - pose[0, :3, 3]) @ pose[0, :3, :3]
+
+    valid8 = (img8[0, 0] * 10 > 0.5) & (img8[0, 0] * 10 < 10)
+    c8, c1, c64 = cloud_of(img8), cloud_of(img1), cloud_of(o64.float())
+    same1 = torch.equal(valid8, (img1[0, 0] * 10 > 0.5) & (img1[0, 0] * 10 < 10))
+    same64 = torch.equal(valid8, (o64.float()[0, 0] * 10 > 0.5) & (o64.float()[0, 0] * 10 < 10))
+    free = ~((img_cond[:, 1:2] + 1) * 0.5 > 0.5)
+    rep = {"xyz_spread_1_vs_8_threads_m": float(np.abs(c8 - c1).max()) if same1 else float("nan"),
+           "xyz_ref_to_exact_m": float(np.abs(c8 - c64).max()) if same64 else float("nan"),
+           "depth_spread_1_vs_8_threads": (img8 - img1).abs().max().item(),
+           "depth_ref_to_exact": (img8.double() - o64).abs().max().item(),
+           "saturated_fraction_inpainted": float(((img8 <= 0) | (img8 >= 1))[free].float().mean()),
+           "inpainted_fraction": float(free.float().mean())}
+    print(f"  {name}:", rep)
+    save(name, depth=depth, K=K, pose=pose, img_cond=img_cond, pc=pc, noise_seed=np.int64(noise_seed),
+         n_draws=np.int64(len(nz)), noise_sha256=np.frombuffer(bytes.fromhex(sha), dtype=np.uint8),
+         noise_probe=nz[[0, 1, len(nz) - 1]].reshape(3, -1)[:, :8], x20=states["x20"], sampled=img8, sampled_1thread=img1,
+         sampled_exact=o64, cloud=c8, wseed=np.int64(wseed), steps=np.int64(steps),
+         **{k: np.float64(v) for k, v in rep.items()})
+
+
+def g19_chain1000_64():
+    long_chain_fixture("G19_chain1000_ancestral_64", 64, 19, 19, 1900, 1000)
+
+
+def g20_ddim250_128():
+    long_chain_fixture("G20_ddim250_128", 128, 20, 20, 2000, 250)
+
+
 def spec_fixture():
     import json
     spec = {"unet64": [[k, list(v.shape)] for k, v in sd.Unet(dim=64, param_cond_dim=4).state_dict().items()],
@@ -535,7 +639,8 @@ if __name__ == "__main__":
     jobs = [("g0", g0_host_tables), ("g1", g1_schedule), ("g2", g2_intrinsics), ("g3", g3_pose), ("g4", g4_pc2depth), ("g5", g5_g6_reproject),
             ("g7", g7_unet_taps), ("g8", g8_unet_full), ("g9", g9_g10_sampler), ("g11", g11_maskunet),
             ("g12", g12_end_to_end), ("g12b", g12b_envelope), ("g13", g13_unet_128), ("g14", g14_chain_128),
-            ("g15", g15_maskunet_128), ("g16", g16_unet_256), ("g17", g17_ddim_cond_gt1), ("g18", g18_refine_and_tester), ("spec", spec_fixture)]
+            ("g15", g15_maskunet_128), ("g16", g16_unet_256), ("g17", g17_ddim_cond_gt1), ("g18", g18_refine_and_tester), ("g19", g19_chain1000_64),
+            ("g20", g20_ddim250_128), ("spec", spec_fixture)]
     for name, fn in jobs:
         if not only or name in only:
             fn()
