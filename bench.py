@@ -203,7 +203,7 @@ def e2e_files(a, unet, mask, diff, rank, world, B, S, lanes=None):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def drift_vs_reference(dtypes, dim):
+def drift_vs_reference(dtypes, dim, rep_batch=64):
     """Distance of the library's precision modes from the REAL reference on chains of real length: the committed fixtures
     G20 (250-step DDIM @128x128) and G19 (1000-step ancestral @64x64), both produced by the reference itself on the
     calibrated synthetic denoiser (tools/make_goldens.py), re-run here through the C-ABI on the fixtures' stored condition
@@ -226,13 +226,15 @@ def drift_vs_reference(dtypes, dim):
         torch.manual_seed(int(g["noise_seed"]))
         nz = torch.stack([torch.randn((1, 1, S, S)) for _ in range(int(g["n_draws"]))])
         torch.random.set_rng_state(st)
+        nz = nz.reshape(-1, 1, 1, S, S)
         if hashlib.sha256(nz.numpy().tobytes()).digest() != bytes(bytearray(g["noise_sha256"].tolist())):
             out[name] = "torch.randn does not reproduce the fixture's noise on this build"
             continue
         known = (g["img_cond"][:, 1:2] + 1) * 0.5 > 0.5
         ref = g["sampled"]
         v_ref = ((ref[0, 0] * 10 > 0.5) & (ref[0, 0] * 10 < 10)).reshape(-1)
-        res = {"chain": f"{steps or 1000}-step {'DDIM' if steps else 'ancestral DDNM'} @{S}x{S}, B=1, dim {dim}, calibrated synthetic weights",
+        res = {"chain": f"{steps or 1000}-step {'DDIM' if steps else 'ancestral DDNM'} @{S}x{S}, dim {dim}, calibrated synthetic weights; "
+                        f"the fixture's scene replicated x{rep_batch} (benchmarked launch shapes), slot 0 compared",
                "reference_spread_1_vs_8_threads_xyz_m": float(g["xyz_spread_1_vs_8_threads_m"]),
                "reference_to_float64_twin_xyz_m": float(g["xyz_ref_to_exact_m"]),
                "inpainted_fraction": float(g["inpainted_fraction"]),
@@ -246,8 +248,14 @@ def drift_vs_reference(dtypes, dim):
                 for j, k in enumerate(("c_x0", "c_x", "c_eps", "sigma", "sqrt_recip", "sqrt_recipm1")):
                     r[k] = float(v[j])
             d.step_table = lambda rows=rows: rows
-            img_d = d.sample(param_cond=torch.from_numpy(g["pc"]).cuda(), img_cond=torch.from_numpy(g["img_cond"]).cuda(),
-                             noise=nz.cuda())
+            # the scene replicated over the benchmarked batch: the launches then have the benchmarked shapes and take the
+            # benchmarked kernels (the 256-pixel / MX kernels only run where a launch fills the chip); slot 0 is compared
+            nzb = nz.cuda().expand(-1, rep_batch, -1, -1, -1).contiguous()
+            img_b = d.sample(param_cond=torch.from_numpy(g["pc"]).cuda().repeat(rep_batch, 1),
+                             img_cond=torch.from_numpy(g["img_cond"]).cuda().repeat(rep_batch, 1, 1, 1), noise=nzb)
+            slot_invariant = bool(torch.equal(img_b[0], img_b[rep_batch - 1]))
+            img_d = img_b[:1].contiguous()
+            del nzb, img_b
             cloud = G.point_clouds(img_d, torch.from_numpy(g["K"]).cuda(), torch.from_numpy(g["pose"]).cuda())[0]
             img = img_d.cpu().numpy()
             dd = np.abs(img.astype(np.float64) - ref)[~known] * 10.0
@@ -255,7 +263,7 @@ def drift_vs_reference(dtypes, dim):
             ch = np.full((v_hip.size, 3), np.nan); ch[v_hip] = cloud
             cr = np.full((v_ref.size, 3), np.nan); cr[v_ref] = g["cloud"]
             both = v_hip & v_ref
-            res[dt] = {"known_pixels_bit_exact": bool(np.array_equal(img[known], ref[known])),
+            res[dt] = {"known_pixels_bit_exact": bool(np.array_equal(img[known], ref[known])), "batch_slot_invariant": slot_invariant,
                        "inpainted_depth_m": {"max": float(dd.max()), "mean": float(dd.mean()), "median": float(np.median(dd))},
                        "xyz_linf_m": float(np.abs(ch[both] - cr[both]).max()),
                        "valid_mask_identical": bool(np.array_equal(v_hip, v_ref)),

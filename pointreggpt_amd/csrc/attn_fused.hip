@@ -17,6 +17,8 @@
 // MFMA: v_mfma_f32_32x32x16_bf16, D[i][j] = sum_k A[i][k] B[k][j]; lane l supplies A[l&31][8(l>>5)..+7] and
 // B[8(l>>5)..+7][l&31] and receives D[(r&3) + 8(r>>2) + 4(l>>5)][l&31] in register r.
 // The LayerNorm gain of PreNorm is folded into the projection weights on the host (unet.hip).
+#include <cstdlib>
+
 #include "blocks.h"
 
 namespace prg {
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
 // =====================================================================================================
 // pass 2: per-slab sums of p = exp(k - max) and of p v^T
 // =====================================================================================================
-template <int C>
-__global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+template <int C, bool O3>   // O3: register budget for three blocks per CU (C = 64: 168 registers, three of them spilled)
+__global__ __launch_bounds__(256, O3 ? 3 : 1) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
                                                            const float* __restrict__ pmax, const float* __restrict__ kshift,
                                                            float* __restrict__ ctxp, float* __restrict__ sump, int N, int nslab) {
   using G = Geo<C>;
@@ -213,14 +215,25 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
     for (int s2 = 0; s2 < nslab; ++s2) m = fmaxf(m, pmax[((size_t)b * nslab + s2) * kHid + 32 * wave + l31]);
   }
   f32x16 ctx = zero16();                               // rows d, column e = l31 of head `wave`
-  float ssum = 0.0f;
+  // Round 3: the shift is the k accumulators' initial value (one splat instead of 64 subtractions per tile and lane), and
+  // sum_n p comes out of the matrix pipe — pT times an all-ones B operand, every column of `psum` = the row sums of the SAME
+  // bf16-rounded p that feeds ctx — instead of 64 float additions per tile and lane.
+  float nm = -m;
+  f32x16 psum = zero16();                              // rows d (any column)
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   XTile<C> xt;
   if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
   for (int t = t0; t < t1; ++t) {
     xt.normalize_to(xn);
     __syncthreads();
     if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
-    f32x16 ka[2] = {zero16(), zero16()}, va[2] = {zero16(), zero16()};
+    asm volatile("" : "+v"(nm));                           // (keeps the 16-register splat from being hoisted out of the loop)
+    f32x16 kinit;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) kinit[e] = nm;
+    f32x16 ka[2] = {kinit, kinit}, va[2] = {zero16(), zero16()};
 #pragma unroll
     for (int kk = 0; kk < G::KK; ++kk) {
 #pragma unroll
@@ -241,16 +254,10 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
         float p[4];
         if (full) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            p[j] = __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j] - m);
-            ssum += p[j];
-          }
+          for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            p[j] = px0 + j < valid ? __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j] - m) : 0.0f;
-            ssum += p[j];
-          }
+          for (int j = 0; j < 4; ++j) p[j] = px0 + j < valid ? __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]) : 0.0f;
         }
         uint2 pw, vw;
         pw.x = pack2(p[0], p[1]);
@@ -262,13 +269,18 @@ __global__ __launch_bounds__(256) void la_ctx_fused_kernel(const bf16_t* __restr
       }
     // ctx[d][e] += sum_px p[px][d] v[px][e]   (same wave wrote the tiles: LDS operations of a wave stay in order)
 #pragma unroll
-    for (int kk = 0; kk < kTP / 16; ++kk)
-      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(pT, kLdP, l31, hi, kk), frag(vT, kLdP, l31, hi, kk), ctx, 0, 0, 0);
+    for (int kk = 0; kk < kTP / 16; ++kk) {
+      const bf16x8 pf = frag(pT, kLdP, l31, hi, kk);
+      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag(vT, kLdP, l31, hi, kk), ctx, 0, 0, 0);
+      psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ones, psum, 0, 0, 0);
+    }
     __syncthreads();
   }
-  ssum += __shfl_xor(ssum, 32, 64);
   const size_t ph = ((size_t)b * 4 + wave) * nslab + slab;
-  if (hi == 0) sump[ph * 32 + l31] = ssum;
+  if (l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sump[ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = psum[r];
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) ctxp[ph * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = ctx[r];
 }
@@ -311,11 +323,11 @@ __global__ __launch_bounds__(256) void la_fin_fused_kernel(const float* __restri
 // =====================================================================================================
 // pass 4: q, softmax over d, ctx^T q, to_out conv + bias, LayerNorm, residual
 // =====================================================================================================
-template <int C>
+template <int C, bool QSTAT>   // QSTAT: static softmax shift of q (qshift != null)
 __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
                                                            const bf16_t* __restrict__ wout, const float* __restrict__ bias,
                                                            const float* __restrict__ out_g, const bf16_t* __restrict__ ctxT,
-                                                           bf16_t* __restrict__ out, int N) {
+                                                           bf16_t* __restrict__ out, int N, const float* __restrict__ qshift) {
   using G = Geo<C>;
   constexpr int RT = C / 32;                 // 32-channel row tiles of y
   constexpr int NA = RT / 2;                 // y accumulators per wave (RT x 2 pixel tiles over 4 waves)
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   bf16x8 wo[NR][kHid / 16];                            // to_out rows of this wave's y row tile(s)
 #pragma unroll
   for (int r = 0; r < NR; ++r) load_wfrags<kHid>(wo[r], wout, yrt[RT > 4 ? 2 * r : 0] * 32, l31, hi);
+  const float nq = QSTAT ? -qshift[wave] : 0.0f;
   XTile<C> xt;
   if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
   for (int t = t0; t < t1; ++t) {
@@ -356,8 +369,18 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
     xt.normalize_to(xn);
     __syncthreads();                                                                            // (1) xn ready
     if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
-    // q^T[d][px] of head `wave`
-    f32x16 qa[2] = {zero16(), zero16()};
+    // q^T[d][px] of head `wave`.  Static shift (round 3): the softmax over d is shift-invariant and |q| <= qs (the bound of
+    // la_ctx's k shift, taken over the head's 32 rows), so -qs is the accumulators' initial value and exp2 cannot overflow
+    // or lose every term (exp2(q - qs) >= 2^-2qs with qs <= 57); no maximum, no subtraction.
+    constexpr bool qstat = QSTAT;
+    f32x16 qinit;
+    {
+      float q0 = QSTAT ? nq : 0.0f;
+      asm volatile("" : "+v"(q0));                         // (no 16-register splat live across the tile loop)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) qinit[e] = q0;
+    }
+    f32x16 qa[2] = {qinit, qinit};
 #pragma unroll
     for (int kk = 0; kk < G::KK; ++kk) {
 #pragma unroll
@@ -366,26 +389,47 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
     }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      // softmax over the 32 d of pixel pt*32 + l31: 16 in this lane, 16 in lane ^ 32
-      float mx = qa[pt][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qa[pt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sm = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        qa[pt][r] = __builtin_amdgcn_exp2f(qa[pt][r] - mx);   // q arrives times log2(e) (weights pre-scaled)
-        sm += qa[pt][r];
-      }
-      sm += __shfl_xor(sm, 32, 64);
-      const float inv = 1.0f / sm;
       f32x16 oa = zero16();
+      if constexpr (qstat) {
+        // e^q unnormalised into the contraction; sum_d e^q of pixel (column) l31 from the same operands against an
+        // all-ones A (every row of `sa` holds it); the 1 / sum scales the 16 OUTPUTS of the lane instead of its 32 inputs
+        f32x16 sa = zero16();
+        bf16x8 ones;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        bf16x8 qb;
+        for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) qb[s2] = (__bf16)(qa[pt][8 * i + s2] * inv);
-        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], qb, oa, 0, 0, 0);      // rows e, column px
+        for (int i = 0; i < 2; ++i) {
+          bf16x8 qb;
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) qb[s2] = (__bf16)__builtin_amdgcn_exp2f(qa[pt][8 * i + s2]);
+          oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], qb, oa, 0, 0, 0);      // rows e, column px
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, qb, sa, 0, 0, 0);
+        }
+        const float inv = __builtin_amdgcn_rcpf(sa[0]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[r] *= inv;
+      } else {
+        // measured maximum (blocks whose static bound is too large): softmax over the 32 d of pixel pt*32 + l31, 16 in this
+        // lane, 16 in lane ^ 32
+        float mx = qa[pt][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qa[pt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sm = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          qa[pt][r] = __builtin_amdgcn_exp2f(qa[pt][r] - mx);   // q arrives times log2(e) (weights pre-scaled)
+          sm += qa[pt][r];
+        }
+        sm += __shfl_xor(sm, 32, 64);
+        const float inv = 1.0f / sm;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf16x8 qb;
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) qb[s2] = (__bf16)(qa[pt][8 * i + s2] * inv);
+          oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], qb, oa, 0, 0, 0);      // rows e, column px
+        }
       }
       const int px = pt * 32 + l31;
 #pragma unroll
@@ -654,7 +698,7 @@ __global__ __launch_bounds__(256) void resblock_tail_fused_kernel(const bf16_t* 
                                                                   const bf16_t* __restrict__ wres, const float* __restrict__ bres,
                                                                   bf16_t* __restrict__ out, int N, const float* __restrict__ head_w,
                                                                   const float* __restrict__ head_b, float* __restrict__ head_out,
-                                                                  int head_sigmoid) {
+                                                                  int head_sigmoid, const GnFold fold) {
   constexpr int LDX = CIN + 8, LDH = COUT + 8;
   constexpr int RT = COUT / 32, NA = RT / 2;          // row tiles of 32 channels; accumulators per wave
   constexpr int XV = CIN / 32, HV = COUT / 32;        // 16-byte vectors per thread of the source / h tile
@@ -677,8 +721,19 @@ __global__ __launch_bounds__(256) void resblock_tail_fused_kernel(const bf16_t* 
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
     const int c0 = yrt * 32 + 8 * g4 + 4 * hi;
-    ca[g4] = *reinterpret_cast<const float4*>(A + (size_t)b * COUT + c0);
-    cb[g4] = *reinterpret_cast<const float4*>(Bc + (size_t)b * COUT + c0);
+    if (fold.acc) {
+      // GroupNorm coefficients of this lane's channel quad (inside one group) from the image's fixed-point statistics
+      float mean, rstd;
+      gn_fold_stats(fold, b, c0 / fold.cpg, mean, rstd);
+      const float4 p4 = *reinterpret_cast<const float4*>(fold.P + (size_t)b * fold.pq_stride + c0);
+      const float4 q4 = *reinterpret_cast<const float4*>(fold.Q + (size_t)b * fold.pq_stride + c0);
+      ca[g4] = make_float4(rstd * p4.x, rstd * p4.y, rstd * p4.z, rstd * p4.w);
+      cb[g4] = make_float4(fmaf(-mean, ca[g4].x, q4.x), fmaf(-mean, ca[g4].y, q4.y), fmaf(-mean, ca[g4].z, q4.z),
+                           fmaf(-mean, ca[g4].w, q4.w));
+    } else {
+      ca[g4] = *reinterpret_cast<const float4*>(A + (size_t)b * COUT + c0);
+      cb[g4] = *reinterpret_cast<const float4*>(Bc + (size_t)b * COUT + c0);
+    }
     cr[g4] = *reinterpret_cast<const float4*>(bres + c0);
   }
   uint4 xv[XV], hv[HV];
@@ -766,8 +821,8 @@ __global__ __launch_bounds__(256) void resblock_tail_fused_kernel(const bf16_t* 
 
 template <int CIN, int COUT>
 int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1, int C1,
-                const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, hipStream_t s, const float* head_w = nullptr,
-                const float* head_b = nullptr, float* head_out = nullptr, int head_sigmoid = 0) {
+                const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, hipStream_t s, const GnFold& fold,
+                const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr, int head_sigmoid = 0) {
   const size_t lds = (size_t)kTP * (CIN + 8 + COUT + 8) * 2;
   static bool attr = false;
   if (!attr) {
@@ -776,7 +831,7 @@ int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* 
     attr = true;
   }
   resblock_tail_fused_kernel<CIN, COUT><<<dim3(tail_slabs(N), B), 256, lds, s>>>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, N, head_w, head_b,
-                                                                                 head_out, head_sigmoid);
+                                                                                 head_out, head_sigmoid, fold);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
@@ -789,8 +844,10 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
   if (!attr) {
     int rc;
     if ((rc = set_lds(&la_kmax_fused_kernel<C>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C>, lds_ctx<C>()))) return rc;
-    if ((rc = set_lds(&la_out_fused_kernel<C>, lds_out<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false>, lds_ctx<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, C == 64>, lds_ctx<C>()))) return rc;
+    if ((rc = set_lds(&la_out_fused_kernel<C, false>, lds_out<C>()))) return rc;
+    if ((rc = set_lds(&la_out_fused_kernel<C, true>, lds_out<C>()))) return rc;
     attr = true;
   }
   const int nslab = la_slabs(N);
@@ -803,11 +860,15 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
     la_kmax_fused_kernel<C><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, N, nslab);
     PRG_LAUNCH_CHECK();
   }
-  la_ctx_fused_kernel<C><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  static const int occ3 = [] { const char* e = std::getenv("PRG_LA_OCC3"); return e ? std::atoi(e) : 0; }();
+  if (occ3 && C == 64) la_ctx_fused_kernel<C, C == 64><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  else la_ctx_fused_kernel<C, false><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
   PRG_LAUNCH_CHECK();
   la_fin_fused_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctxT, N, nslab);
   PRG_LAUNCH_CHECK();
-  la_out_fused_kernel<C><<<grid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N);
+  // (the q shifts of the four heads follow the 128 k shifts)
+  if (kshift) la_out_fused_kernel<C, true><<<grid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N, kshift + kHid);
+  else la_out_fused_kernel<C, false><<<grid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N, nullptr);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
@@ -853,12 +914,19 @@ bool resblock_tail_fused_supported(int C0, int C1, int Cout) {
 int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1,
                                int C1, const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, int Cout,
                                hipStream_t s,
-                               const float* head_w, const float* head_b, float* head_out, int head_sigmoid) {
+                               const float* head_w, const float* head_b, float* head_out, int head_sigmoid, const GnFold* fold) {
   PRG_CHECK(resblock_tail_fused_supported(C0, C1, Cout) && bres, "fused resblock tail: unsupported shape");
   PRG_CHECK(!head_out || (Cout == 64 && head_w && head_b), "fused resblock tail: the head needs Cout = 64");
-  if (Cout == 64) return launch_tail<128, 64>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s, head_w, head_b, head_out, head_sigmoid);
-  if (C0 + C1 == 192) return launch_tail<192, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);   // up level 2
-  return launch_tail<256, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s);
+  GnFold f{};
+  if (fold && fold->acc) {
+    f = *fold;
+    PRG_CHECK(f.cpg % 4 == 0 && f.G * f.cpg == Cout && f.P && f.Q, "fused resblock tail: bad GroupNorm fold");
+  } else {
+    PRG_CHECK(A && Bc, "fused resblock tail: no coefficients");
+  }
+  if (Cout == 64) return launch_tail<128, 64>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s, f, head_w, head_b, head_out, head_sigmoid);
+  if (C0 + C1 == 192) return launch_tail<192, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s, f);   // up level 2
+  return launch_tail<256, 128>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, B, N, s, f);
 }
 
 bool linattn_fused_supported(int C) { return C == 64 || C == 128 || C == 256; }

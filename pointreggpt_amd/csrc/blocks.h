@@ -20,6 +20,18 @@ int launch_gn_stats(const T* x, float* partials, int B, int HW, int C, int G, in
 int launch_gn_coeff(const float* partials, int nsplit, const GnApply& p, float* A, float* Bc, int B, int HW, int C,
                     int G, hipStream_t s);
 
+// The same coefficients from the fixed-point accumulators of the bf16 path (common.h, GnFold) into [B][C] tables: only
+// for consumers that cannot fold in-kernel (the wave-specialised conv's prologue, the 1x1 res_conv epilogue).
+int launch_gn_coeff_acc(const GnFold& f, float* A, float* Bc, int B, int C, hipStream_t s);
+// P = gamma * (scale + 1), Q = beta * (scale + 1) + shift for every conditioned GroupNorm of a forward, ONE launch:
+// entries [n] of (ss_off, C, gamma offset, beta offset into `flat`); pq [B][ss_total]: P at ss_off, Q at ss_off + C.
+struct CondFoldEntry { int ss_off, C; long long gamma_off, beta_off; };
+int launch_cond_fold(const CondFoldEntry* entries, int n, const float* flat, const GnApply& ss, float* pq, int64_t pq_stride,
+                     int B, hipStream_t s);
+// y = silu(x * A + B) + residual with the coefficients folded per block from the accumulators (one image per block row)
+int launch_affine_silu_fold(const bf16_t* x, const GnFold& f, const bf16_t* residual, bf16_t* out, int B, int HW, int C,
+                            hipStream_t s);
+
 // y = silu(x * A[b][c] + Bc[b][c]) + residual over NHWC x (B, HW, C): the apply half of GroupNorm once gn_coeff ran.
 template <typename T>
 int launch_affine_silu(const T* x, const float* A, const float* Bc, const T* residual, T* out, int B, int HW, int C,
@@ -43,7 +55,8 @@ int launch_linear_attention(const T* qkv, T* out, float* ws, int B, int N, hipSt
 // the PreNorm gain folded in, wout [C][128] bf16.  ws: at least linattn_fused_ws_floats(B, N) floats.
 bool linattn_fused_supported(int C);
 size_t linattn_fused_ws_floats(int B, int N);
-// kshift: [128] static per-column softmax shift (a bound on |k|; see unet.hip) or null = measure the column maxima.
+// kshift: [128 + 4] static softmax shifts — a bound on |k| per column, then a bound on |q| per head (see unet.hip) — or
+// null = measure the maxima.
 int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias,
                                   const float* out_g, bf16_t* out, float* ws, int B, int N, int C, const float* kshift,
                                   hipStream_t s);
@@ -52,11 +65,12 @@ int launch_linear_attention_fused(const bf16_t* x, const bf16_t* wqkv, const bf1
 bool resblock_tail_fused_supported(int C0, int C1, int Cout);
 // head_out != null (Cout = 64 only): the Unet's final 1x1 conv to one channel (+ optional sigmoid) is applied to the tile
 // in LDS and ONLY its float32 result (B, N) is written — the 64-channel tensor never reaches HBM.
+// fold != null (acc set): the GroupNorm coefficients are computed per block from the accumulators instead of read from A / Bc.
 int launch_resblock_tail_fused(const bf16_t* h, const float* A, const float* Bc, const bf16_t* s0, int C0, const bf16_t* s1,
                                int C1, const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, int Cout,
                                hipStream_t s,
                                const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr,
-                               int head_sigmoid = 0);
+                               int head_sigmoid = 0, const GnFold* fold = nullptr);
 
 // Attention core on MFMA (bf16 path, N in {64, 128, 256} tokens) (attn_fused.hip)
 bool full_attention_mfma_supported(int N);

@@ -340,6 +340,115 @@ int launch_gn_coeff(const float* partials, int nsplit, const GnApply& p, float* 
   return PRG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fixed-point GroupNorm statistics (common.h, GnFold): the three small kernels around the in-kernel folds
+// ---------------------------------------------------------------------------------------------
+// grid (B): coefficient tables from the accumulators, for the consumers that cannot fold in-kernel
+__global__ __launch_bounds__(256) void gn_coeff_acc_kernel(GnFold f, float* __restrict__ A, float* __restrict__ Bc, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, rstd;
+    gn_fold_stats(f, b, c / f.cpg, mean, rstd);
+    const float a = rstd * f.P[(size_t)b * f.pq_stride + c];
+    A[(size_t)b * C + c] = a;
+    Bc[(size_t)b * C + c] = fmaf(-mean, a, f.Q[(size_t)b * f.pq_stride + c]);
+  }
+}
+
+int launch_gn_coeff_acc(const GnFold& f, float* A, float* Bc, int B, int C, hipStream_t s) {
+  PRG_CHECK(f.acc && f.P && f.Q && A && Bc && f.G * f.cpg == C, "gn_coeff_acc: bad arguments");
+  gn_coeff_acc_kernel<<<B, 256, 0, s>>>(f, A, Bc, C);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+// grid (entries, B): P = gamma (scale + 1), Q = beta (scale + 1) + shift of every conditioned GroupNorm of one forward
+__global__ __launch_bounds__(256) void cond_fold_kernel(const CondFoldEntry* __restrict__ entries, const float* __restrict__ flat,
+                                                        GnApply ss, float* __restrict__ pq, int64_t pq_stride) {
+  const CondFoldEntry e = entries[blockIdx.x];
+  const int b = blockIdx.y;
+  const float* ssa = ss.ss_a + (size_t)b * ss.ss_a_stride + e.ss_off;
+  if (ss.ss_a_row) ssa += (size_t)(*ss.ss_a_row) * ss.ss_a_row_stride;
+  const float* ssb = ss.ss_b ? ss.ss_b + (size_t)b * ss.ss_b_stride + e.ss_off : nullptr;
+  const float* gamma = flat + e.gamma_off;
+  const float* beta = flat + e.beta_off;
+  float* o = pq + (size_t)b * pq_stride + e.ss_off;
+  for (int c = threadIdx.x; c < e.C; c += 256) {
+    float s0 = ssa[c], s1 = ssa[e.C + c];
+    if (ssb) { s0 += ssb[c]; s1 += ssb[e.C + c]; }
+    o[c] = gamma[c] * (s0 + 1.0f);
+    o[e.C + c] = fmaf(beta[c], s0 + 1.0f, s1);
+  }
+}
+
+int launch_cond_fold(const CondFoldEntry* entries, int n, const float* flat, const GnApply& ss, float* pq, int64_t pq_stride,
+                     int B, hipStream_t s) {
+  PRG_CHECK(entries && n > 0 && flat && ss.ss_a && pq, "cond_fold: bad arguments");
+  cond_fold_kernel<<<dim3(n, B), 256, 0, s>>>(entries, flat, ss, pq, pq_stride);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+// grid (blocks per image, B): y = silu(x * A + B) + residual; every block folds its image's coefficients into LDS first
+// (C <= 1024: two int64 loads and two parameter loads per channel), then streams a contiguous run of the image's vectors
+__global__ __launch_bounds__(256) void affine_silu_fold_kernel(const bf16_t* __restrict__ x, GnFold f,
+                                                               const bf16_t* __restrict__ residual, bf16_t* __restrict__ out,
+                                                               int64_t nvec_per_img, int nvc, int C) {
+  __shared__ float sA[1024], sB[1024];
+  const int b = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, rstd;
+    gn_fold_stats(f, b, c / f.cpg, mean, rstd);
+    const float a = rstd * f.P[(size_t)b * f.pq_stride + c];
+    sA[c] = a;
+    sB[c] = fmaf(-mean, a, f.Q[(size_t)b * f.pq_stride + c]);
+  }
+  __syncthreads();
+  const int64_t per_blk = (nvec_per_img + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per_blk, hi = min(lo + per_blk, nvec_per_img);
+  const int64_t base = (int64_t)b * nvec_per_img;
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += 1024) {
+    Vec16<bf16_t> v[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * 256;
+      if (i < hi) {
+        v[k] = vec_load(x + (base + i) * 8);
+        if (residual) r[k] = vec_load(residual + (base + i) * 8);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * 256;
+      if (i < hi) {
+        const int vc = (int)(i % nvc);
+        Vec16<bf16_t> w;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float y = Elem<bf16_t>::silu(fmaf(Elem<bf16_t>::load(v[k].e[u]), sA[vc * 8 + u], sB[vc * 8 + u]));
+          if (residual) y += Elem<bf16_t>::load(r[k].e[u]);
+          w.e[u] = Elem<bf16_t>::store(y);
+        }
+        vec_store(out + (base + i) * 8, w);
+      }
+    }
+  }
+}
+
+int launch_affine_silu_fold(const bf16_t* x, const GnFold& f, const bf16_t* residual, bf16_t* out, int B, int HW, int C,
+                            hipStream_t s) {
+  PRG_CHECK(f.acc && f.P && f.Q && C % 8 == 0 && C <= 1024 && f.G * f.cpg == C, "affine_silu_fold: bad arguments");
+  const int nvc = C / 8;
+  const int64_t per_img = (int64_t)HW * nvc;
+  // ~4096 vectors (64 KB in, 64 KB out) per block, at least one block per image, at most 16384 blocks in all
+  int64_t bpi = (per_img + 4095) / 4096;
+  if (bpi * B > 16384) bpi = 16384 / B > 0 ? 16384 / B : 1;
+  if (bpi < 1) bpi = 1;
+  affine_silu_fold_kernel<<<dim3((int)bpi, B), 256, 0, s>>>(x, f, residual, out, per_img, nvc, C);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
 // =============================================================================================
 // channel LayerNorm (per pixel over C, biased variance, eps 1e-5, gain only) + optional residual
 // =============================================================================================

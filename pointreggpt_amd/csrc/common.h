@@ -154,6 +154,47 @@ struct GnApply {
 };
 
 // ---------------------------------------------------------------------------------------------
+// GroupNorm statistics as fixed-point accumulators (bf16 throughput path, round 3)
+// ---------------------------------------------------------------------------------------------
+// Instead of per-tile (sum, sumsq) slabs + one gn_coeff_kernel launch per GroupNorm (38 launches per U-Net evaluation),
+// the producing conv adds every wave's partial sums into ONE pair of 64-bit integers per (image, group) with no-return
+// agent-scope atomics — integer addition is associative, so the result does not depend on the order in which tiles
+// finish: deterministic and batch-slot invariant like the fixed-order slab reduction it replaces — and every CONSUMER
+// turns the pair into the affine coefficients itself: y = x * A + B with A = rstd * P[c], B = Q[c] - mean * A, where
+// P = gamma * (scale + 1), Q = beta * (scale + 1) + shift were folded once per evaluation (cond_fold_kernel) or at weight
+// load (unconditioned norms: P = gamma, Q = beta).  Scales: sum * 2^24, sumsq * 2^20 (|sum| < 5.5e11, sumsq < 8.8e12: an
+// image group of 524288 elements with rms < 4096; resolution 6e-8 / 1e-6 per partial).
+constexpr float kGnSumScale = 16777216.0f, kGnSqScale = 1048576.0f;
+
+struct GnFold {
+  const long long* acc;   // [B][G][2] (sum * 2^24, sumsq * 2^20); null = this launch uses coefficient tables instead
+  const float* P;         // [C] (+ b * pq_stride), 16-byte aligned
+  const float* Q;
+  int64_t pq_stride;      // floats between images (0: shared by the batch)
+  float inv_n;            // 1 / (pixels per image * channels per group)
+  int G, cpg;             // groups, channels per group (C = G * cpg)
+};
+
+#if defined(__HIPCC__)
+// one wave total (float) -> the image group's accumulator; `which` 0 = sum, 1 = sumsq
+__device__ inline void gn_acc_add(long long* acc, int G, int b, int g, int which, float v) {
+  const long long q = __float2ll_rn(v * (which ? kGnSqScale : kGnSumScale));
+  __hip_atomic_fetch_add(acc + ((size_t)b * G + g) * 2 + which, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void gn_fold_stats_raw(long long s_fx, long long q_fx, float inv_n, float& mean, float& rstd) {
+  const double m = (double)s_fx * (1.0 / 16777216.0) * (double)inv_n;
+  double var = (double)q_fx * (1.0 / 1048576.0) * (double)inv_n - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  mean = (float)m;
+  rstd = __builtin_amdgcn_rsqf((float)var + 1e-5f);
+}
+__device__ inline void gn_fold_stats(const GnFold& f, int b, int g, float& mean, float& rstd) {
+  const long long* a = f.acc + ((size_t)b * f.G + g) * 2;
+  gn_fold_stats_raw(a[0], a[1], f.inv_n, mean, rstd);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // activations
 // ---------------------------------------------------------------------------------------------
 __device__ inline float silu_f(float x) { return x / (1.0f + expf(-x)); }

@@ -59,6 +59,12 @@ struct ConvLaunch {
   float* gn_coef_a;
   float* gn_coef_b;
   int* gn_tickets;
+  // Fixed-point statistics (common.h, GnFold): producers that support it add their wave totals into gn_acc [B][gn_groups][2]
+  // (zeroed by the caller) INSTEAD of writing gn_partials slabs and report so through launch_conv's acc_done; consumers
+  // with pro_fold.acc != null compute the prologue coefficients themselves (pro_a / pro_b then point to [B][C0] scratch
+  // tables that kernels without the in-kernel fold fill with one gn_coeff_acc launch first).
+  long long* gn_acc;
+  GnFold pro_fold;
   // MX-fp8 operands (handles of dtype PRG_MXFP8, 3x3 / s1 / p1 convs with 64-channel multiples): OCP e4m3 weights
   // [tap][64-channel chunk][CoutPad][64] with one E8M0 scale per 32 input channels [tap][chunk][CoutPad][2]; null = bf16.
   const uint8_t* w_mx;
@@ -87,7 +93,7 @@ float e4m3_to_f32(uint8_t b);
 // when statistics were requested but this shape cannot fuse them.  `allow_prologue` must be checked by the
 // caller with conv_supports_prologue() before setting pro_a / pro_b.
 template <typename T>
-int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done = nullptr);
+int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done = nullptr, int* acc_done = nullptr);
 
 // true when the 3x3 halo kernel will run this conv (so a fused input prologue is available)
 template <typename T>

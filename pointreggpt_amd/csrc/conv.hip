@@ -23,6 +23,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "blocks.h"
 #include "conv.h"
 
 namespace prg {
@@ -851,11 +852,22 @@ static int launch_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats,
   return PRG_OK;
 }
 // MX-fp8 operands: 1 = launched, 0 = shape not covered (bf16 kernels run instead)
-int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_w256.hip
-static int try_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done);   // conv_w256.hip
+// Consumers without the in-kernel GroupNorm fold (common.h, GnFold): fill the pro_a / pro_b tables from the accumulators
+// with one small launch, then run on the tables as before.
+int materialize_prologue(ConvLaunch<bf16_t>& L, hipStream_t s) {
+  if (!L.pro_fold.acc) return PRG_OK;
+  PRG_CHECK(L.pro_a && L.pro_b, "conv: pro_fold needs scratch coefficient tables in pro_a / pro_b");
+  const int rc = launch_gn_coeff_acc(L.pro_fold, const_cast<float*>(L.pro_a), const_cast<float*>(L.pro_b), L.d.B, L.d.C0, s);
+  L.pro_fold.acc = nullptr;
+  return rc;
+}
+static int materialize_prologue(ConvLaunch<float>&, hipStream_t) { return PRG_OK; }
+
+static int try_mx(ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done) {
   if (!L.w_mx || !L.w_mx_scale) return 0;
   {
-    const int r = try_launch_conv3x3_w256mx(L, s, gn_nsplit_out);   // 256-pixel x 128-channel tiles with MX operands
+    const int r = try_launch_conv3x3_w256mx(L, s, gn_nsplit_out, acc_done);   // 256-pixel x 128-channel tiles with MX operands
     if (r != 0) return r;
   }
   // Shapes the 256-pixel MX kernel does not cover (the 64-channel convs, launches with few tiles): by default the bf16
@@ -870,6 +882,7 @@ static int try_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out
   const int tiles = (d.Wout / hp.TW) * (d.Hout / hp.TH);
   const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= hp.BN && tiles <= kGnMaxSplit;
   int rc;
+  if ((rc = materialize_prologue(L, s))) return rc;
   if (hp.TH == 8 && hp.TW == 32 && hp.BN == 64) rc = launch_mx<8, 32, 64>(L, s, fuse, gn_nsplit_out);
   else if (hp.TH == 4 && hp.TW == 32 && hp.BN == 128) rc = launch_mx<4, 32, 128>(L, s, fuse, gn_nsplit_out);
   else if (hp.TH == 8 && hp.TW == 16 && hp.BN == 128) rc = launch_mx<8, 16, 128>(L, s, fuse, gn_nsplit_out);
@@ -877,24 +890,32 @@ static int try_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out
   else return 0;
   return rc == PRG_OK ? 1 : rc;
 }
-static int try_mx(const ConvLaunch<float>&, hipStream_t, int*) { return 0; }
+static int try_mx(ConvLaunch<float>&, hipStream_t, int*, int*) { return 0; }
 
-int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_ws.hip
-int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done);  // conv_c64.hip
-int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out);   // conv_w256.hip
+int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done);   // conv_ws.hip
+int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done);  // conv_c64.hip
+int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done);   // conv_w256.hip
 int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s);                       // conv_w256.hip
 static inline int try_down(const ConvLaunch<bf16_t>& L, hipStream_t s) { return try_launch_conv4x4s2_w256(L, s); }
 static inline int try_down(const ConvLaunch<float>&, hipStream_t) { return 0; }
-static inline int try_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done) {
-  int r = try_launch_conv3x3_c64(L, s, n, coef_done);        // weights-stationary kernel for the 64 -> 64 convs
-  if (r == 0) r = try_launch_conv3x3_w256(L, s, n);          // 256-pixel x 128-channel tiles where the launch fills the chip
-  return r != 0 ? r : try_launch_conv3x3_ws(L, s, n);
+static inline int try_ws(ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done, int* acc_done) {
+  int r = try_launch_conv3x3_c64(L, s, n, coef_done, acc_done);   // weights-stationary kernel for the 64 -> 64 convs
+  if (r == 0) r = try_launch_conv3x3_w256(L, s, n, acc_done);     // 256-pixel x 128-channel tiles where the launch fills the chip
+  if (r != 0) return r;
+  // the wave-specialised kernel reads coefficient tables (hand-counted loads): fold the accumulators into them first when
+  // it is going to run (its shape test is repeated here so that a conv it does not cover launches nothing)
+  const ConvDesc& d = L.d;
+  if (L.pro_fold.acc && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Cout % 64 == 0)
+    if (int rc = materialize_prologue(L, s)) return rc;
+  return try_launch_conv3x3_ws(L, s, n, acc_done);
 }
-static inline int try_ws(const ConvLaunch<float>&, hipStream_t, int*, int*) { return 0; }
+static inline int try_ws(ConvLaunch<float>&, hipStream_t, int*, int*, int*) { return 0; }
 
 template <typename T>
-int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done) {
+int launch_conv(const ConvLaunch<T>& Lin, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
   if (coef_done) *coef_done = 0;
+  if (acc_done) *acc_done = 0;
+  ConvLaunch<T> L = Lin;          // (materialize_prologue clears pro_fold once the coefficient tables are filled)
   const ConvDesc& d = L.d;
   constexpr int VEC = Elem<T>::kVec;
   PRG_CHECK(L.src0 && L.w && L.out, "conv: null pointer");
@@ -909,16 +930,17 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* 
   const int want_stats = L.gn_partials != nullptr;
   if (gn_nsplit_out) *gn_nsplit_out = 0;
   {
-    const int r = try_mx(L, s, gn_nsplit_out);              // MX-fp8 operands when the handle carries them
+    const int r = try_mx(L, s, gn_nsplit_out, acc_done);    // MX-fp8 operands when the handle carries them
     if (r < 0) return r;
     if (r == 1) return PRG_OK;
   }
   {
-    int r = try_ws(L, s, gn_nsplit_out, coef_done);         // persistent kernels of the bf16 throughput path
+    int r = try_ws(L, s, gn_nsplit_out, coef_done, acc_done);   // persistent kernels of the bf16 throughput path
     if (r == 0 && !L.gn_partials) r = try_down(L, s);       // Downsample (4 x 4, stride 2) as a 2 x 2-tap conv of the same kernel
     if (r < 0) return r;
     if (r == 1) return PRG_OK;
   }
+  if (int rc = materialize_prologue(L, s)) return rc;       // the generic kernels below read coefficient tables
   HaloPick<T> hp;
   if (pick_halo<T>(d, &hp)) {
     const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
@@ -947,8 +969,8 @@ void s2d_equivalent_weights(const float* w, int Cout, int Cin, std::vector<float
         }
 }
 
-template int launch_conv<float>(const ConvLaunch<float>&, hipStream_t, int*, int*);
-template int launch_conv<bf16_t>(const ConvLaunch<bf16_t>&, hipStream_t, int*, int*);
+template int launch_conv<float>(const ConvLaunch<float>&, hipStream_t, int*, int*, int*);
+template int launch_conv<bf16_t>(const ConvLaunch<bf16_t>&, hipStream_t, int*, int*, int*);
 
 // ---------------------------------------------------------------------------------------------
 // weight packing (host)

@@ -145,7 +145,7 @@ __device__ inline void c64_fold_coefficients(const ConvLaunch<bf16_t>& L, int im
   L.gn_coef_b[(size_t)img * 64 + c] = bb;
 }
 
-template <bool PRO>
+template <int PRO>   // 0: no prologue; 1: GroupNorm coefficient tables (pro_a / pro_b); 2: coefficients folded here from pro_fold
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
                                                           const int flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -309,9 +309,14 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           const int nsplit = tiles_x * tiles_y * 2 * split_n;
           const int slab = (((ty0 / TH) * tiles_x + tx0 / TW) * 2 + wm) * split_n + (split_n == 2 ? wn : 0);
           const int grp = (wn * 4 + q) / gn_per;
-          // agent-scope (write-through, sc1) store: the workgroup that completes the image reads these from another CU
-          __hip_atomic_store(&L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 2)], D,
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (L.gn_acc) {
+            // fixed-point accumulators (common.h): one no-return 64-bit integer atomic per wave total
+            gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, i >> 2, D);
+          } else {
+            // agent-scope (write-through, sc1) store: the workgroup that completes the image reads these from another CU
+            __hip_atomic_store(&L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 2)], D,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
     }
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     int done_in_img = 0;                                   // tiles of the current image this workgroup has finished
     unsigned okmask = 0, okmask_nxt = 0;
     float4 ca[2], cb[2], ca_n[2], cb_n[2];
+    longlong2 fs_n = make_longlong2(0, 0);                  // PRO == 2: (sum, sumsq) of the 8-channel unit's group, fixed point
     auto issue = [&](int s, c64_u32x4(&h)[KU]) {           // loads of halo s (clamped to the last tile: harmless reloads)
       int b, y0, x0;
       c64_tile(first + min(s, nsteps - 1) * stride, tiles_x, tiles_y, b, y0, x0);
@@ -360,13 +366,25 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         h[k] = *reinterpret_cast<const c64_u32x4*>(src + ((size_t)y * d.Win + x) * 64);
         okmask_nxt |= (ok ? 1u : 0u) << k;
       }
-      if constexpr (PRO) {
+      if constexpr (PRO == 1) {
         const float* pa = L.pro_a + (size_t)b * 64 + slot * 8;
         const float* pb = L.pro_b + (size_t)b * 64 + slot * 8;
         ca_n[0] = *reinterpret_cast<const float4*>(pa);
         ca_n[1] = *reinterpret_cast<const float4*>(pa + 4);
         cb_n[0] = *reinterpret_cast<const float4*>(pb);
         cb_n[1] = *reinterpret_cast<const float4*>(pb + 4);
+      }
+      if constexpr (PRO == 2) {
+        // the raw material of the coefficients: this unit's group statistics and its folded gain / bias (P, Q); the
+        // arithmetic happens in adopt(), a step later, when the loads have long landed
+        const GnFold& f = L.pro_fold;
+        fs_n = *reinterpret_cast<const longlong2*>(f.acc + ((size_t)b * f.G + (slot * 8) / f.cpg) * 2);
+        const float* pp = f.P + (size_t)b * f.pq_stride + slot * 8;
+        const float* pq = f.Q + (size_t)b * f.pq_stride + slot * 8;
+        ca_n[0] = *reinterpret_cast<const float4*>(pp);
+        ca_n[1] = *reinterpret_cast<const float4*>(pp + 4);
+        cb_n[0] = *reinterpret_cast<const float4*>(pq);
+        cb_n[1] = *reinterpret_cast<const float4*>(pq + 4);
       }
     };
     auto write = [&](int s, c64_u32x4(&h)[KU]) {           // halo s -> LDS buffer s & 1
@@ -390,8 +408,18 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     };
     auto adopt = [&]() {                                   // the validity mask and coefficients of the halo about to be written
       okmask = okmask_nxt;
-      if constexpr (PRO) {
+      if constexpr (PRO == 1) {
         ca[0] = ca_n[0]; ca[1] = ca_n[1]; cb[0] = cb_n[0]; cb[1] = cb_n[1];
+      }
+      if constexpr (PRO == 2) {                            // A = rstd P, B = Q - mean A
+        float mean, rstd;
+        gn_fold_stats_raw(fs_n.x, fs_n.y, L.pro_fold.inv_n, mean, rstd);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          ca[h2] = make_float4(rstd * ca_n[h2].x, rstd * ca_n[h2].y, rstd * ca_n[h2].z, rstd * ca_n[h2].w);
+          cb[h2] = make_float4(fmaf(-mean, ca[h2].x, cb_n[h2].x), fmaf(-mean, ca[h2].y, cb_n[h2].y),
+                               fmaf(-mean, ca[h2].z, cb_n[h2].z), fmaf(-mean, ca[h2].w, cb_n[h2].w));
+        }
       }
     };
     issue(0, hA);
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
 }  // namespace
 
 // Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
-int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done) {
+int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
   static const int enabled = [] {
     const char* e = std::getenv("PRG_CONV_C64");
     return e ? std::atoi(e) : 1;
@@ -471,29 +499,36 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
              tiles_x * tiles_y * 2 * split_n <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
-  static bool attr_done[2] = {false, false};
-  const int pro = L.pro_a ? 1 : 0;
+  static bool attr_done[3] = {false, false, false};
+  const GnFold& pf = L.pro_fold;
+  const bool fold_ok = pf.acc && pf.P && pf.Q && pf.G * pf.cpg == 64 && pf.cpg % 8 == 0;
+  if (pf.acc && !fold_ok) return 0;
+  const int pro = fold_ok ? 2 : (L.pro_a ? 1 : 0);
   if (!attr_done[pro]) {
-    hipError_t e = pro ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS)
-                       : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS);
+    const void* fn = pro == 2 ? reinterpret_cast<const void*>(&conv3x3_c64_kernel<2>)
+                   : pro == 1 ? reinterpret_cast<const void*>(&conv3x3_c64_kernel<1>)
+                              : reinterpret_cast<const void*>(&conv3x3_c64_kernel<0>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(c64 conv): ") + hipGetErrorString(e));
     attr_done[pro] = true;
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 * split_n : 0;
   // the image-completing workgroup folds the statistics into the coefficients itself (no gn_coeff launch)
-  const bool fold = fuse && L.gn_tickets && L.gn_coef_a && L.gn_coef_b && L.gn.gamma && L.gn.beta && d.B <= kMaxTicketImages;
+  const bool use_acc = fuse && L.gn_acc != nullptr;          // fixed-point accumulators instead of slabs (+ no in-kernel ticket fold)
+  const bool fold = fuse && !use_acc && L.gn_tickets && L.gn_coef_a && L.gn_coef_b && L.gn.gamma && L.gn.beta && d.B <= kMaxTicketImages;
   ConvLaunch<bf16_t> Lk = L;
   if (!fold) Lk.gn_tickets = nullptr;
+  if (!use_acc) Lk.gn_acc = nullptr;
   if (coef_done) *coef_done = fold ? 1 : 0;
+  if (acc_done) *acc_done = use_acc ? 1 : 0;
   // interleaved tile runs are ~2 % faster (neighbouring tiles run at the same time on neighbouring CUs of the XCD); the
   // coefficient fold wants contiguous runs (one ticket per workgroup and image).  PRG_C64_INTERLEAVE=0/1 overrides.
   static const int interleave_env = [] { const char* e = std::getenv("PRG_C64_INTERLEAVE"); return e ? std::atoi(e) : -1; }();
   const int interleave = interleave_env >= 0 ? interleave_env : (fold ? 0 : 1);
   const int flags = (fuse ? 1 : 0) | (interleave ? 2 : 0);
-  if (pro) conv3x3_c64_kernel<true><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
-  else conv3x3_c64_kernel<false><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  if (pro == 2) conv3x3_c64_kernel<2><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  else if (pro == 1) conv3x3_c64_kernel<1><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  else conv3x3_c64_kernel<0><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
   PRG_LAUNCH_CHECK();
   return 1;
 }

@@ -124,7 +124,7 @@ __device__ constexpr int w2_toff(int p) { return MODE ? (1 + p / 2) * HP + 1 + p
 template <int MODE>
 __device__ constexpr int w2_tapid(int p) { return MODE ? (1 + p / 2) * 3 + 1 + p % 2 : p; }
 
-template <int TW, bool PRO, int MODE>
+template <int TW, int PRO, int MODE>   // PRO 0: no prologue, 1: coefficient tables, 2: coefficients folded in-kernel (pro_fold)
 __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
                                                            const int tiles_n, const int fuse_stats) {
   using G = W2Geom<TW>;
@@ -300,7 +300,8 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
                 const int nsplit = tiles_x * tiles_y * 2;
                 const int slab = ((ty0 / TH) * tiles_x + tx0 / TW) * 2 + wm;
                 const int grp = (((tm.tn * BN + wn * 64) >> 3) + cc) >> gn_per_sh;
-                L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
+                if (L.gn_acc) gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, i >> 3, D);   // fixed-point accumulators (common.h)
+                else L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
               }
             }
           }
@@ -383,6 +384,25 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     unsigned ld_cs2 = 0, ld_tedge = 0;
     const float* ld_ca = nullptr;
     const float* ld_cb = nullptr;
+    // pro_fold (common.h, GnFold): ld_ca / ld_cb point at P / Q and the coefficients are folded here from the image group's
+    // fixed-point statistics (ld_acc) when a halo's coefficients are adopted: A = rstd P, B = Q - mean A
+    constexpr bool pfold = PRO == 2;
+    const long long* ld_acc = nullptr;
+    longlong2 nacc = make_longlong2(0, 0);
+    auto fold_inplace = [&](float4* c) {
+      if constexpr (PRO) {
+        if (pfold) {
+          float mean, rstd;
+          gn_fold_stats_raw(nacc.x, nacc.y, L.pro_fold.inv_n, mean, rstd);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            c[h2] = make_float4(rstd * c[h2].x, rstd * c[h2].y, rstd * c[h2].z, rstd * c[h2].w);
+            c[2 + h2] = make_float4(fmaf(-mean, c[h2].x, c[2 + h2].x), fmaf(-mean, c[h2].y, c[2 + h2].y),
+                                    fmaf(-mean, c[h2].z, c[2 + h2].z), fmaf(-mean, c[h2].w, c[2 + h2].w));
+          }
+        }
+      }
+    };
     auto issue_setup = [&](const StepInfo& si) {
       if constexpr (MODE == 1) {
         // chunk = sub-pixel (dy, dx) of the 2 x 2 blocks, then 64 of its C0 channels.  Virtual pixel (y', x') of the chunk
@@ -407,9 +427,17 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
         ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
       }
       if constexpr (PRO) {
-        const size_t o = (size_t)si.b * d.C0 + si.chunk * kCH + slot * 8;
-        ld_ca = L.pro_a + o;
-        ld_cb = L.pro_b + o;
+        const int c0 = si.chunk * kCH + slot * 8;
+        if (pfold) {
+          const GnFold& f = L.pro_fold;
+          ld_ca = f.P + (size_t)si.b * f.pq_stride + c0;
+          ld_cb = f.Q + (size_t)si.b * f.pq_stride + c0;
+          ld_acc = f.acc + ((size_t)si.b * f.G + c0 / f.cpg) * 2;
+        } else {
+          const size_t o = (size_t)si.b * d.C0 + c0;
+          ld_ca = L.pro_a + o;
+          ld_cb = L.pro_b + o;
+        }
       }
       hvalid_nxt = 0;
     };
@@ -419,6 +447,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
         dst[1] = *reinterpret_cast<const float4*>(ld_ca + 4);
         dst[2] = *reinterpret_cast<const float4*>(ld_cb);
         dst[3] = *reinterpret_cast<const float4*>(ld_cb + 4);
+        if (pfold) nacc = *reinterpret_cast<const longlong2*>(ld_acc);
       }
     };
     auto issue_unit = [&](int k) {                           // k is a compile-time constant at every call site
@@ -461,6 +490,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     // ---- prologue: halo 0 and weight tiles 0, 1 into LDS; halo 1 and tiles 2, 3, 4 into registers
     issue_setup(sA);
     issue_coeffs(cf);
+    fold_inplace(cf);
 #pragma unroll
     for (int k = 0; k < KU; ++k) issue_unit(k);
     hvalid = hvalid_nxt;
@@ -477,6 +507,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     hvalid = hvalid_nxt;
 #pragma unroll
     for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+    fold_inplace(cf);
     w_issue(2, w_tile(2 % NPH, chunk_of(2)));
     w_issue(0, w_tile(3 % NPH, chunk_of(3)));
     w_issue(1, w_tile(4 % NPH, chunk_of(4)));
@@ -504,6 +535,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
           hvalid = hvalid_nxt;
 #pragma unroll
           for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+          fold_inplace(cf);
           sA = sB;
           sB = sC;
           advance(sC);
@@ -557,7 +589,7 @@ __device__ inline uint32_t w2_cvt4(float a, float b, float c, float d) {
   return (uint32_t)w;
 }
 
-template <int TW, bool PRO>
+template <int TW, int PRO>   // PRO as in conv3x3_w256_kernel
 __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
                                                              const int tiles_n, const int fuse_stats) {
   using G = W2MxGeom<TW>;
@@ -714,7 +746,8 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
                 const int nsplit = tiles_x * tiles_y * 2;
                 const int slab = ((ty0 / TH) * tiles_x + tx0 / TW) * 2 + wm;
                 const int grp = (((tm.tn * BN + wn * 64) >> 3) + cc) >> gn_per_sh;
-                L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
+                if (L.gn_acc) gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, i >> 3, D);   // fixed-point accumulators (common.h)
+                else L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
               }
             }
           }
@@ -786,6 +819,25 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
     unsigned ld_cs2 = 0, ld_tedge = 0;
     const float* ld_ca = nullptr;
     const float* ld_cb = nullptr;
+    // pro_fold (common.h, GnFold): ld_ca / ld_cb point at P / Q and the coefficients are folded here from the image group's
+    // fixed-point statistics (ld_acc) when a halo's coefficients are adopted: A = rstd P, B = Q - mean A
+    constexpr bool pfold = PRO == 2;
+    const long long* ld_acc = nullptr;
+    longlong2 nacc = make_longlong2(0, 0);
+    auto fold_inplace = [&](float4* c) {
+      if constexpr (PRO) {
+        if (pfold) {
+          float mean, rstd;
+          gn_fold_stats_raw(nacc.x, nacc.y, L.pro_fold.inv_n, mean, rstd);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            c[h2] = make_float4(rstd * c[h2].x, rstd * c[h2].y, rstd * c[h2].z, rstd * c[h2].w);
+            c[2 + h2] = make_float4(fmaf(-mean, c[h2].x, c[2 + h2].x), fmaf(-mean, c[h2].y, c[2 + h2].y),
+                                    fmaf(-mean, c[h2].z, c[2 + h2].z), fmaf(-mean, c[h2].w, c[2 + h2].w));
+          }
+        }
+      }
+    };
     auto issue_setup = [&](const StepInfo& si) {
       const int c = si.chunk * kCH;
       const bool first = c < d.C0;
@@ -797,9 +849,17 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
       const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> d.ups)) * d.Win + (si.x0 >> d.ups) - (d.Win + 1);
       ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
       if constexpr (PRO) {
-        const size_t o = (size_t)si.b * d.C0 + si.chunk * kCH + slot * 8;
-        ld_ca = L.pro_a + o;
-        ld_cb = L.pro_b + o;
+        const int c0 = si.chunk * kCH + slot * 8;
+        if (pfold) {
+          const GnFold& f = L.pro_fold;
+          ld_ca = f.P + (size_t)si.b * f.pq_stride + c0;
+          ld_cb = f.Q + (size_t)si.b * f.pq_stride + c0;
+          ld_acc = f.acc + ((size_t)si.b * f.G + c0 / f.cpg) * 2;
+        } else {
+          const size_t o = (size_t)si.b * d.C0 + c0;
+          ld_ca = L.pro_a + o;
+          ld_cb = L.pro_b + o;
+        }
       }
       hvalid_nxt = 0;
     };
@@ -809,6 +869,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
         dst[1] = *reinterpret_cast<const float4*>(ld_ca + 4);
         dst[2] = *reinterpret_cast<const float4*>(ld_cb);
         dst[3] = *reinterpret_cast<const float4*>(ld_cb + 4);
+        if (pfold) nacc = *reinterpret_cast<const longlong2*>(ld_acc);
       }
     };
     auto issue_unit = [&](int k) {
@@ -875,6 +936,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
 
     issue_setup(sA);
     issue_coeffs(cf);
+    fold_inplace(cf);
 #pragma unroll
     for (int k = 0; k < KU; ++k) issue_unit(k);
     hvalid = hvalid_nxt;
@@ -891,6 +953,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
     hvalid = hvalid_nxt;
 #pragma unroll
     for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+    fold_inplace(cf);
     w_issue(2, 2, sA.chunk);
     w_issue(0, 3, sA.chunk);
     w_issue(1, 4, sA.chunk);
@@ -916,6 +979,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
           hvalid = hvalid_nxt;
 #pragma unroll
           for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+          fold_inplace(cf);
           sA = sB;
           sB = sC;
           advance(sC);
@@ -930,7 +994,17 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
 }  // namespace
 
 // Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
-int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+int materialize_prologue(ConvLaunch<bf16_t>& L, hipStream_t s);   // conv.hip
+
+// in-kernel GroupNorm fold of the prologue (common.h, GnFold): valid when an 8-channel unit lies inside one group
+static int w256_prepare_fold(ConvLaunch<bf16_t>& Lk, hipStream_t s) {
+  if (!Lk.pro_fold.acc) return PRG_OK;
+  const GnFold& f = Lk.pro_fold;
+  if (f.P && f.Q && f.cpg % 8 == 0 && f.G * f.cpg == Lk.d.C0 && Lk.d.C1 == 0) return PRG_OK;
+  return materialize_prologue(Lk, s);
+}
+
+int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done) {
   static const int enabled = [] {
     const char* e = std::getenv("PRG_CONV_W256");
     return e ? std::atoi(e) : 1;
@@ -966,32 +1040,37 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
   const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
                    tiles_x * tiles_y * 2 <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
-  const int pro = L.pro_a ? 1 : 0;
-  const void* fn = tw == 32 ? (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, true, 0>)
-                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, false, 0>))
-                            : (pro ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, true, 0>)
-                                   : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, false, 0>));
+  ConvLaunch<bf16_t> Lk = L;
+  if (int rc = w256_prepare_fold(Lk, s)) return rc;
+  const int pro = Lk.pro_fold.acc ? 2 : (L.pro_a ? 1 : 0);
+  const void* fns[2][3] = {{reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 1, 0>),
+                            reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 2, 0>)},
+                           {reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 1, 0>),
+                            reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 2, 0>)}};
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
-  static bool attr_done[2][2] = {{false, false}, {false, false}};
+  static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
   if (!attr_done[tw == 32][pro]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fns[tw == 32][pro], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 conv): ") + hipGetErrorString(e));
     attr_done[tw == 32][pro] = true;
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
+  if (acc_done) *acc_done = (fuse && L.gn_acc) ? 1 : 0;
   if (tw == 32) {
-    if (pro) conv3x3_w256_kernel<32, true, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
-    else conv3x3_w256_kernel<32, false, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro == 2) conv3x3_w256_kernel<32, 2, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else if (pro == 1) conv3x3_w256_kernel<32, 1, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256_kernel<32, 0, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
   } else {
-    if (pro) conv3x3_w256_kernel<16, true, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
-    else conv3x3_w256_kernel<16, false, 0><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro == 2) conv3x3_w256_kernel<16, 2, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else if (pro == 1) conv3x3_w256_kernel<16, 1, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256_kernel<16, 0, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
   }
   PRG_LAUNCH_CHECK();
   return 1;
 }
 
 // MX-fp8 operands (handles of dtype PRG_MXFP8): same shapes as the bf16 entry.  Returns 1 / 0 / negative.
-int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done) {
   static const int enabled = [] {
     const char* e = std::getenv("PRG_CONV_W256MX");
     return e ? std::atoi(e) : 1;
@@ -1026,25 +1105,30 @@ int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* g
   const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
                    tiles_x * tiles_y * 2 <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
-  const int pro = L.pro_a ? 1 : 0;
-  const void* fn = tw == 32 ? (pro ? reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, true>)
-                                   : reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, false>))
-                            : (pro ? reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<16, true>)
-                                   : reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<16, false>));
+  ConvLaunch<bf16_t> Lk = L;
+  if (int rc = w256_prepare_fold(Lk, s)) return rc;
+  const int pro = Lk.pro_fold.acc ? 2 : (L.pro_a ? 1 : 0);
+  const void* fns[2][3] = {{reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<16, 0>), reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<16, 1>),
+                            reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<16, 2>)},
+                           {reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 0>), reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 1>),
+                            reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 2>)}};
   const size_t lds = tw == 32 ? W2MxGeom<32>::LDS : W2MxGeom<16>::LDS;
-  static bool attr_done[2][2] = {{false, false}, {false, false}};
+  static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
   if (!attr_done[tw == 32][pro]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fns[tw == 32][pro], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 mx conv): ") + hipGetErrorString(e));
     attr_done[tw == 32][pro] = true;
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
+  if (acc_done) *acc_done = (fuse && L.gn_acc) ? 1 : 0;
   if (tw == 32) {
-    if (pro) conv3x3_w256mx_kernel<32, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
-    else conv3x3_w256mx_kernel<32, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro == 2) conv3x3_w256mx_kernel<32, 2><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else if (pro == 1) conv3x3_w256mx_kernel<32, 1><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256mx_kernel<32, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
   } else {
-    if (pro) conv3x3_w256mx_kernel<16, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
-    else conv3x3_w256mx_kernel<16, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro == 2) conv3x3_w256mx_kernel<16, 2><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else if (pro == 1) conv3x3_w256mx_kernel<16, 1><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else conv3x3_w256mx_kernel<16, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
   }
   PRG_LAUNCH_CHECK();
   return 1;
@@ -1081,8 +1165,8 @@ int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
   const int grid = num_cus & ~7;
   static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
   if (grid < 8 || total < (min_fill > 0 ? min_fill : grid / 2)) return 0;   // the generic kernel for tiny launches
-  const void* fn = tw == 32 ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, false, 1>)
-                            : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, false, 1>);
+  const void* fn = tw == 32 ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 1>)
+                            : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 1>);
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
   static bool attr_done[2] = {false, false};
   if (!attr_done[tw == 32]) {
@@ -1090,8 +1174,8 @@ int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 downsample): ") + hipGetErrorString(e));
     attr_done[tw == 32] = true;
   }
-  if (tw == 32) conv3x3_w256_kernel<32, false, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
-  else conv3x3_w256_kernel<16, false, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
+  if (tw == 32) conv3x3_w256_kernel<32, 0, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
+  else conv3x3_w256_kernel<16, 0, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
   PRG_LAUNCH_CHECK();
   return 1;
 }

@@ -817,7 +817,8 @@ __global__ __launch_bounds__(768) void conv3x3_ws_kernel(const ConvLaunch<bf16_t
               const int nsplit = tiles_x * tiles_y * G::WAVES_M;
               const int slab = ((ty0 / TH) * tiles_x + tx0 / TW) * G::WAVES_M + wm;
               const int grp = (((ttn * BN + wn * 64) >> 3) + cc) >> gn_per_sh;
-              L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
+              if (L.gn_acc) gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, i >> 3, D);   // fixed-point accumulators (common.h)
+              else L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 3)] = D;
             }
           }
 #pragma unroll
@@ -928,7 +929,7 @@ int launch_ws_cfg(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, in
 }  // namespace
 
 // Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
-int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out) {
+int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done) {
   static const int enabled = [] {
     const char* e = std::getenv("PRG_CONV_WS");
     return e ? std::atoi(e) : 1;
@@ -966,6 +967,7 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
       (prefer64 >= 2 || tn64 == 2)) {
     rc = launch_ws_cfg<8, 32, 64>(L, s, fuse_for(8, 32, 64), gn_nsplit_out, num_cus);
     if (rc == kWsUnsupported) return 0;
+    if (rc == PRG_OK && acc_done) *acc_done = (L.gn_acc && gn_nsplit_out && *gn_nsplit_out > 0) ? 1 : 0;
     return rc == PRG_OK ? 1 : rc;
   }
   if (d.Cout % 128 == 0) {
@@ -979,6 +981,7 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
     else return 0;
   }
   if (rc == kWsUnsupported) return 0;
+  if (rc == PRG_OK && acc_done) *acc_done = (L.gn_acc && gn_nsplit_out && *gn_nsplit_out > 0) ? 1 : 0;
   return rc == PRG_OK ? 1 : rc;
 }
 

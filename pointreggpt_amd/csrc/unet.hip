@@ -4,6 +4,7 @@
 // sd:1283-1409.  Activations live as NHWC tensors of T (bf16_t or float) in a stack arena owned by the handle;
 // the skip `torch.cat` never materialises (two source pointers into the conv), `nn.Upsample` is folded into the
 // following conv's gather, weight standardisation is folded into the packed weights at load time.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,12 @@ static bool head_fuse_enabled() {
 }
 static bool res_epilogue_enabled() {
   static const int on = [] { const char* e = std::getenv("PRG_RES_EPILOGUE"); return e ? std::atoi(e) : 1; }();
+  return on != 0;
+}
+// PRG_GN_ACC=0: GroupNorm statistics as per-tile slabs + one gn_coeff_kernel launch per norm (rounds 1-2) instead of the
+// fixed-point accumulators folded by the consumers (common.h, GnFold).  bf16 / mxfp8 handles only; fp32 always uses slabs.
+static bool gn_acc_enabled() {
+  static const int on = [] { const char* e = std::getenv("PRG_GN_ACC"); return e ? std::atoi(e) : 1; }();
   return on != 0;
 }
 static bool gn_fold_enabled() {
@@ -99,6 +106,8 @@ struct ResP {
   int64_t g1 = 0, b1 = 0, g2 = 0, b2 = 0;
   int64_t fw_res = -1;             // bf16 element offset of the raw res_conv weight in the fused-kernel arena (-1: unfused)
   bool has_res = false;
+  int64_t pq1 = -1, pq2 = -1;      // float offsets into d_pq_static of (P = gamma | Q = beta) of norm 1 / 2, each cpad floats
+  int cpad = 0;                    // cout rounded up to 4 floats (16-byte aligned rows)
 };
 struct AttnP {
   int C = 0;
@@ -179,6 +188,10 @@ static int build_layout(const prg_unet_config& cfg, Layout& L) {
     L.dims.push_back(cfg.dim * cfg.dim_mults[i]);
   }
   for (size_t i = 0; i < L.dims.size(); ++i) PRG_CHECK(L.dims[i] % cfg.groups == 0, "config: width not divisible by groups");
+  for (size_t i = 0; i < L.dims.size(); ++i)
+    if (L.dims[i] > 1024)
+      return fail(PRG_E_INVALID, "config: dim * dim_mult = " + std::to_string(L.dims[i]) + " exceeds 1024 channels, the widest "
+                  "GroupNorm the coefficient kernels handle (gn_coeff_kernel / affine_silu_fold_kernel: four channels per thread)");
   const bool cond = cfg.conditional != 0;
   Cursor c;
   const int d0 = cfg.dim, e = L.emb;
@@ -256,6 +269,13 @@ struct prg_unet {
   uint8_t* d_mx_scale = nullptr;
   float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
   int* d_tickets = nullptr;     // [kMaxTicketImages] per-image arrival counters of the conv kernels that fold GroupNorm coefficients (self-resetting)
+  // fixed-point GroupNorm statistics (common.h, GnFold; bf16 / mxfp8 handles)
+  long long* d_gnacc = nullptr; // [slots][resB][groups][2], zeroed by ONE memset at the start of every forward
+  size_t gnacc_bytes = 0;
+  int gn_slots = 0, gn_slot = 0;
+  float* d_pq_static = nullptr; // (gamma | beta) of every norm, 16-byte aligned rows: P / Q of the unconditioned norms
+  CondFoldEntry* d_cond_entries = nullptr;   // one entry per conditioned norm (Block 1 of every ResnetBlock)
+  int n_cond_entries = 0;
   Arena arena;
   uint64_t arena_gen = 0;       // bumped whenever the workspace is reallocated: captured graphs bake its pointers in
   int resB = 0, resS = 0;
@@ -298,6 +318,9 @@ struct UnetImpl : prg_unet {
     float* coef_a = nullptr;
     float* coef_b = nullptr;
     int* coef_done = nullptr;       // out: 1 = coef_a / coef_b are written by the conv launch (no gn_coeff launch needed)
+    long long* gn_acc = nullptr;    // fixed-point statistics of the output (instead of gn_partials when the kernel can)
+    int* acc_done = nullptr;        // out: 1 = the launch accumulated into gn_acc
+    const GnFold* fold = nullptr;   // prologue coefficients folded by the consumer (pro_a / pro_b = scratch tables)
   };
 
   ConvDesc make_desc(const ConvP& p, int C0, int C1, int B, int Hin, int Win, int stride, int pad, int ups) const {
@@ -326,9 +349,12 @@ struct UnetImpl : prg_unet {
     L.gn = o.gn ? *o.gn : GnApply{};
     L.gn_coef_a = o.gn ? o.coef_a : nullptr; L.gn_coef_b = o.gn ? o.coef_b : nullptr;
     L.gn_tickets = (o.gn && gn_fold_enabled()) ? d_tickets : nullptr;
+    L.gn_acc = o.gn_acc;
+    L.pro_fold = o.fold ? *o.fold : GnFold{};
     PRG_CHECK(C0 + C1 == p.Cin, "conv: channel mismatch");
     if (o.gn_nsplit) *o.gn_nsplit = 0;
     if (o.coef_done) *o.coef_done = 0;
+    if (o.acc_done) *o.acc_done = 0;
     if (arena.dry) return PRG_OK;
     if (prof && prof->on) {
       if (prof->used == prof->pool.size()) {
@@ -339,7 +365,7 @@ struct UnetImpl : prg_unet {
       }
       auto& ev = prof->pool[prof->used++];
       PRG_HIP(hipEventRecord(ev.first, s));
-      int rc = launch_conv<T>(L, s, o.gn_nsplit, o.coef_done);
+      int rc = launch_conv<T>(L, s, o.gn_nsplit, o.coef_done, o.acc_done);
       PRG_HIP(hipEventRecord(ev.second, s));
       prof->conv_flops += conv_flops(L.d);
       prof->conv_bytes += ((double)L.d.B * L.d.Hin * L.d.Win * (L.d.C0 + L.d.C1) + (double)L.d.B * L.d.Hout * L.d.Wout * L.d.Cout +
@@ -347,7 +373,28 @@ struct UnetImpl : prg_unet {
       prof->launches += 1;
       return rc;
     }
-    return launch_conv<T>(L, s, o.gn_nsplit, o.coef_done);
+    return launch_conv<T>(L, s, o.gn_nsplit, o.coef_done, o.acc_done);
+  }
+
+  // ---- fixed-point GroupNorm statistics (bf16 path) ----
+  const float* pq_dyn = nullptr;     // [B][ss_total] P | Q of the conditioned norms of THIS forward (cond_fold_kernel)
+  bool acc_on() const { return std::is_same<T, bf16_t>::value && d_gnacc && gn_acc_enabled(); }
+  long long* next_acc(int B) {
+    if (!acc_on() || gn_slot >= gn_slots) return nullptr;
+    return d_gnacc + (size_t)(gn_slot++) * resB * lay.cfg.groups * 2;
+  }
+  GnFold make_fold(const long long* acc, int C, int HW, bool conditioned, int ss_off, int64_t pq_static) const {
+    GnFold f{};
+    f.acc = acc;
+    f.G = lay.cfg.groups;
+    f.cpg = C / f.G;
+    f.inv_n = 1.0f / ((float)HW * (float)f.cpg);
+    if (conditioned && pq_dyn) {
+      f.P = pq_dyn + ss_off; f.Q = f.P + C; f.pq_stride = lay.ss_total;
+    } else {
+      f.P = d_pq_static + pq_static; f.Q = f.P + ((C + 3) & ~3); f.pq_stride = 0;
+    }
+    return f;
   }
 
   GnApply gn_params(int64_t g_off, int64_t b_off, const CondSrc* cs, int ss_off) const {
@@ -383,28 +430,48 @@ struct UnetImpl : prg_unet {
     PRG_CHECK(arena.dry || (h1 && part1 && part2 && coefA && coefB && coefA2 && coefB2 && (!r.has_res || res)),
               "workspace exhausted (resblock)");
     const CondSrc* c1 = lay.cfg.conditional ? cs : nullptr;
-    int rc, ns1 = 0, ns2 = 0, cd1 = 0, cd2 = 0;
+    int rc, ns1 = 0, ns2 = 0, cd1 = 0, cd2 = 0, ad1 = 0, ad2 = 0;
     const GnApply g1 = gn_params(r.g1, r.b1, c1, r.ss_off);
     const GnApply g2 = gn_params(r.g2, r.b2, nullptr, 0);
+    // bf16: statistics as fixed-point accumulators, coefficients folded by whoever consumes them (no gn_coeff launches)
+    long long* acc1 = next_acc(B);
+    long long* acc2 = next_acc(B);
     ConvOpt o1;
     o1.gn_partials = part1; o1.gn_nsplit = &ns1;
     o1.gn = &g1; o1.coef_a = coefA; o1.coef_b = coefB; o1.coef_done = &cd1;
+    o1.gn_acc = acc1; o1.acc_done = &ad1;
     if ((rc = conv(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, o1, h1, s))) return rc;
     if (!arena.dry && ns1 == 0 && (rc = launch_gn_stats<T>(h1, part1, B, HW, r.cout, G, &ns1, s))) return rc;
     // conv2's own statistics fold into a second coefficient pair (coefA / coefB are still being read by its prologue)
     ConvOpt o2;
     o2.gn_partials = part2; o2.gn_nsplit = &ns2;
     o2.gn = &g2; o2.coef_a = coefA2; o2.coef_b = coefB2; o2.coef_done = &cd2;
+    o2.gn_acc = acc2; o2.acc_done = &ad2;
     // PRG_FUSE_PRO: -1 (default) fuse wherever the conv supports it; 0 never; N > 0 only for widths >= N
     static const int fuse_min = [] { const char* e = std::getenv("PRG_FUSE_PRO"); return e ? std::atoi(e) : -1; }();
+    // PRG_FUSE_PRO_MAX=N: widths above N apply GroupNorm + SiLU in one flat pass over h1 instead (a conv with several
+    // output-channel tiles transforms every input pixel once per tile in its prologue)
+    static const int fuse_max = [] { const char* e = std::getenv("PRG_FUSE_PRO_MAX"); return e ? std::atoi(e) : 1 << 30; }();
     const bool fuse_pro = conv_supports_prologue<T>(make_desc(r.c2, r.cout, 0, B, H, Wd, 1, 1, 0)) &&
-                          (fuse_min < 0 || (fuse_min > 0 && r.cout >= fuse_min));
+                          (fuse_min < 0 || (fuse_min > 0 && r.cout >= fuse_min)) && r.cout <= fuse_max;
+    GnFold f1{}, f2{};
     if (!arena.dry) {
-      if (!cd1 && (rc = launch_gn_coeff(part1, ns1, g1, coefA, coefB, B, HW, r.cout, G, s))) return rc;
-      if (fuse_pro) {
-        o2.pro_a = coefA; o2.pro_b = coefB;
-      } else if ((rc = launch_affine_silu<T>(h1, coefA, coefB, nullptr, h1, B, HW, r.cout, s))) {
-        return rc;
+      if (ad1) {
+        f1 = make_fold(acc1, r.cout, HW, c1 && c1->ss_a, r.ss_off, r.pq1);
+        if (fuse_pro) {
+          o2.fold = &f1; o2.pro_a = coefA; o2.pro_b = coefB;    // (tables: scratch for kernels without the in-kernel fold)
+        } else {
+          if constexpr (std::is_same<T, bf16_t>::value) {
+            if ((rc = launch_affine_silu_fold(h1, f1, nullptr, h1, B, HW, r.cout, s))) return rc;
+          }
+        }
+      } else {
+        if (!cd1 && (rc = launch_gn_coeff(part1, ns1, g1, coefA, coefB, B, HW, r.cout, G, s))) return rc;
+        if (fuse_pro) {
+          o2.pro_a = coefA; o2.pro_b = coefB;
+        } else if ((rc = launch_affine_silu<T>(h1, coefA, coefB, nullptr, h1, B, HW, r.cout, s))) {
+          return rc;
+        }
       }
     }
     if ((rc = conv(r.c2, h1, r.cout, nullptr, 0, B, H, Wd, 1, 1, 0, o2, out, s))) return rc;
@@ -425,16 +492,19 @@ struct UnetImpl : prg_unet {
       PRG_CHECK(C1 == 0 && C0 == r.cout, "resblock: identity skip needs equal widths");
     }
     if (!arena.dry) {
-      // GroupNorm + SiLU + skip: fold the statistics into per-(image, channel) coefficients, then one flat pass
-      if (!cd2 && (rc = launch_gn_coeff(part2, ns2, g2, coefA2, coefB2, B, HW, r.cout, G, s))) return rc;
+      // GroupNorm + SiLU + skip.  Accumulator path: the tail kernels fold the coefficients themselves (the 1x1 res_conv's
+      // epilogue reads tables: one gn_coeff_acc launch for those four blocks); slab path: gn_coeff launch, then the tables
+      if (ad2) f2 = make_fold(acc2, r.cout, HW, false, 0, r.pq2);
+      else if (!cd2 && (rc = launch_gn_coeff(part2, ns2, g2, coefA2, coefB2, B, HW, r.cout, G, s))) return rc;
       if constexpr (std::is_same<T, bf16_t>::value) {
         if (fused_tail) {
           rc = launch_resblock_tail_fused(out, coefA2, coefB2, s0, C0, s1, C1, d_attn + r.fw_res, F(r.res.b_off), out, B, HW,
-                                          r.cout, s, head_w, head_b, head_out, head_sigmoid);
+                                          r.cout, s, head_w, head_b, head_out, head_sigmoid, ad2 ? &f2 : nullptr);
           head_done = head_out != nullptr;
           arena.reset(m);
           return rc;
         }
+        if (ad2 && epi_tail && (rc = launch_gn_coeff_acc(f2, coefA2, coefB2, B, r.cout, s))) return rc;
       }
       if (epi_tail) {
         ConvOpt ro;
@@ -442,6 +512,13 @@ struct UnetImpl : prg_unet {
         rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, ro, out, s);
         arena.reset(m);
         return rc;
+      }
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        if (ad2) {
+          rc = launch_affine_silu_fold(out, f2, skip, out, B, HW, r.cout, s);
+          arena.reset(m);
+          return rc;
+        }
       }
       if ((rc = launch_affine_silu<T>(out, coefA2, coefB2, skip, out, B, HW, r.cout, s))) return rc;
     } else if (epi_tail) {
@@ -512,6 +589,24 @@ struct UnetImpl : prg_unet {
     const CondSrc* cs = L.cfg.conditional ? &cond : nullptr;
     int rc;
     const int d0 = L.cfg.dim;
+    // fixed-point GroupNorm statistics (bf16 path): one memset for every norm of the evaluation, one launch that folds the
+    // conditioning (scale + 1, shift) of every ResnetBlock into P / Q — instead of one gn_coeff launch per norm
+    gn_slot = 0;
+    pq_dyn = nullptr;
+    if (std::is_same<T, bf16_t>::value && gn_acc_enabled()) {
+      if (acc_on() && !arena.dry) PRG_HIP(hipMemsetAsync(d_gnacc, 0, gnacc_bytes, s));
+      if (L.cfg.conditional && n_cond_entries > 0) {
+        float* pq = alloc<float>((size_t)B * L.ss_total);
+        PRG_CHECK(arena.dry || pq, "workspace exhausted (conditioning fold)");
+        if (acc_on() && !arena.dry && cs && cs->ss_a) {
+          GnApply ss{};
+          ss.ss_a = cs->ss_a; ss.ss_a_stride = cs->ss_a_stride; ss.ss_b = cs->ss_b; ss.ss_b_stride = cs->ss_b_stride;
+          ss.ss_a_row = cs->row; ss.ss_a_row_stride = cs->row_stride;
+          if ((rc = launch_cond_fold(d_cond_entries, n_cond_entries, d_flat, ss, pq, L.ss_total, B, s))) return rc;
+          pq_dyn = pq;
+        }
+      }
+    }
     T* x0 = alloc<T>((size_t)B * S * S * d0);
     PRG_CHECK(arena.dry || x0, "workspace exhausted (stem)");
     bool stem_done = false;
@@ -791,6 +886,35 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       PRG_HIP(hipMemcpy(u->d_mx_scale, scales.data(), scales.size(), hipMemcpyHostToDevice));
     }
   }
+  if (std::is_same<T, bf16_t>::value) {
+    // fixed-point GroupNorm statistics (common.h, GnFold): P = gamma, Q = beta of every norm in 16-byte aligned rows (what
+    // the unconditioned norms use directly) and the table cond_fold_kernel walks for the conditioned ones
+    std::vector<float> pq;
+    std::vector<CondFoldEntry> ent;
+    auto add = [&](ResP& r) {
+      r.cpad = (r.cout + 3) & ~3;
+      auto put = [&](int64_t g_off, int64_t b_off) {
+        const int64_t o = (int64_t)pq.size();
+        pq.resize(pq.size() + 2 * (size_t)r.cpad, 0.0f);
+        std::memcpy(pq.data() + o, weights + g_off, sizeof(float) * r.cout);
+        std::memcpy(pq.data() + o + r.cpad, weights + b_off, sizeof(float) * r.cout);
+        return o;
+      };
+      r.pq1 = put(r.g1, r.b1);
+      r.pq2 = put(r.g2, r.b2);
+      if (L.cfg.conditional) ent.push_back(CondFoldEntry{r.ss_off, r.cout, (long long)r.g1, (long long)r.b1});
+    };
+    for (auto& lv : u->lay.downs) { add(lv.r0); add(lv.r1); }
+    for (auto& lv : u->lay.ups) { add(lv.r0); add(lv.r1); }
+    add(u->lay.mid1); add(u->lay.mid2); add(u->lay.fin);
+    if (hipMalloc(&u->d_pq_static, pq.size() * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(norm gains)");
+    PRG_HIP(hipMemcpy(u->d_pq_static, pq.data(), pq.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!ent.empty()) {
+      if (hipMalloc(&u->d_cond_entries, ent.size() * sizeof(CondFoldEntry)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(cond entries)");
+      PRG_HIP(hipMemcpy(u->d_cond_entries, ent.data(), ent.size() * sizeof(CondFoldEntry), hipMemcpyHostToDevice));
+      u->n_cond_entries = (int)ent.size();
+    }
+  }
   if (hipMalloc(&u->d_tickets, kMaxTicketImages * sizeof(int)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(tickets)");
   PRG_HIP(hipMemset(u->d_tickets, 0, kMaxTicketImages * sizeof(int)));
   if (std::is_same<T, bf16_t>::value && L.cfg.in_channels == 1 && L.cfg.dim == 64) {
@@ -829,9 +953,26 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
         shifts[d] = (float)(1.02 * std::sqrt(n2 * a.C));
         ok = ok && shifts[d] <= 40.0f * 1.4426950408889634f;
       }
+      // the same bound for the q rows (softmax over the 32 d of a head, per pixel): one shift per head
+      float qsh[kHeads];
+      for (int h = 0; h < kHeads; ++h) {
+        double worst = 0;
+        for (int d = 0; d < kDimHead; ++d) {
+          double n2 = 0;
+          for (int c = 0; c < a.C; ++c) {
+            const double w = bf16_to_f32(aw[(size_t)a.fw_qkv + (size_t)(h * kDimHead + d) * a.C + c]);
+            n2 += w * w;
+          }
+          worst = std::max(worst, 1.02 * std::sqrt(n2 * a.C));
+        }
+        qsh[h] = (float)worst;
+        ok = ok && qsh[h] <= 40.0f * 1.4426950408889634f;
+      }
       if (ok) {
         a.kshift = (int64_t)ks.size();
         ks.insert(ks.end(), shifts, shifts + kHidden);
+        ks.insert(ks.end(), qsh, qsh + kHeads);
+        ks.resize((ks.size() + 3) & ~(size_t)3);
       }
       a.fw_out = (int64_t)aw.size();
       for (int c = 0; c < a.C; ++c)
@@ -879,6 +1020,17 @@ static int reserve(prg_unet* h, int B, int S) {
   ++h->arena_gen;
   h->resB = nb;
   h->resS = ns;
+  if (h->dtype != PRG_F32 && h->d_pq_static) {
+    // fixed-point GroupNorm accumulators: two norms per ResnetBlock, [slots][resB][groups][2] int64
+    if (h->d_gnacc) PRG_HIP(hipFree(h->d_gnacc));
+    h->d_gnacc = nullptr;
+    h->gn_slots = 2 * (4 * h->lay.L + 3);
+    h->gnacc_bytes = (size_t)h->gn_slots * nb * h->lay.cfg.groups * 2 * sizeof(long long);
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_gnacc), h->gnacc_bytes) != hipSuccess) {
+      h->d_gnacc = nullptr;
+      return fail(PRG_E_NOMEM, "hipMalloc(GroupNorm accumulators)");
+    }
+  }
   return PRG_OK;
 }
 
@@ -1007,6 +1159,9 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_mx) hipFree(h->d_mx);
   if (h->d_mx_scale) hipFree(h->d_mx_scale);
   if (h->d_tickets) hipFree(h->d_tickets);
+  if (h->d_gnacc) hipFree(h->d_gnacc);
+  if (h->d_pq_static) hipFree(h->d_pq_static);
+  if (h->d_cond_entries) hipFree(h->d_cond_entries);
   if (h->d_stem_frag) hipFree(h->d_stem_frag);
   if (h->arena.base) hipFree(h->arena.base);
   delete h;

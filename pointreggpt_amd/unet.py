@@ -80,13 +80,22 @@ class _HipNet:
         return self
 
     def set_time_freqs(self, freqs=None):
-        """SinusoidalPosEmb's frequency table (sd:645-657).  Default = the reference's own expression evaluated by torch on
-        this host, i.e. what the reference would use here; pass the table of another host to reproduce results made
-        there (the reference's outputs depend on this float32 exp at the 4e-5 level over a 50-step chain)."""
+        """SinusoidalPosEmb's frequency table (sd:645-657), a float32 `exp` whose last bit matters: one ulp moves a 50-step
+        chain by 4e-5.  The reference evaluates it with torch on the device its model lives on
+        (`torch.arange(half_dim, device=x.device)`), so:
+          * None (default) — torch on THIS HOST'S CPU: what the reference's CPU path, the parity target named by
+            BASELINE.json's north star, computes on this machine;
+          * "device" — torch on the HIP device: what the reference would compute when it runs on an accelerator;
+          * an array — the table of another host (the golden fixtures carry the one of the host that made them)."""
         import math
         half = self.cfg.dim // 2
-        if freqs is None:
+        if freqs is None or (isinstance(freqs, str) and freqs == "cpu"):
             freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+        elif isinstance(freqs, str):
+            if freqs != "device":
+                raise ValueError("freqs must be None, 'cpu', 'device' or an array of dim/2 values")
+            _lib.require_gpu()
+            freqs = torch.exp(torch.arange(half, device="cuda") * -(math.log(10000) / (half - 1))).cpu()
         f = np.ascontiguousarray(np.asarray(freqs, dtype=np.float32).reshape(-1))
         if f.size != half:
             raise ValueError(f"need {half} frequencies")
