@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
 // =====================================================================================================
 // pass 2: per-slab sums of p = exp(k - max) and of p v^T
 // =====================================================================================================
-template <int C, bool O3>   // O3: register budget for three blocks per CU (C = 64: 168 registers, three of them spilled)
-__global__ __launch_bounds__(256, O3 ? 3 : 1) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+template <int C, bool PSUM_MFMA>   // PSUM_MFMA: sum_n p on the matrix pipe (16 more registers: C = 64 keeps the float sum and three blocks per CU)
+__global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : 1) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
                                                            const float* __restrict__ pmax, const float* __restrict__ kshift,
                                                            float* __restrict__ ctxp, float* __restrict__ sump, int N, int nslab) {
   using G = Geo<C>;
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256, O3 ? 3 : 1) void la_ctx_fused_kernel(const bf1
   // bf16-rounded p that feeds ctx — instead of 64 float additions per tile and lane.
   float nm = -m;
   f32x16 psum = zero16();                              // rows d (any column)
+  float ssum = 0.0f;
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256, O3 ? 3 : 1) void la_ctx_fused_kernel(const bf1
 #pragma unroll
           for (int j = 0; j < 4; ++j) p[j] = px0 + j < valid ? __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]) : 0.0f;
         }
+        if constexpr (!PSUM_MFMA) ssum += (p[0] + p[1]) + (p[2] + p[3]);
         uint2 pw, vw;
         pw.x = pack2(p[0], p[1]);
         pw.y = pack2(p[2], p[3]);
@@ -272,14 +274,19 @@ __global__ __launch_bounds__(256, O3 ? 3 : 1) void la_ctx_fused_kernel(const bf1
     for (int kk = 0; kk < kTP / 16; ++kk) {
       const bf16x8 pf = frag(pT, kLdP, l31, hi, kk);
       ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag(vT, kLdP, l31, hi, kk), ctx, 0, 0, 0);
-      psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ones, psum, 0, 0, 0);
+      if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ones, psum, 0, 0, 0);
     }
     __syncthreads();
   }
   const size_t ph = ((size_t)b * 4 + wave) * nslab + slab;
-  if (l31 == 0) {
+  if constexpr (PSUM_MFMA) {
+    if (l31 == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sump[ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = psum[r];
+      for (int r = 0; r < 16; ++r) sump[ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = psum[r];
+    }
+  } else {
+    ssum += __shfl_xor(ssum, 32, 64);
+    if (hi == 0) sump[ph * 32 + l31] = ssum;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) ctxp[ph * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = ctx[r];
@@ -845,7 +852,7 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
     int rc;
     if ((rc = set_lds(&la_kmax_fused_kernel<C>, lds_kmax<C>()))) return rc;
     if ((rc = set_lds(&la_ctx_fused_kernel<C, false>, lds_ctx<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, C == 64>, lds_ctx<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true>, lds_ctx<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, false>, lds_out<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, true>, lds_out<C>()))) return rc;
     attr = true;
@@ -860,9 +867,12 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
     la_kmax_fused_kernel<C><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, N, nslab);
     PRG_LAUNCH_CHECK();
   }
-  static const int occ3 = [] { const char* e = std::getenv("PRG_LA_OCC3"); return e ? std::atoi(e) : 0; }();
-  if (occ3 && C == 64) la_ctx_fused_kernel<C, C == 64><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
-  else la_ctx_fused_kernel<C, false><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  // PRG_LA_PSUM: -1 (default) the matrix-pipe sum where it costs no occupancy (C >= 128), 0 never, 1 always
+  static const int psum_env = [] { const char* e = std::getenv("PRG_LA_PSUM"); return e ? std::atoi(e) : -1; }();
+  if (psum_env > 0 || (psum_env < 0 && C >= 128))
+    la_ctx_fused_kernel<C, true><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  else
+    la_ctx_fused_kernel<C, false><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
   PRG_LAUNCH_CHECK();
   la_fin_fused_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctxT, N, nslab);
   PRG_LAUNCH_CHECK();
