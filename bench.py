@@ -203,9 +203,10 @@ def e2e_files(a, unet, mask, diff, rank, world, B, S, lanes=None):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def drift_vs_reference(dtypes, dim, rep_batch=64):
+def drift_vs_reference(dtypes, dim):
     """Distance of the library's precision modes from the REAL reference on chains of real length: the committed fixtures
-    G20 (250-step DDIM @128x128) and G19 (1000-step ancestral @64x64), both produced by the reference itself on the
+    G20 (250-step DDIM @128x128), G19 (1000-step ancestral @64x64) and G21 (250-step DDIM @256x256: configs[4]'s chain), all
+    produced by the reference itself on the
     calibrated synthetic denoiser (tools/make_goldens.py), re-run here through the C-ABI on the fixtures' stored condition
     and regenerated noise.  Metres (normalised depth x 10); in-painted pixels only (known pixels are bit-exact)."""
     import hashlib
@@ -216,7 +217,8 @@ def drift_vs_reference(dtypes, dim, rep_batch=64):
     gold = os.path.join(ROOT, "tests", "golden")
     g0 = np.load(os.path.join(gold, "G0_host_tables.npz"))
     out = {}
-    for name, S, steps, tab in (("G20_ddim250_128", 128, 250, "ddim250"), ("G19_chain1000_ancestral_64", 64, None, "anc1000")):
+    for name, S, steps, tab, rep_batch in (("G20_ddim250_128", 128, 250, "ddim250", 64), ("G19_chain1000_ancestral_64", 64, None, "anc1000", 64),
+                                           ("G21_ddim250_256", 256, 250, "ddim250", 16)):
         path = os.path.join(gold, name + ".npz")
         if not os.path.exists(path):
             out[name] = "fixture missing"

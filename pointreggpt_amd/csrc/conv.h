@@ -65,6 +65,9 @@ struct ConvLaunch {
   // tables that kernels without the in-kernel fold fill with one gn_coeff_acc launch first).
   long long* gn_acc;
   GnFold pro_fold;
+  // res_fold.acc != null (with `residual`, 1x1 convs on the implicit-GEMM kernel): the activated residual's coefficients are
+  // folded in the epilogue from the accumulators (once per thread and image) instead of read from res_a / res_b
+  GnFold res_fold;
   // MX-fp8 operands (handles of dtype PRG_MXFP8, 3x3 / s1 / p1 convs with 64-channel multiples): OCP e4m3 weights
   // [tap][64-channel chunk][CoutPad][64] with one E8M0 scale per 32 input channels [tap][chunk][CoutPad][2]; null = bf16.
   const uint8_t* w_mx;

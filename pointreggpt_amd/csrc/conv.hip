@@ -143,6 +143,10 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
   for (int u = 0; u < 8; ++u) bias[u] = (L.bias && col_ok) ? L.bias[col + u] : 0.0f;
   gs = 0;
   gq = 0;
+  // activated residual with in-kernel GroupNorm fold (common.h, GnFold): this thread's 8 channels lie in one group; the
+  // coefficients are recomputed only when the row's image changes (a tile spans one image, rarely two)
+  float fa[8], fb[8];
+  int fimg = -1;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     __syncthreads();  // previous pass fully read (and, first time, the main loop's LDS reads are done)
@@ -169,7 +173,25 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
         }
         if (L.residual) {
           float ra[8], rb[8];
-          if (L.res_a) {
+          const bool act = L.res_a != nullptr || L.res_fold.acc != nullptr;
+          if (L.res_fold.acc) {
+            const int img = (int)m / (L.d.Hout * L.d.Wout);
+            if (img != fimg) {
+              fimg = img;
+              const GnFold& f = L.res_fold;
+              float mean, rstd;
+              gn_fold_stats(f, img, col / f.cpg, mean, rstd);
+              const float* pp = f.P + (size_t)img * f.pq_stride + col;
+              const float* pq = f.Q + (size_t)img * f.pq_stride + col;
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                fa[u] = rstd * pp[u];
+                fb[u] = fmaf(-mean, fa[u], pq[u]);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ra[u] = fa[u]; rb[u] = fb[u]; }
+          } else if (L.res_a) {
             const size_t cb = (size_t)((int)m / (L.d.Hout * L.d.Wout)) * L.d.Cout + col;   // this row's image
             const float4 a0 = *reinterpret_cast<const float4*>(L.res_a + cb), a1 = *reinterpret_cast<const float4*>(L.res_a + cb + 4);
             const float4 b0 = *reinterpret_cast<const float4*>(L.res_b + cb), b1 = *reinterpret_cast<const float4*>(L.res_b + cb + 4);
@@ -182,7 +204,7 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
 #pragma unroll
             for (int u = 0; u < VEC; ++u) {
               const float r = Elem<T>::load(rv.e[u]);
-              v[h * VEC + u] += L.res_a ? Elem<T>::silu(fmaf(r, ra[h * VEC + u], rb[h * VEC + u])) : r;
+              v[h * VEC + u] += act ? Elem<T>::silu(fmaf(r, ra[h * VEC + u], rb[h * VEC + u])) : r;
             }
           }
         }
@@ -923,6 +945,9 @@ int launch_conv(const ConvLaunch<T>& Lin, hipStream_t s, int* gn_nsplit_out, int
   PRG_CHECK(d.C1 == 0 || L.src1, "conv: second source missing");
   PRG_CHECK(!L.res_a || (L.residual && L.res_b && d.KH == 1 && d.KW == 1 && d.Cout % 8 == 0),
             "conv: the activated residual is a 1x1 (implicit-GEMM, wide epilogue) feature");
+  PRG_CHECK(!L.res_fold.acc || (L.residual && d.KH == 1 && d.KW == 1 && d.Cout % 8 == 0 && L.res_fold.cpg % 8 == 0 &&
+                                L.res_fold.G * L.res_fold.cpg == d.Cout && L.res_fold.P && L.res_fold.Q),
+            "conv: the folded activated residual needs a 1x1 conv whose 8-channel vectors lie inside one GroupNorm group");
   PRG_CHECK(d.CoutPad % 64 == 0 && d.CoutPad >= d.Cout, "conv: bad CoutPad");
   const int64_t M64 = (int64_t)d.B * d.Hout * d.Wout;
   PRG_CHECK(M64 > 0 && M64 < (int64_t)1 << 31, "conv: M out of range");

@@ -321,6 +321,7 @@ struct UnetImpl : prg_unet {
     long long* gn_acc = nullptr;    // fixed-point statistics of the output (instead of gn_partials when the kernel can)
     int* acc_done = nullptr;        // out: 1 = the launch accumulated into gn_acc
     const GnFold* fold = nullptr;   // prologue coefficients folded by the consumer (pro_a / pro_b = scratch tables)
+    const GnFold* res_fold = nullptr;   // activated residual folded in the 1x1 conv's epilogue (instead of res_a / res_b)
   };
 
   ConvDesc make_desc(const ConvP& p, int C0, int C1, int B, int Hin, int Win, int stride, int pad, int ups) const {
@@ -351,6 +352,7 @@ struct UnetImpl : prg_unet {
     L.gn_tickets = (o.gn && gn_fold_enabled()) ? d_tickets : nullptr;
     L.gn_acc = o.gn_acc;
     L.pro_fold = o.fold ? *o.fold : GnFold{};
+    L.res_fold = o.res_fold ? *o.res_fold : GnFold{};
     PRG_CHECK(C0 + C1 == p.Cin, "conv: channel mismatch");
     if (o.gn_nsplit) *o.gn_nsplit = 0;
     if (o.coef_done) *o.coef_done = 0;
@@ -504,11 +506,19 @@ struct UnetImpl : prg_unet {
           arena.reset(m);
           return rc;
         }
-        if (ad2 && epi_tail && (rc = launch_gn_coeff_acc(f2, coefA2, coefB2, B, r.cout, s))) return rc;
       }
       if (epi_tail) {
         ConvOpt ro;
-        ro.residual = out; ro.res_a = coefA2; ro.res_b = coefB2;
+        ro.residual = out;
+        const bool fold_ok = ad2 && f2.cpg % 8 == 0;
+        if (fold_ok) {
+          ro.res_fold = &f2;                                  // coefficients folded in the res_conv's epilogue
+        } else {
+          if constexpr (std::is_same<T, bf16_t>::value) {
+            if (ad2 && (rc = launch_gn_coeff_acc(f2, coefA2, coefB2, B, r.cout, s))) return rc;
+          }
+          ro.res_a = coefA2; ro.res_b = coefB2;
+        }
         rc = conv(r.res, s0, C0, s1, C1, B, H, Wd, 1, 0, 0, ro, out, s);
         arena.reset(m);
         return rc;

@@ -288,7 +288,7 @@ def test_G0_host_tables_are_this_hosts():
 
 
 def test_G19_G20_long_chain_prefix_and_clouds(golden):
-    """Round-3 chains of real length (1000-step ancestral at 64x64, 250-step DDIM at 128x128, calibrated denoiser).
+    """Round-3 chains of real length (1000-step ancestral at 64x64, 250-step DDIM at 128x128 and at 256x256, calibrated denoiser).
     tools/make_goldens.py asserted the oracle bit-exact over the WHOLE chain when the fixture was made (minutes of CPU);
     here: the regenerated noise matches its sha256, the oracle reproduces the reference's state after 20 transitions
     bit-exactly, and the stored cloud is the oracle's unprojection of the stored image."""
@@ -299,9 +299,10 @@ def test_G19_G20_long_chain_prefix_and_clouds(golden):
         nz = regenerate_chain_noise(g)
         sd = W.synth_state_dict(W.unet_config(64), int(g["wseed"]), calibrated=True)
         den = lambda x, t, cc: OU.unet_forward(sd, x, t, cc)
-        x20 = OD.sample(sch, den, T(g["pc"]), T(g["img_cond"]), c["S"], OD.stored_noise(nz), sampling_steps=c["steps"],
-                        stop_after=20)
-        assert np.array_equal(x20.numpy(), g["x20"]), name
+        if c["S"] <= 128:       # (256x256: 2.4 s per oracle evaluation — the whole-chain assert of make_goldens.py stands alone)
+            x20 = OD.sample(sch, den, T(g["pc"]), T(g["img_cond"]), c["S"], OD.stored_noise(nz), sampling_steps=c["steps"],
+                            stop_after=20)
+            assert np.array_equal(x20.numpy(), g["x20"]), name
         cloud = OG.inverse_pose_apply(OG.point_cloud(g["sampled"][0, 0] * 10, g["K"][0], (0.5, 10.0)), g["pose"][0])
         assert np.array_equal(cloud, g["cloud"])
         # the fixture is a non-degenerate workload: the in-painted pixels do not sit on the clamp
