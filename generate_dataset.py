@@ -12,6 +12,8 @@ hard-coded literals, generate_dataset.py:32-55):
   --data_root /path/to/3DMatch-RGBD/train
   --streams 2         lanes per GPU: batches are dealt round-robin to N host threads / HIP streams with their own network
                       handles, so one lane's launch gaps are filled by the other's kernels (+7 % pairs/s); files are identical
+  --device cpu        the prg_cpu_* twins (libprg_cpu.so: plain C++ / OpenMP, float32) instead of the HIP library: BASELINE
+                      configs[0]'s plumbing run without a GPU; explicit only, the default never falls back to it
   --synthetic SEED    synthetic scenes instead of 3DMatch frames (no dataset needed)
   --noise_seed N      seed of the diffusion noise (default: fresh entropy, printed; synthetic runs default to SEED)
   --resume synthetic[:SEED]   deterministic synthetic weights instead of ./successive_ddnm_diffusion_results/model-<resume>.pt
@@ -39,6 +41,9 @@ def main():
                    help="arithmetic of the two U-Nets: fp32 = parity mode (the reference's amp=False), bf16 / mxfp8 = throughput modes")
     p.add_argument("--streams", default=2, type=int,
                    help="concurrent lanes per GPU (own network handles + HIP stream + host thread each; batches dealt round-robin)")
+    p.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                   help="cpu = the prg_cpu_* twins (plain C++ / OpenMP, float32): BASELINE configs[0]'s plumbing run without a "
+                        "GPU.  Never chosen implicitly: the default fails loudly when there is no HIP device")
     p.add_argument("--data_root", default="/path/to/3DMatch-RGBD/train", type=str)
     p.add_argument("--synthetic", default=None, type=int, help="seed of the synthetic scene generator")
     p.add_argument("--mask_threshold", default=0.99, type=float)
@@ -48,13 +53,20 @@ def main():
     args = p.parse_args()
 
     from pointreggpt_amd import sharding
-    from pointreggpt_amd.diffusion import GaussianDiffusion
     from pointreggpt_amd.generator import Generator
-    from pointreggpt_amd.unet import MaskUnet, Unet
     from pointreggpt_amd.weights import maskunet_state_from_checkpoint
+    if args.device == "cpu":
+        if args.dtype != "fp32":
+            p.error("--device cpu computes in float32: use --dtype fp32")
+        from pointreggpt_amd.cpu import GaussianDiffusion, MaskUnet, Unet
+        args.streams = 1
+    else:
+        from pointreggpt_amd.diffusion import GaussianDiffusion
+        from pointreggpt_amd.unet import MaskUnet, Unet
 
     rank, world, local = sharding.rank_world()
-    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # (more ranks than devices: ranks share, used by the tests)
+    if args.device == "cuda":
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # (more ranks than devices: ranks share, used by the tests)
     start, stop = sharding.shard_range(args.start_scene_index, args.stop_scene_index, rank, world, args.batch_size)
 
     model = Unet(dim=args.dim, param_cond_dim=4, dim_mults=(1, 2, 4, 8), channels=1, dtype=args.dtype)
@@ -64,7 +76,8 @@ def main():
                                   beta_schedule="sigmoid", ddim_sampling_eta=1.0, is_ddnm_sampling=True)
     generator = Generator(diffusion, args.data_root, batch_size=args.batch_size,
                           results_folder="./successive_ddnm_diffusion_results",
-                          samples_folder="./{}/data".format(args.dataset_name), synthetic_seed=args.synthetic)
+                          samples_folder="./{}/data".format(args.dataset_name), synthetic_seed=args.synthetic,
+                          device=args.device)
 
     def load_weights(unet, mask):
         if args.resume.startswith("synthetic"):
@@ -96,7 +109,8 @@ def main():
         generator.generate(start_scene_index=start, stop_scene_index=stop, num_samples=args.num_samples,
                            has_refine_step=False, depth_correction=depth_correction,
                            mask_threshold=args.mask_threshold, noise_seed=args.noise_seed, lanes=lanes)
-    torch.cuda.synchronize()
+    if args.device == "cuda":
+        torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

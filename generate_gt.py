@@ -15,9 +15,13 @@ def main():
     p.add_argument("--stop_scene_index", "-stop", default=1, type=int, help="scenes index to stop")
     p.add_argument("--num_samples", default=2, type=int, help="sample numbers for each scene")
     p.add_argument("--disable_tqdm", action="store_true", help="disable tqdm")
+    p.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                   help="cpu = the numpy grid specification of the overlap test instead of the HIP all-pairs kernel "
+                        "(BASELINE configs[0]: no GPU); explicit only")
     args = p.parse_args()
     from pointreggpt_amd.generator import gather_gt, generate_gt
-    generate_gt(args.dataset_name, args.start_scene_index, args.stop_scene_index, args.num_samples)
+    generate_gt(args.dataset_name, args.start_scene_index, args.stop_scene_index, args.num_samples,
+                overlap="hip" if args.device == "cuda" else "numpy-spec")
     gather_gt(args.dataset_name, args.start_scene_index, args.stop_scene_index)
 
 

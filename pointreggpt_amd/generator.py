@@ -44,6 +44,13 @@ class Generator:
         self.results_folder = Path(results_folder)
         self.synthetic_seed = synthetic_seed
         self.device = torch.device(device)
+        # device ops: the HIP library (default; raises without a GPU) or, ONLY when asked for with device="cpu", the
+        # prg_cpu_* twins (BASELINE configs[0]: the plumbing run that needs no GPU)
+        if self.device.type == "cpu":
+            from . import cpu as _cpu
+            self.G = _cpu.ops
+        else:
+            self.G = G
 
     # -- weights (sd:2307-2324): the generator samples from the EMA copy ------------------------------------------
     def load(self, milestone, unet=None):
@@ -133,6 +140,8 @@ class Generator:
                 continue
             batches.append(idxs)
         pairs = [(self.model, depth_correction)] + list(lanes or [])
+        if self.device.type == "cpu":
+            pairs = pairs[:1]                 # lanes are HIP streams
         if self.synthetic_seed is None and not seed_poses:
             pairs = pairs[:1]                 # one global pose stream cannot be shared by concurrent lanes
         pairs = pairs[:max(1, len(batches))]
@@ -206,7 +215,7 @@ class Generator:
                     depth0[j, 0], K[j] = self._scene_inputs(idx, info_train, sdir)
                 K_dev = torch.from_numpy(K).to(dev)
                 # the source frames of the whole batch in ONE unprojection (sd:2479-2483 does it per scene)
-                frames = G.point_clouds(torch.from_numpy(depth0).to(dev), K_dev, None)
+                frames = self.G.point_clouds(torch.from_numpy(depth0).to(dev), K_dev, None)
                 memory: List[np.ndarray] = []
                 marker_cur = None
                 for j in range(batch):
@@ -220,7 +229,7 @@ class Generator:
                         marker_cur = job              # this batch's resume marker: written after everything else
                     else:
                         job()
-                param_cond = G.param_vector(K_dev)
+                param_cond = self.G.param_vector(K_dev)
                 fragments: List[Optional[np.ndarray]] = [None] * batch
                 poses0 = None
                 for sample_idx in range(num_samples):
@@ -229,15 +238,15 @@ class Generator:
                     if sample_idx == 0:
                         poses0 = pose
                     pose_dev = torch.from_numpy(pose).to(dev)
-                    rpj, hit = G.project_clouds(memory, pose, K, S, dev, depth_scale=0.1)
+                    rpj, hit = self.G.project_clouds(memory, pose, K, S, dev, depth_scale=0.1)
                     prob = depth_correction(rpj)
-                    rpj_c, hit_c, cond = G.apply_mask(prob, rpj, hit, mask_threshold)
+                    rpj_c, hit_c, cond = self.G.apply_mask(prob, rpj, hit, mask_threshold)
                     seeds = [synthetic.noise_seed(noise_seed, i, sample_idx) for i in idxs]
                     images = model.sample(param_cond=param_cond, img_cond=cond, seeds=seeds,
                                           has_refine_step=has_refine_step)
                     prob2 = depth_correction(images)
-                    images, _, _ = G.apply_mask(prob2, images, None, mask_threshold, want_cond=False)
-                    xyz, valid = G.unproject_f64(images, K_dev, pose_dev)      # common frame, float64 (sd:2623-2628)
+                    images, _, _ = self.G.apply_mask(prob2, images, None, mask_threshold, want_cond=False)
+                    xyz, valid = self.G.unproject_f64(images, K_dev, pose_dev)      # common frame, float64 (sd:2623-2628)
                     # one blocking copy per tensor: the host waits here for the GPU while the pool writes the previous batch
                     rpj_host, crt_host, img_host = rpj.cpu().numpy(), rpj_c.cpu().numpy(), images.cpu().numpy()
                     xyz_host, valid_host = xyz.cpu().numpy(), valid.cpu().numpy()
