@@ -1089,6 +1089,15 @@ def test_two_ranks_produce_the_single_rank_files_byte_for_byte(tmp_path):
     diff = [k for k in f1 if f1[k] != f2[k]]
     assert not diff, diff[:10]
     assert len(f1["metadata/gt.log"].splitlines()) >= 1
+    # ... and neither do they depend on the lanes inside a rank (the runs above used the default two): one lane, same bytes
+    lane1 = tmp_path / "lane1"
+    lane1.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(root, "generate_dataset.py"), "--streams", "1"] + args, cwd=lane1, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    f3 = _files_of(lane1 / "ds")
+    data = [k for k in f1 if k.startswith("data/") and not k.endswith("gt.log")]
+    assert len(data) == 72 and not [k for k in data if f1[k] != f3[k]]
 
 
 def test_real_data_path_end_to_end(tmp_path):
