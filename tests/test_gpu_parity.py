@@ -632,7 +632,15 @@ def test_long_chain_fp32_north_star(hip, golden, name):
           f"|hip - exact|max {maxerr(torch.from_numpy(img), g['sampled_exact']) * 10:.3e} m; saturated {rep['saturated_fraction']:.4f}")
     assert rep["same_valid_mask"] and rep["points"][0] == rep["points"][1]
     assert rep["saturated_fraction"] < 0.2
-    assert rep["xyz_linf_m"] <= max(1e-4, spread), rep
+    if rep["xyz_linf_m"] > max(1e-4, spread):
+        # A chain on which the reference sits farther from exact arithmetic than its own thread-count spread (G21: 4.3e-4 m
+        # from its float64 twin, 1.8e-4 m between 1 and 8 threads — both runs share most of their roundoff): an implementation
+        # that is CLOSER to exact arithmetic cannot also be inside that spread.  Then, as for G12: at most half as far from
+        # exact arithmetic as the reference is, and no farther from the reference than the reference is from exact.
+        e_exact = maxerr(torch.from_numpy(img), g["sampled_exact"])
+        print(f"{name}: outside the reference's thread spread; |hip - exact| {e_exact:.3e} vs |reference - exact| {float(g['depth_ref_to_exact']):.3e} (depth)")
+        assert e_exact <= 0.5 * float(g["depth_ref_to_exact"]), (e_exact, float(g["depth_ref_to_exact"]))
+        assert rep["xyz_linf_m"] <= 1.1 * float(g["xyz_ref_to_exact_m"]), rep
 
 
 # <= 2x observed (printed by the test; B = 64, the benchmarked launch shapes): (depth max, depth mean) of the in-painted pixels
@@ -642,7 +650,10 @@ def test_long_chain_fp32_north_star(hip, golden, name):
 LONG_DRIFT_BOUNDS = {("G19_chain1000_ancestral_64", "bf16"): (0.08, 0.02, 0.08), ("G19_chain1000_ancestral_64", "mxfp8"): (0.26, 0.062, 0.26),
                      ("G20_ddim250_128", "bf16"): (1.3, 0.05, 1.3), ("G20_ddim250_128", "mxfp8"): (2.5, 0.093, 2.4),
                      # BASELINE configs[4]'s own chain and format (256x256, 250-step DDIM; B = 16)
-                     ("G21_ddim250_256", "bf16"): (None, None, None), ("G21_ddim250_256", "mxfp8"): (None, None, None)}
+                     # (16.6 % of this chain's in-painted pixels sit on the clamp in the reference itself: a pixel that saturates in one
+                     # run and not in the other differs by metres, so the maximum / L-infinity are not bounded here — the mean is;
+                     # observed bf16 mean 4.5 cm / median 1.2 cm, mxfp8 mean 8.9 cm / median 4.0 cm)
+                     ("G21_ddim250_256", "bf16"): (None, 0.09, None), ("G21_ddim250_256", "mxfp8"): (None, 0.18, None)}
 
 
 @pytest.mark.parametrize("name", ["G19_chain1000_ancestral_64", "G20_ddim250_128", "G21_ddim250_256"])
@@ -658,8 +669,8 @@ def test_long_chain_reduced_precision_drift_in_metres(hip, golden, name, dtype):
           f"{rep['same_valid_mask']}; saturated {rep['saturated_fraction']:.4f}")
     assert rep["saturated_fraction"] < 0.2
     mx, mean, xyz = LONG_DRIFT_BOUNDS[(name, dtype)]
-    assert mx is not None, "bounds not recorded yet"
-    assert rep["depth_max_m"] <= mx and rep["depth_mean_m"] <= mean and rep["xyz_linf_m"] <= xyz, rep
+    assert rep["depth_mean_m"] <= mean and rep["depth_median_m"] <= mean, rep
+    assert (mx is None or rep["depth_max_m"] <= mx) and (xyz is None or rep["xyz_linf_m"] <= xyz), rep
 
 
 # ------------------------------------------------------------------------------------------------------------------
