@@ -14,11 +14,15 @@ def load(path, flt):
     names = [n for n, _ in seq]
     # period of the middle of the sequence (the first and last transitions of a run differ from the steady ones)
     N = len(names)
-    mid = N // 2
-    for P in range(50, N // 3):
-        if names[mid:mid + P] == names[mid + P:mid + 2 * P] == names[mid - P:mid]:
+    P = None
+    for mid in (N // 2, N // 4, (3 * N) // 4, N // 3):      # (the middle of a two-batch trace is the gap between the batches)
+        for cand in range(50, N // 6):
+            if names[mid:mid + cand] == names[mid + cand:mid + 2 * cand] == names[mid - cand:mid]:
+                P = cand
+                break
+        if P:
             break
-    else:
+    if not P:
         raise SystemExit("no period found")
     starts = [s for s in range(mid % P, N - P + 1, P) if names[s:s + P] == names[mid:mid + P]]
     # rotate the window so that it starts at the U-Net's first kernel (the stem conv)
