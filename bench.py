@@ -557,6 +557,13 @@ def main():
         res["cpu_baseline"] = cpu_baseline(S, a.dim)
 
     if rank == 0:
+        res["evidence"] = {"profiles": "profiles/r03_*: rocprofv3 --kernel-trace --stats summaries (one and two lanes), the three PMC passes, "
+                                       "per-launch listing of one evaluation, the driver-command bench line, the GPU test log",
+                           "ab_records": "profiles/r03_ab_*.json compare pairs/s of alternating runs of the same binary on the same box (box to "
+                                         "box the same binary spreads +-4 %); kernel-level comparisons (tools/prof_seq.py) are microseconds at the "
+                                         "same position of the replayed graph on one box — rocprofv3's kernel trace carries no cycle counts; "
+                                         "SQ_WAVE_CYCLES / SQ_BUSY_CYCLES per kernel are in profiles/r03_end_pmc_sq_summary.txt",
+                           "power": "profiles/r03_power_1_vs_2_lanes.json: pairs per joule is the same with one and two lanes (power ceiling)"}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
