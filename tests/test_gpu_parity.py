@@ -1209,3 +1209,33 @@ def test_real_data_path_end_to_end(tmp_path):
         e_ema = np.abs(d16 - np.round(imgs["ema"][i, 0].cpu().numpy().astype(np.float64) * 1e4)).max()
         e_onl = np.abs(d16 - np.round(imgs["online"][i, 0].cpu().numpy().astype(np.float64) * 1e4)).max()
         assert e_ema <= 1 and e_onl > 100, (e_ema, e_onl)
+
+
+def test_bench_contract_line(tmp_path):
+    """bench.py's contract with the driver on a small workload: ONE JSON line on stdout with the fixed keys, the roofline object of
+    the dominant kernel class measured live, two lanes, the file leg and the configs[4] leg."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--size", "64", "--sampling-steps", "6", "--profile-transitions", "3", "--e2e-batches", "2", "--c4-batch", "2",
+                        "--c4-steps", "1", "--no-cpu-baseline", "--no-drift"], cwd=tmp_path, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "e2e_files", "configs4", "workload"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["vs_baseline"] is None and j["dtype"] == "bf16" and j["data"] == "synthetic" and j["unit"] == "pairs/s"
+    assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["streams"] == 2
+    assert abs(j["value"] - 2 * 8 / (j["ms_per_step"] * 2 / 1e3)) < 1e-6 * j["value"]
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] > 0
+    assert j["e2e_files"]["files_written"] == 9 * 8 * (2 + 2) and j["e2e_files"]["gt_log"]["lines"] >= 0
+    assert j["configs4"]["dtype"] == "mxfp8" and j["configs4"]["config"]["image_size"] == 256 and j["configs4"]["roofline"]["peak"] == 5000.0
