@@ -186,8 +186,15 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
 // =====================================================================================================
 // pass 2: per-slab sums of p = exp(k - max) and of p v^T
 // =====================================================================================================
-template <int C, bool PSUM_MFMA>   // PSUM_MFMA: sum_n p on the matrix pipe (16 more registers: C = 64 keeps the float sum and three blocks per CU)
-__global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : 1) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+// PSUM_MFMA: sum_n p on the matrix pipe (16 more registers: C = 64 keeps the float sum and three blocks per CU).
+// REGOP: p and v go into the context MFMA STRAIGHT FROM THE ACCUMULATOR REGISTERS — the contraction index (pixels) may be
+// enumerated in any order as long as both operands use the same one, and lane (column, half hi) of the k / v accumulators
+// holds, in registers 8 i .. 8 i + 7, exactly the eight pixels that A's row / B's column `l31` supplies for k-slots
+// 8 hi .. 8 hi + 7 of k-step i (la_out's trick for q) — no transposed LDS tiles (32 two-way bank-conflicted ds_write_b64 and
+// 8 ds_read_b128 per tile and wave), 37 KB less LDS per block.
+// DEPTH: x tiles in flight per block (register slots; the loop is unrolled by DEPTH so that a slot is a compile-time choice).
+template <int C, bool PSUM_MFMA, bool REGOP, int DEPTH>
+__global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : (C == 128 ? 2 : 1)) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
                                                            const float* __restrict__ pmax, const float* __restrict__ kshift,
                                                            float* __restrict__ ctxp, float* __restrict__ sump, int N, int nslab) {
   using G = Geo<C>;
@@ -224,12 +231,14 @@ __global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : 1) void la_ctx_f
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  XTile<C> xt;
-  if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
-  for (int t = t0; t < t1; ++t) {
+  XTile<C> xs[DEPTH];
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd)
+    if (t0 + dd < t1) xs[dd].load(x, (int64_t)b * N + (int64_t)(t0 + dd) * kTP, min(kTP, N - (t0 + dd) * kTP));
+  auto tile = [&](XTile<C>& xt, const int t) {
     xt.normalize_to(xn);
     __syncthreads();
-    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
+    if (t + DEPTH < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + DEPTH) * kTP, min(kTP, N - (t + DEPTH) * kTP));
     asm volatile("" : "+v"(nm));                           // (keeps the 16-register splat from being hoisted out of the loop)
     f32x16 kinit;
 #pragma unroll
@@ -246,37 +255,62 @@ __global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : 1) void la_ctx_f
     }
     const int valid = min(kTP, N - t * kTP);
     const bool full = valid == kTP;                        // wave-uniform: whole tiles skip the 32 per-pixel masks
-    // p and v, transposed to [channel][pixel] so that pixels become the MFMA k index
+    if constexpr (REGOP) {
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int px0 = pt * 32 + 8 * g4 + 4 * hi;
-        float p[4];
-        if (full) {
+        for (int i = 0; i < 2; ++i) {
+          bf16x8 pa, vb;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) p[j] = px0 + j < valid ? __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]) : 0.0f;
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const int r = 8 * i + s2;
+            const int px = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float pv = (full || px < valid) ? __builtin_amdgcn_exp2f(ka[pt][r]) : 0.0f;
+            if constexpr (!PSUM_MFMA) ssum += pv;
+            pa[s2] = (__bf16)pv;
+            vb[s2] = (__bf16)va[pt][r];
+          }
+          ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, ctx, 0, 0, 0);
+          if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ones, psum, 0, 0, 0);
         }
-        if constexpr (!PSUM_MFMA) ssum += (p[0] + p[1]) + (p[2] + p[3]);
-        uint2 pw, vw;
-        pw.x = pack2(p[0], p[1]);
-        pw.y = pack2(p[2], p[3]);
-        vw.x = pack2(va[pt][4 * g4], va[pt][4 * g4 + 1]);
-        vw.y = pack2(va[pt][4 * g4 + 2], va[pt][4 * g4 + 3]);
-        *reinterpret_cast<uint2*>(pT + l31 * kLdP + px0) = pw;
-        *reinterpret_cast<uint2*>(vT + l31 * kLdP + px0) = vw;
-      }
-    // ctx[d][e] += sum_px p[px][d] v[px][e]   (same wave wrote the tiles: LDS operations of a wave stay in order)
+    } else {
+      // p and v, transposed to [channel][pixel] so that pixels become the MFMA k index
 #pragma unroll
-    for (int kk = 0; kk < kTP / 16; ++kk) {
-      const bf16x8 pf = frag(pT, kLdP, l31, hi, kk);
-      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag(vT, kLdP, l31, hi, kk), ctx, 0, 0, 0);
-      if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ones, psum, 0, 0, 0);
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int px0 = pt * 32 + 8 * g4 + 4 * hi;
+          float p[4];
+          if (full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = px0 + j < valid ? __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]) : 0.0f;
+          }
+          if constexpr (!PSUM_MFMA) ssum += (p[0] + p[1]) + (p[2] + p[3]);
+          uint2 pw, vw;
+          pw.x = pack2(p[0], p[1]);
+          pw.y = pack2(p[2], p[3]);
+          vw.x = pack2(va[pt][4 * g4], va[pt][4 * g4 + 1]);
+          vw.y = pack2(va[pt][4 * g4 + 2], va[pt][4 * g4 + 3]);
+          *reinterpret_cast<uint2*>(pT + l31 * kLdP + px0) = pw;
+          *reinterpret_cast<uint2*>(vT + l31 * kLdP + px0) = vw;
+        }
+      // ctx[d][e] += sum_px p[px][d] v[px][e]   (same wave wrote the tiles: LDS operations of a wave stay in order)
+#pragma unroll
+      for (int kk = 0; kk < kTP / 16; ++kk) {
+        const bf16x8 pf = frag(pT, kLdP, l31, hi, kk);
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag(vT, kLdP, l31, hi, kk), ctx, 0, 0, 0);
+        if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ones, psum, 0, 0, 0);
+      }
     }
     __syncthreads();
+  };
+  for (int t = t0; t < t1; t += DEPTH) {
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd)
+      if (t + dd < t1) tile(xs[dd], t + dd);
   }
   const size_t ph = ((size_t)b * 4 + wave) * nslab + slab;
   if constexpr (PSUM_MFMA) {
@@ -851,8 +885,12 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
   if (!attr) {
     int rc;
     if ((rc = set_lds(&la_kmax_fused_kernel<C>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false>, lds_ctx<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, true>, lds_ctx<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, false, 1>, lds_ctx<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, false, 1>, lds_ctx<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 1>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 1>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 2>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 3>, lds_kmax<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, false>, lds_out<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, true>, lds_out<C>()))) return rc;
     attr = true;
@@ -867,12 +905,23 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
     la_kmax_fused_kernel<C><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, N, nslab);
     PRG_LAUNCH_CHECK();
   }
-  // PRG_LA_PSUM: -1 (default) the matrix-pipe sum where it costs no occupancy (C >= 128), 0 never, 1 always
+  // PRG_LA_PSUM: -1 (default) the matrix-pipe sum where it costs no occupancy (every width with REGOP, C >= 128 without), 0 never, 1 always
+  // PRG_LA_CTX_REGOP: 1 (default) the context MFMA takes p and v from the accumulator registers; 0 = transposed LDS tiles
   static const int psum_env = [] { const char* e = std::getenv("PRG_LA_PSUM"); return e ? std::atoi(e) : -1; }();
-  if (psum_env > 0 || (psum_env < 0 && C >= 128))
-    la_ctx_fused_kernel<C, true><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
-  else
-    la_ctx_fused_kernel<C, false><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  static const int regop = [] { const char* e = std::getenv("PRG_LA_CTX_REGOP"); return e ? std::atoi(e) : 1; }();
+  const bool psum = psum_env > 0 || (psum_env < 0 && (regop || C >= 128));   // (REGOP + matrix-pipe sum at C = 64: 168 registers, no spill)
+  // PRG_LA_DEPTH: x tiles in flight per block in la_ctx (register-operand + matrix-pipe-sum variant only): 1, 2 or 3
+  static const int depth_env = [] { const char* e = std::getenv("PRG_LA_DEPTH"); return e ? std::atoi(e) : 1; }();
+  const int depth = (C <= 128 && regop && psum) ? (C == 128 && depth_env > 2 ? 2 : depth_env) : 1;   // (C = 128 at depth 3 spills)
+  if (regop) {
+    if (psum && depth >= 3) la_ctx_fused_kernel<C, true, true, 3><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+    else if (psum && depth == 2) la_ctx_fused_kernel<C, true, true, 2><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+    else if (psum) la_ctx_fused_kernel<C, true, true, 1><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+    else la_ctx_fused_kernel<C, false, true, 1><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  } else {
+    if (psum) la_ctx_fused_kernel<C, true, false, 1><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+    else la_ctx_fused_kernel<C, false, false, 1><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  }
   PRG_LAUNCH_CHECK();
   la_fin_fused_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctxT, N, nslab);
   PRG_LAUNCH_CHECK();
