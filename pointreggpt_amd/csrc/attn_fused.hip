@@ -18,6 +18,7 @@
 // B[8(l>>5)..+7][l&31] and receives D[(r&3) + 8(r>>2) + 4(l>>5)][l&31] in register r.
 // The LayerNorm gain of PreNorm is folded into the projection weights on the host (unet.hip).
 #include <cstdlib>
+#include <type_traits>
 
 #include "blocks.h"
 
@@ -34,9 +35,19 @@ constexpr int kTilesPerBlock = 8;
 // Linear attention: tiles per block as a function of the image size ONLY (a batch-independent slab structure keeps a
 // scene's result identical for every batch size): 8 from 64 x 64 pixels up, fewer for the small levels, whose launches
 // otherwise fill a quarter of the CUs with blocks that walk four tiles in series (16 x 16: 64 blocks -> 256).
-__host__ __device__ inline int la_tpb(int ntiles) {
+#ifndef PRG_LA_CTX_TPB
+#define PRG_LA_CTX_TPB 8
+#endif
+#ifndef PRG_LA_OUT_TPB
+#define PRG_LA_OUT_TPB 8
+#endif
+__host__ __device__ inline int la_tpb(int ntiles) {             // la_kmax / la_ctx (the slab structure of the partials)
   const int t = ntiles / 8;
-  return t < 1 ? 1 : (t > kTilesPerBlock ? kTilesPerBlock : t);
+  return t < 1 ? 1 : (t > PRG_LA_CTX_TPB ? PRG_LA_CTX_TPB : t);
+}
+__host__ __device__ inline int la_out_tpb(int ntiles) {         // la_out (pixels are independent there: any partition)
+  const int t = ntiles / 8;
+  return t < 1 ? 1 : (t > PRG_LA_OUT_TPB ? PRG_LA_OUT_TPB : t);
 }
 constexpr int kLdO = kHid + 8;       // LDS row stride of 128-wide rows (bf16 elements)
 constexpr int kLdP = kTP + 8;        // LDS row stride of the transposed p / v tiles
@@ -57,6 +68,13 @@ struct Geo {
   static constexpr int VPT = C / 32;      // 16-byte vectors per thread of a 64 x C tile (4 threads per pixel row)
   static constexpr int KK = C / 16;       // MFMA k-steps over C
 };
+
+// sum over the four lanes of a quad (quad_perm [1,0,3,2] then [2,3,0,1]), every lane gets the total
+__device__ inline float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
 
 // ---- x tile: global -> registers -> LayerNorm -> LDS ------------------------------------------------------------
 // thread t: pixel row t >> 2, vectors (t & 3) + 4 i (interleaved so that a row's four threads read one contiguous run)
@@ -84,8 +102,7 @@ struct XTile {
         s += f[i][2 * j] + f[i][2 * j + 1];
       }
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    s = quad_sum(s);                                     // a row's four threads are one quad: DPP, no LDS crossbar
     const float mean = s * (1.0f / C);
     float q = 0.0f;
 #pragma unroll
@@ -95,9 +112,8 @@ struct XTile {
         f[i][j] -= mean;
         q = fmaf(f[i][j], f[i][j], q);
       }
-    q += __shfl_xor(q, 1, 64);
-    q += __shfl_xor(q, 2, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + kLnEps);
+    q = quad_sum(q);
+    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / C) + kLnEps);   // (v_rsq_f32, 1 ulp: these tiles are rounded to bf16 next)
 #pragma unroll
     for (int i = 0; i < Geo<C>::VPT; ++i) {
       uint4 o;
@@ -193,8 +209,9 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
 // 8 hi .. 8 hi + 7 of k-step i (la_out's trick for q) — no transposed LDS tiles (32 two-way bank-conflicted ds_write_b64 and
 // 8 ds_read_b128 per tile and wave), 37 KB less LDS per block.
 // DEPTH: x tiles in flight per block (register slots; the loop is unrolled by DEPTH so that a slot is a compile-time choice).
-template <int C, bool PSUM_MFMA, bool REGOP, int DEPTH>
-__global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : (C == 128 ? 2 : 1)) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+// PTSEQ (with REGOP): the two 32-pixel halves of a tile one after the other (half the accumulator registers).
+template <int C, bool PSUM_MFMA, bool REGOP, int DEPTH, bool PTSEQ = false>
+__global__ __launch_bounds__(256, C == 64 ? ((REGOP || !PSUM_MFMA) ? 3 : 2) : (C == 128 ? 2 : 1)) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
                                                            const float* __restrict__ pmax, const float* __restrict__ kshift,
                                                            float* __restrict__ ctxp, float* __restrict__ sump, int N, int nslab) {
   using G = Geo<C>;
@@ -231,15 +248,65 @@ __global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : (C == 128 ? 2 : 
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  f32x16 kinit0;                                       // (REGOP) the k accumulators' initial value, loop-invariant
+#pragma unroll
+  for (int e = 0; e < 16; ++e) kinit0[e] = nm;
   XTile<C> xs[DEPTH];
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd)
     if (t0 + dd < t1) xs[dd].load(x, (int64_t)b * N + (int64_t)(t0 + dd) * kTP, min(kTP, N - (t0 + dd) * kTP));
   auto tile = [&](XTile<C>& xt, const int t) {
+    if constexpr (DEPTH > 1) __builtin_amdgcn_sched_barrier(0);   // (tiles stay apart: interleaving two of them doubles the live accumulators)
     xt.normalize_to(xn);
     __syncthreads();
     if (t + DEPTH < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + DEPTH) * kTP, min(kTP, N - (t + DEPTH) * kTP));
-    asm volatile("" : "+v"(nm));                           // (keeps the 16-register splat from being hoisted out of the loop)
+    const int valid = min(kTP, N - t * kTP);
+    const bool full = valid == kTP;                        // wave-uniform: whole tiles take the branch without the per-pixel masks
+    if constexpr (REGOP) {
+      // One 32-pixel half: k = x Wk^T - shift and v = x Wv^T on the matrix pipe (the shift is the first MFMA's C operand, a
+      // loop-invariant register set: no splat and no subtraction per tile), p = exp2(k), then ctx += p^T v with p and v
+      // taken straight from the accumulator registers.  FULL tiles carry no masks (the loop is VALU-bound: per tile and
+      // wave the masks were ~100 of ~330 VALU instructions).
+      auto half = [&](const int pt, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        f32x16 k1, v1;
+#pragma unroll
+        for (int kk = 0; kk < G::KK; ++kk) {
+          const bf16x8 xf = frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk);
+          k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wk[kk], kk == 0 ? kinit0 : k1, 0, 0, 0);
+          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv[kk], kk == 0 ? zero16() : v1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf16x8 pa, vb;
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const int r = 8 * i + s2;
+            float pe = __builtin_amdgcn_exp2f(k1[r]);
+            if constexpr (!FULL) pe = (pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) < valid ? pe : 0.0f;
+            if constexpr (!PSUM_MFMA) ssum += pe;
+            pa[s2] = (__bf16)pe;
+            vb[s2] = (__bf16)v1[r];
+          }
+          ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, ctx, 0, 0, 0);
+          if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ones, psum, 0, 0, 0);
+        }
+      };
+      auto both = [&](auto full_c) {
+        if constexpr (PTSEQ) {
+          // one half after the other: 32 accumulator registers live instead of 64
+#pragma unroll 1
+          for (int pt = 0; pt < 2; ++pt) half(pt, full_c);
+        } else {
+          half(0, full_c);
+          half(1, full_c);
+        }
+      };
+      if (full) both(std::true_type{});
+      else both(std::false_type{});
+      __syncthreads();
+      return;
+    }
     f32x16 kinit;
 #pragma unroll
     for (int e = 0; e < 16; ++e) kinit[e] = nm;
@@ -253,27 +320,7 @@ __global__ __launch_bounds__(256, (C == 64 && !PSUM_MFMA) ? 3 : (C == 128 ? 2 : 
         va[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv[kk], va[pt], 0, 0, 0);
       }
     }
-    const int valid = min(kTP, N - t * kTP);
-    const bool full = valid == kTP;                        // wave-uniform: whole tiles skip the 32 per-pixel masks
-    if constexpr (REGOP) {
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          bf16x8 pa, vb;
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            const int r = 8 * i + s2;
-            const int px = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float pv = (full || px < valid) ? __builtin_amdgcn_exp2f(ka[pt][r]) : 0.0f;
-            if constexpr (!PSUM_MFMA) ssum += pv;
-            pa[s2] = (__bf16)pv;
-            vb[s2] = (__bf16)va[pt][r];
-          }
-          ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, ctx, 0, 0, 0);
-          if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ones, psum, 0, 0, 0);
-        }
-    } else {
+    {
       // p and v, transposed to [channel][pixel] so that pixels become the MFMA k index
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
@@ -381,7 +428,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int ntiles = (N + kTP - 1) / kTP;
-  const int tpb = la_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
+  const int tpb = la_out_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
   bf16x8 wq[G::KK];                                    // q rows of head `wave`
   load_wfrags<C>(wq, wqkv, 32 * wave, l31, hi);
   // ctx^T rows e = l31 of head `wave`; k-slot s of half hi in k-step i is d = 16 i + 8 (s >> 2) + 4 hi + (s & 3):
@@ -421,12 +468,13 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
 #pragma unroll
       for (int e = 0; e < 16; ++e) qinit[e] = q0;
     }
-    f32x16 qa[2] = {qinit, qinit};
+    f32x16 qa[2];                                          // (qinit is the first MFMA's C operand: no copies)
 #pragma unroll
     for (int kk = 0; kk < G::KK; ++kk) {
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
-        qa[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[kk], frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk), qa[pt], 0, 0, 0);
+        qa[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[kk], frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk),
+                                                         kk == 0 ? qinit : qa[pt], 0, 0, 0);
     }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -503,13 +551,11 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
         s1 += ya[a][r];
         s2 = fmaf(ya[a][r], ya[a][r], s2);
       }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (hi == 0) {
-        float* dst = lnb + ((ypt[a] * 32 + l31) * RTL + yrt[a]) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
-      }
+      // v_permlane32_swap(s1, s2): lanes 0..31 end up with (s1 lower, s1 upper), lanes 32..63 with (s2 lower, s2 upper), so
+      // one swap and one add leave the pixel's sum in the lower half and its sum of squares in the upper half
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2), false, false);
+      const float tot = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+      lnb[((ypt[a] * 32 + l31) * RTL + yrt[a]) * 2 + hi] = tot;
     }
     __syncthreads();                                                                            // (3) partial sums
 #pragma unroll
@@ -522,7 +568,7 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
         s2 += lnb[(px * RTL + rt) * 2 + 1];
       }
       const float mean = s1 * (1.0f / C);
-      const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.0f) + kLnEps);
+      const float rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * (1.0f / C) - mean * mean, 0.0f) + kLnEps);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int c0 = yrt[a] * 32 + 8 * g4 + 4 * hi;
@@ -889,8 +935,12 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
     if ((rc = set_lds(&la_ctx_fused_kernel<C, true, false, 1>, lds_ctx<C>()))) return rc;
     if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 1>, lds_kmax<C>()))) return rc;
     if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 1>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 2>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 3>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 2>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 3>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 1, true>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 1, true>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 2, true>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 3, true>, lds_kmax<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, false>, lds_out<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, true>, lds_out<C>()))) return rc;
     attr = true;
@@ -909,15 +959,25 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
   // PRG_LA_CTX_REGOP: 1 (default) the context MFMA takes p and v from the accumulator registers; 0 = transposed LDS tiles
   static const int psum_env = [] { const char* e = std::getenv("PRG_LA_PSUM"); return e ? std::atoi(e) : -1; }();
   static const int regop = [] { const char* e = std::getenv("PRG_LA_CTX_REGOP"); return e ? std::atoi(e) : 1; }();
-  const bool psum = psum_env > 0 || (psum_env < 0 && (regop || C >= 128));   // (REGOP + matrix-pipe sum at C = 64: 168 registers, no spill)
+  const bool psum = psum_env > 0 || (psum_env < 0 && C >= 256);   // (C <= 128: the scalar sum keeps the loop inside the 3- / 2-block register budget)
   // PRG_LA_DEPTH: x tiles in flight per block in la_ctx (register-operand + matrix-pipe-sum variant only): 1, 2 or 3
   static const int depth_env = [] { const char* e = std::getenv("PRG_LA_DEPTH"); return e ? std::atoi(e) : 1; }();
-  const int depth = (C <= 128 && regop && psum) ? (C == 128 && depth_env > 2 ? 2 : depth_env) : 1;   // (C = 128 at depth 3 spills)
-  if (regop) {
-    if (psum && depth >= 3) la_ctx_fused_kernel<C, true, true, 3><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
-    else if (psum && depth == 2) la_ctx_fused_kernel<C, true, true, 2><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
-    else if (psum) la_ctx_fused_kernel<C, true, true, 1><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
-    else la_ctx_fused_kernel<C, false, true, 1><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
+  const int depth = (C <= 128 && regop) ? (C == 128 && depth_env > 2 ? 2 : depth_env) : 1;   // (C = 128 at depth 3 spills)
+  // PRG_LA_PTSEQ: the two 32-pixel halves of a tile one after the other (C <= 128, register operands): 0 off, 1 with the
+  // matrix-pipe sum, 2 with the scalar sum
+  static const int ptseq = [] { const char* e = std::getenv("PRG_LA_PTSEQ"); return e ? std::atoi(e) : 0; }();
+#define PRG_LA_CTX_GO(PS, DP, SEQ) la_ctx_fused_kernel<C, PS, true, DP, SEQ><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab)
+  if (regop && ptseq && C <= 128) {
+    if (ptseq == 1) PRG_LA_CTX_GO(true, 1, true);
+    else if (depth >= 3) PRG_LA_CTX_GO(false, 3, true);
+    else if (depth == 2) PRG_LA_CTX_GO(false, 2, true);
+    else PRG_LA_CTX_GO(false, 1, true);
+  } else if (regop) {
+    if (depth >= 3) PRG_LA_CTX_GO(false, 3, false);
+    else if (depth == 2) PRG_LA_CTX_GO(false, 2, false);
+    else if (psum) PRG_LA_CTX_GO(true, 1, false);
+    else PRG_LA_CTX_GO(false, 1, false);
+#undef PRG_LA_CTX_GO
   } else {
     if (psum) la_ctx_fused_kernel<C, true, false, 1><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
     else la_ctx_fused_kernel<C, false, false, 1><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
@@ -926,8 +986,10 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
   la_fin_fused_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctxT, N, nslab);
   PRG_LAUNCH_CHECK();
   // (the q shifts of the four heads follow the 128 k shifts)
-  if (kshift) la_out_fused_kernel<C, true><<<grid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N, kshift + kHid);
-  else la_out_fused_kernel<C, false><<<grid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N, nullptr);
+  const int nt = ceil_div(N, kTP);
+  const dim3 ogrid(ceil_div(nt, la_out_tpb(nt)), B);
+  if (kshift) la_out_fused_kernel<C, true><<<ogrid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N, kshift + kHid);
+  else la_out_fused_kernel<C, false><<<ogrid, 256, lds_out<C>(), s>>>(x, wqkv, wout, bias, out_g, ctxT, out, N, nullptr);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
