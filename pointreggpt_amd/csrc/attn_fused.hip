@@ -26,6 +26,7 @@ namespace prg {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 namespace {
 
@@ -50,7 +51,6 @@ __host__ __device__ inline int la_out_tpb(int ntiles) {         // la_out (pixel
   return t < 1 ? 1 : (t > PRG_LA_OUT_TPB ? PRG_LA_OUT_TPB : t);
 }
 constexpr int kLdO = kHid + 8;       // LDS row stride of 128-wide rows (bf16 elements)
-constexpr int kLdP = kTP + 8;        // LDS row stride of the transposed p / v tiles
 constexpr float kLnEps = 1e-5f;
 
 __device__ inline uint32_t pack2(float a, float b) {
@@ -202,162 +202,89 @@ __global__ __launch_bounds__(256) void la_kmax_fused_kernel(const bf16_t* __rest
 // =====================================================================================================
 // pass 2: per-slab sums of p = exp(k - max) and of p v^T
 // =====================================================================================================
-// PSUM_MFMA: sum_n p on the matrix pipe (16 more registers: C = 64 keeps the float sum and three blocks per CU).
-// REGOP: p and v go into the context MFMA STRAIGHT FROM THE ACCUMULATOR REGISTERS — the contraction index (pixels) may be
-// enumerated in any order as long as both operands use the same one, and lane (column, half hi) of the k / v accumulators
-// holds, in registers 8 i .. 8 i + 7, exactly the eight pixels that A's row / B's column `l31` supplies for k-slots
-// 8 hi .. 8 hi + 7 of k-step i (la_out's trick for q) — no transposed LDS tiles (32 two-way bank-conflicted ds_write_b64 and
-// 8 ds_read_b128 per tile and wave), 37 KB less LDS per block.
-// DEPTH: x tiles in flight per block (register slots; the loop is unrolled by DEPTH so that a slot is a compile-time choice).
-// PTSEQ (with REGOP): the two 32-pixel halves of a tile one after the other (half the accumulator registers).
-template <int C, bool PSUM_MFMA, bool REGOP, int DEPTH, bool PTSEQ = false>
-__global__ __launch_bounds__(256, C == 64 ? ((REGOP || !PSUM_MFMA) ? 3 : 2) : (C == 128 ? 2 : 1)) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
-                                                           const float* __restrict__ pmax, const float* __restrict__ kshift,
-                                                           float* __restrict__ ctxp, float* __restrict__ sump, int N, int nslab) {
+// Both kernels of this file's attention are VALU-ISSUE bound (SQ counters, round 3: per tile and wave ~330 VALU instructions
+// beside 24 MFMAs, VALU issue + matrix-pipe busy cycles ~ the kernel's duration, i.e. they barely overlap; neither occupancy
+// 3 -> 4, nor the slab count, nor a deeper x prefetch moved it), so the loop is written to issue as few VALU instructions
+// as possible:
+//  * p and v go into the context MFMA STRAIGHT FROM THE ACCUMULATOR REGISTERS — the contraction index (pixels) may be
+//    enumerated in any order as long as both operands use the same one, and lane (column, half hi) of the k / v
+//    accumulators holds, in registers 8 i .. 8 i + 7, exactly the eight pixels that A's row / B's column `l31` supplies for
+//    k-slots 8 hi .. 8 hi + 7 of k-step i (la_out's trick for q): no transposed LDS tiles;
+//  * KSTAT (static bound on |k|, <= 57.7 in the log2 units the pre-scaled rows produce — unet.hip): NO shift at all.  The
+//    softmax is shift-invariant, exp2(k) stays inside [2^-58, 2^58], the sums over at most 2^16 pixels inside 2^74, and
+//    bf16 / fp32 relative precision does not depend on the scale: no splat, no subtraction, no maximum pass.  Otherwise
+//    (measured maxima) the shift is the first MFMA's C operand, a loop-invariant register set;
+//  * whole tiles take a branch without the per-pixel masks;
+//  * PSUM_MFMA: sum_n p from the matrix pipe (pT times an all-ones operand: the SAME bf16-rounded p that feeds ctx) instead
+//    of 32 float additions per tile and lane.
+template <int C, bool PSUM_MFMA, bool KSTAT>
+__global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 2 : 1)) void la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+                                                           const float* __restrict__ pmax, float* __restrict__ ctxp,
+                                                           float* __restrict__ sump, int N, int nslab) {
   using G = Geo<C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]
-  __bf16* pv = xn + kTP * G::LDW;                    // per wave: pT [32][kLdP], vT [32][kLdP]
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
-  __bf16* pT = pv + wave * 2 * 32 * kLdP;
-  __bf16* vT = pT + 32 * kLdP;
   const int ntiles = (N + kTP - 1) / kTP;
   const int tpb = la_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
   bf16x8 wk[G::KK], wv[G::KK];                         // k and v rows of head `wave`
   load_wfrags<C>(wk, wqkv, kHid + 32 * wave, l31, hi);
   load_wfrags<C>(wv, wqkv, 2 * kHid + 32 * wave, l31, hi);
-  // Shift of the softmax over pixels (any shift gives the same softmax): either the static bound of this column,
-  // |k[n][d]| <= ||w_d|| sqrt(C) because a LayerNorm output has norm <= sqrt(C) (computed once at weight load; used when
-  // it is small enough that exp(k - bound) cannot underflow: no extra pass over x), or the measured column maximum
-  // (fixed-order reduce of la_kmax's slab maxima).
-  float m;
-  if (kshift) {
-    m = kshift[32 * wave + l31];
-  } else {
-    m = -INFINITY;
+  f32x16 kinit0 = zero16();                            // the k accumulators' initial value: minus the column maximum
+  if constexpr (!KSTAT) {
+    float m = -INFINITY;                               // (fixed-order reduce of la_kmax's slab maxima)
     for (int s2 = 0; s2 < nslab; ++s2) m = fmaxf(m, pmax[((size_t)b * nslab + s2) * kHid + 32 * wave + l31]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) kinit0[e] = -m;
   }
   f32x16 ctx = zero16();                               // rows d, column e = l31 of head `wave`
-  // Round 3: the shift is the k accumulators' initial value (one splat instead of 64 subtractions per tile and lane), and
-  // sum_n p comes out of the matrix pipe — pT times an all-ones B operand, every column of `psum` = the row sums of the SAME
-  // bf16-rounded p that feeds ctx — instead of 64 float additions per tile and lane.
-  float nm = -m;
   f32x16 psum = zero16();                              // rows d (any column)
   float ssum = 0.0f;
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  f32x16 kinit0;                                       // (REGOP) the k accumulators' initial value, loop-invariant
-#pragma unroll
-  for (int e = 0; e < 16; ++e) kinit0[e] = nm;
-  XTile<C> xs[DEPTH];
-#pragma unroll
-  for (int dd = 0; dd < DEPTH; ++dd)
-    if (t0 + dd < t1) xs[dd].load(x, (int64_t)b * N + (int64_t)(t0 + dd) * kTP, min(kTP, N - (t0 + dd) * kTP));
-  auto tile = [&](XTile<C>& xt, const int t) {
-    if constexpr (DEPTH > 1) __builtin_amdgcn_sched_barrier(0);   // (tiles stay apart: interleaving two of them doubles the live accumulators)
+  XTile<C> xt;
+  if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
+  for (int t = t0; t < t1; ++t) {
     xt.normalize_to(xn);
     __syncthreads();
-    if (t + DEPTH < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + DEPTH) * kTP, min(kTP, N - (t + DEPTH) * kTP));
+    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
     const int valid = min(kTP, N - t * kTP);
-    const bool full = valid == kTP;                        // wave-uniform: whole tiles take the branch without the per-pixel masks
-    if constexpr (REGOP) {
-      // One 32-pixel half: k = x Wk^T - shift and v = x Wv^T on the matrix pipe (the shift is the first MFMA's C operand, a
-      // loop-invariant register set: no splat and no subtraction per tile), p = exp2(k), then ctx += p^T v with p and v
-      // taken straight from the accumulator registers.  FULL tiles carry no masks (the loop is VALU-bound: per tile and
-      // wave the masks were ~100 of ~330 VALU instructions).
-      auto half = [&](const int pt, auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
-        f32x16 k1, v1;
+    // one 32-pixel half: k = x Wk^T (- shift) and v = x Wv^T, p = exp2(k), ctx += p^T v
+    auto half = [&](const int pt, auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      f32x16 k1, v1;
 #pragma unroll
-        for (int kk = 0; kk < G::KK; ++kk) {
-          const bf16x8 xf = frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk);
-          k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wk[kk], kk == 0 ? kinit0 : k1, 0, 0, 0);
-          v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv[kk], kk == 0 ? zero16() : v1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          bf16x8 pa, vb;
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            const int r = 8 * i + s2;
-            float pe = __builtin_amdgcn_exp2f(k1[r]);
-            if constexpr (!FULL) pe = (pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) < valid ? pe : 0.0f;
-            if constexpr (!PSUM_MFMA) ssum += pe;
-            pa[s2] = (__bf16)pe;
-            vb[s2] = (__bf16)v1[r];
-          }
-          ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, ctx, 0, 0, 0);
-          if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ones, psum, 0, 0, 0);
-        }
-      };
-      auto both = [&](auto full_c) {
-        if constexpr (PTSEQ) {
-          // one half after the other: 32 accumulator registers live instead of 64
-#pragma unroll 1
-          for (int pt = 0; pt < 2; ++pt) half(pt, full_c);
-        } else {
-          half(0, full_c);
-          half(1, full_c);
-        }
-      };
-      if (full) both(std::true_type{});
-      else both(std::false_type{});
-      __syncthreads();
-      return;
-    }
-    f32x16 kinit;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) kinit[e] = nm;
-    f32x16 ka[2] = {kinit, kinit}, va[2] = {zero16(), zero16()};
-#pragma unroll
-    for (int kk = 0; kk < G::KK; ++kk) {
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
+      for (int kk = 0; kk < G::KK; ++kk) {
         const bf16x8 xf = frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk);
-        ka[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wk[kk], ka[pt], 0, 0, 0);
-        va[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv[kk], va[pt], 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wk[kk], kk == 0 ? (KSTAT ? zero16() : kinit0) : k1, 0, 0, 0);
+        v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wv[kk], kk == 0 ? zero16() : v1, 0, 0, 0);
       }
-    }
-    {
-      // p and v, transposed to [channel][pixel] so that pixels become the MFMA k index
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 pa, vb;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int px0 = pt * 32 + 8 * g4 + 4 * hi;
-          float p[4];
-          if (full) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p[j] = px0 + j < valid ? __builtin_amdgcn_exp2f(ka[pt][4 * g4 + j]) : 0.0f;
-          }
-          if constexpr (!PSUM_MFMA) ssum += (p[0] + p[1]) + (p[2] + p[3]);
-          uint2 pw, vw;
-          pw.x = pack2(p[0], p[1]);
-          pw.y = pack2(p[2], p[3]);
-          vw.x = pack2(va[pt][4 * g4], va[pt][4 * g4 + 1]);
-          vw.y = pack2(va[pt][4 * g4 + 2], va[pt][4 * g4 + 3]);
-          *reinterpret_cast<uint2*>(pT + l31 * kLdP + px0) = pw;
-          *reinterpret_cast<uint2*>(vT + l31 * kLdP + px0) = vw;
+        for (int s2 = 0; s2 < 8; ++s2) {
+          const int r = 8 * i + s2;
+          float pe = __builtin_amdgcn_exp2f(k1[r]);
+          if constexpr (!FULL) pe = (pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) < valid ? pe : 0.0f;
+          if constexpr (!PSUM_MFMA) ssum += pe;
+          pa[s2] = (__bf16)pe;
+          vb[s2] = (__bf16)v1[r];
         }
-      // ctx[d][e] += sum_px p[px][d] v[px][e]   (same wave wrote the tiles: LDS operations of a wave stay in order)
-#pragma unroll
-      for (int kk = 0; kk < kTP / 16; ++kk) {
-        const bf16x8 pf = frag(pT, kLdP, l31, hi, kk);
-        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag(vT, kLdP, l31, hi, kk), ctx, 0, 0, 0);
-        if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ones, psum, 0, 0, 0);
+        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, ctx, 0, 0, 0);
+        if constexpr (PSUM_MFMA) psum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, ones, psum, 0, 0, 0);
       }
+    };
+    if (valid == kTP) {                                // (wave-uniform)
+      half(0, std::true_type{});
+      half(1, std::true_type{});
+    } else {
+      half(0, std::false_type{});
+      half(1, std::false_type{});
     }
     __syncthreads();
-  };
-  for (int t = t0; t < t1; t += DEPTH) {
-#pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd)
-      if (t + dd < t1) tile(xs[dd], t + dd);
   }
   const size_t ph = ((size_t)b * 4 + wave) * nslab + slab;
   if constexpr (PSUM_MFMA) {
@@ -411,8 +338,8 @@ __global__ __launch_bounds__(256) void la_fin_fused_kernel(const float* __restri
 // =====================================================================================================
 // pass 4: q, softmax over d, ctx^T q, to_out conv + bias, LayerNorm, residual
 // =====================================================================================================
-template <int C, bool QSTAT>   // QSTAT: static softmax shift of q (qshift != null)
-__global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
+template <int C, bool QSTAT>   // QSTAT: static bound on |q| (qshift != null is the flag; the value itself is not needed)
+__global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 2 : 1)) void la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wqkv,
                                                            const bf16_t* __restrict__ wout, const float* __restrict__ bias,
                                                            const float* __restrict__ out_g, const bf16_t* __restrict__ ctxT,
                                                            bf16_t* __restrict__ out, int N, const float* __restrict__ qshift) {
@@ -422,9 +349,11 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   constexpr int NR = RT > 4 ? RT / 4 : 1;    // distinct row tiles per wave (C = 256: two, each with both pixel tiles)
   constexpr int RTL = RT > 4 ? RT : 4;       // row-tile pitch of the LayerNorm partial sums
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]   (later: the normalised y tile)
+  __bf16* xn = reinterpret_cast<__bf16*>(smem);      // [64][LDW]
   __bf16* ot = xn + kTP * G::LDW;                    // [64][kLdO]  attention output, pixel-major
   float* lnb = reinterpret_cast<float*>(ot + kTP * kLdO);   // [64][4][2] LayerNorm partial sums
+  __bf16* yt = reinterpret_cast<__bf16*>(lnb + kTP * RTL * 2);   // [64][LDW] the normalised y tile (its own buffer: no barrier
+                                                             // between a tile's last phase and the next tile's LayerNorm)
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int ntiles = (N + kTP - 1) / kTP;
@@ -448,33 +377,25 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
   bf16x8 wo[NR][kHid / 16];                            // to_out rows of this wave's y row tile(s)
 #pragma unroll
   for (int r = 0; r < NR; ++r) load_wfrags<kHid>(wo[r], wout, yrt[RT > 4 ? 2 * r : 0] * 32, l31, hi);
-  const float nq = QSTAT ? -qshift[wave] : 0.0f;
   XTile<C> xt;
   if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP, min(kTP, N - t0 * kTP));
   for (int t = t0; t < t1; ++t) {
+    asm volatile("" ::: "memory");                     // (bias / out_g stay loads inside the loop: hoisted they cost 32 registers and a block per CU)
     const XTile<C> xraw = xt;                          // residual
     const int valid = min(kTP, N - t * kTP);
     xt.normalize_to(xn);
     __syncthreads();                                                                            // (1) xn ready
     if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP, min(kTP, N - (t + 1) * kTP));
-    // q^T[d][px] of head `wave`.  Static shift (round 3): the softmax over d is shift-invariant and |q| <= qs (the bound of
-    // la_ctx's k shift, taken over the head's 32 rows), so -qs is the accumulators' initial value and exp2 cannot overflow
-    // or lose every term (exp2(q - qs) >= 2^-2qs with qs <= 57); no maximum, no subtraction.
+    // q^T[d][px] of head `wave`.  QSTAT (static bound |q| <= 57.7, see la_ctx's KSTAT): the softmax over d is
+    // shift-invariant and exp2(q) stays inside [2^-58, 2^58], so there is no maximum, no shift and no subtraction.
     constexpr bool qstat = QSTAT;
-    f32x16 qinit;
-    {
-      float q0 = QSTAT ? nq : 0.0f;
-      asm volatile("" : "+v"(q0));                         // (no 16-register splat live across the tile loop)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) qinit[e] = q0;
-    }
-    f32x16 qa[2];                                          // (qinit is the first MFMA's C operand: no copies)
+    f32x16 qa[2];
 #pragma unroll
     for (int kk = 0; kk < G::KK; ++kk) {
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
         qa[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[kk], frag(xn + pt * 32 * G::LDW, G::LDW, l31, hi, kk),
-                                                         kk == 0 ? qinit : qa[pt], 0, 0, 0);
+                                                         kk == 0 ? zero16() : qa[pt], 0, 0, 0);
     }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -495,8 +416,13 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
           sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, qb, sa, 0, 0, 0);
         }
         const float inv = __builtin_amdgcn_rcpf(sa[0]);
+        const f32x2 inv2 = {inv, inv};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oa[r] *= inv;
+        for (int r = 0; r < 16; r += 2) {                  // (v_pk_mul_f32)
+          const f32x2 o2 = f32x2{oa[r], oa[r + 1]} * inv2;
+          oa[r] = o2[0];
+          oa[r + 1] = o2[1];
+        }
       } else {
         // measured maximum (blocks whose static bound is too large): softmax over the 32 d of pixel pt*32 + l31, 16 in this
         // lane, 16 in lane ^ 32
@@ -576,16 +502,16 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
         uint2 w;
         w.x = pack2((ya[a][4 * g4] - mean) * rstd * gg.x, (ya[a][4 * g4 + 1] - mean) * rstd * gg.y);
         w.y = pack2((ya[a][4 * g4 + 2] - mean) * rstd * gg.z, (ya[a][4 * g4 + 3] - mean) * rstd * gg.w);
-        *reinterpret_cast<uint2*>(xn + px * G::LDW + c0) = w;
+        *reinterpret_cast<uint2*>(yt + px * G::LDW + c0) = w;
       }
     }
-    __syncthreads();                                                                            // (4) y tile in xn
+    __syncthreads();                                                                            // (4) y tile ready
     {
       const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
       if (row < valid) {
 #pragma unroll
         for (int i = 0; i < G::VPT; ++i) {
-          const uint4 yv = *reinterpret_cast<const uint4*>(xn + row * G::LDW + (part + 4 * i) * 8);
+          const uint4 yv = *reinterpret_cast<const uint4*>(yt + row * G::LDW + (part + 4 * i) * 8);
           const uint4 xv = xraw.v[i];
           uint4 o;
           o.x = pack2(bf_lo(yv.x) + bf_lo(xv.x), bf_hi(yv.x) + bf_hi(xv.x));
@@ -596,7 +522,6 @@ __global__ __launch_bounds__(256) void la_out_fused_kernel(const bf16_t* __restr
         }
       }
     }
-    __syncthreads();                                                                            // (5) xn free again
   }
 }
 
@@ -756,9 +681,7 @@ __global__ __launch_bounds__(256) void full_attn_mfma_big_kernel(const bf16_t* _
 template <int C>
 size_t lds_kmax() { return (size_t)kTP * Geo<C>::LDW * 2; }
 template <int C>
-size_t lds_ctx() { return (size_t)kTP * Geo<C>::LDW * 2 + (size_t)4 * 2 * 32 * kLdP * 2; }
-template <int C>
-size_t lds_out() { return (size_t)kTP * Geo<C>::LDW * 2 + (size_t)kTP * kLdO * 2 + (size_t)kTP * (C / 32 > 4 ? C / 32 : 4) * 2 * 4; }
+size_t lds_out() { return (size_t)2 * kTP * Geo<C>::LDW * 2 + (size_t)kTP * kLdO * 2 + (size_t)kTP * (C / 32 > 4 ? C / 32 : 4) * 2 * 4; }
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
@@ -925,22 +848,19 @@ int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* 
 
 
 template <int C>
+constexpr bool kPsumDefault = C >= 128;   // (measured: C = 64 58 against 70 us with it, C = 128 21.4 against 22.8, C = 256 23.7 against 25.6)
+
+template <int C>
 int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias, const float* out_g, bf16_t* out,
              float* ws, int B, int N, const float* kshift, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     int rc;
     if ((rc = set_lds(&la_kmax_fused_kernel<C>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, false, 1>, lds_ctx<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, false, 1>, lds_ctx<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 1>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 1>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 2>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 3>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true, 1, true>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 1, true>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 2, true>, lds_kmax<C>()))) return rc;
-    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true, 3, true>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, false>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, false, true>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, false>, lds_kmax<C>()))) return rc;
+    if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true>, lds_kmax<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, false>, lds_out<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, true>, lds_out<C>()))) return rc;
     attr = true;
@@ -955,33 +875,13 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
     la_kmax_fused_kernel<C><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, N, nslab);
     PRG_LAUNCH_CHECK();
   }
-  // PRG_LA_PSUM: -1 (default) the matrix-pipe sum where it costs no occupancy (every width with REGOP, C >= 128 without), 0 never, 1 always
-  // PRG_LA_CTX_REGOP: 1 (default) the context MFMA takes p and v from the accumulator registers; 0 = transposed LDS tiles
+  // PRG_LA_PSUM: sum_n p on the matrix pipe: -1 (default) where measured faster, 0 never, 1 always
   static const int psum_env = [] { const char* e = std::getenv("PRG_LA_PSUM"); return e ? std::atoi(e) : -1; }();
-  static const int regop = [] { const char* e = std::getenv("PRG_LA_CTX_REGOP"); return e ? std::atoi(e) : 1; }();
-  const bool psum = psum_env > 0 || (psum_env < 0 && C >= 256);   // (C <= 128: the scalar sum keeps the loop inside the 3- / 2-block register budget)
-  // PRG_LA_DEPTH: x tiles in flight per block in la_ctx (register-operand + matrix-pipe-sum variant only): 1, 2 or 3
-  static const int depth_env = [] { const char* e = std::getenv("PRG_LA_DEPTH"); return e ? std::atoi(e) : 1; }();
-  const int depth = (C <= 128 && regop) ? (C == 128 && depth_env > 2 ? 2 : depth_env) : 1;   // (C = 128 at depth 3 spills)
-  // PRG_LA_PTSEQ: the two 32-pixel halves of a tile one after the other (C <= 128, register operands): 0 off, 1 with the
-  // matrix-pipe sum, 2 with the scalar sum
-  static const int ptseq = [] { const char* e = std::getenv("PRG_LA_PTSEQ"); return e ? std::atoi(e) : 0; }();
-#define PRG_LA_CTX_GO(PS, DP, SEQ) la_ctx_fused_kernel<C, PS, true, DP, SEQ><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab)
-  if (regop && ptseq && C <= 128) {
-    if (ptseq == 1) PRG_LA_CTX_GO(true, 1, true);
-    else if (depth >= 3) PRG_LA_CTX_GO(false, 3, true);
-    else if (depth == 2) PRG_LA_CTX_GO(false, 2, true);
-    else PRG_LA_CTX_GO(false, 1, true);
-  } else if (regop) {
-    if (depth >= 3) PRG_LA_CTX_GO(false, 3, false);
-    else if (depth == 2) PRG_LA_CTX_GO(false, 2, false);
-    else if (psum) PRG_LA_CTX_GO(true, 1, false);
-    else PRG_LA_CTX_GO(false, 1, false);
+  const bool psum = psum_env > 0 || (psum_env < 0 && kPsumDefault<C>);
+#define PRG_LA_CTX_GO(PS, KS) la_ctx_fused_kernel<C, PS, KS><<<grid, 256, lds_kmax<C>(), s>>>(x, wqkv, pmax, ctxp, sump, N, nslab)
+  if (kshift) { if (psum) PRG_LA_CTX_GO(true, true); else PRG_LA_CTX_GO(false, true); }
+  else { if (psum) PRG_LA_CTX_GO(true, false); else PRG_LA_CTX_GO(false, false); }
 #undef PRG_LA_CTX_GO
-  } else {
-    if (psum) la_ctx_fused_kernel<C, true, false, 1><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
-    else la_ctx_fused_kernel<C, false, false, 1><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv, pmax, kshift, ctxp, sump, N, nslab);
-  }
   PRG_LAUNCH_CHECK();
   la_fin_fused_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, ctxT, N, nslab);
   PRG_LAUNCH_CHECK();

@@ -247,8 +247,8 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                 # GroupNorm statistics as per-tile slabs + gn_coeff launches (rounds 1-2) instead of the fixed-point accumulators
                 # folded by the consumers (round 3)
                 "no_gn_acc": {"PRG_GN_ACC": "0"},
-                # la_ctx with p / v through transposed LDS tiles (rounds 1-2) instead of straight from the accumulator registers
-                "la_ctx_lds": {"PRG_LA_CTX_REGOP": "0"},
+                # sum_n p of la_ctx on the matrix pipe at every width / as float additions at every width
+                "la_psum": {"PRG_LA_PSUM": "1"}, "la_ssum": {"PRG_LA_PSUM": "0"},
                 # ... and the accumulators with every eligible shape on the 256-pixel kernel (its in-kernel fold at every width)
                 "gn_acc_w256_all": {"PRG_W256_MIN_TILES": "1", "PRG_GN_ACC": "1"}}
     for name, env in variants.items():
@@ -259,7 +259,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
     for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256", "no_res_epilogue", "no_head_fuse",
-                 "no_gn_acc", "gn_acc_w256_all", "la_ctx_lds"):
+                 "no_gn_acc", "gn_acc_w256_all", "la_psum", "la_ssum"):
         for k in ("y64", "y128", "y40", "y96"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()
