@@ -836,26 +836,67 @@ __device__ inline float act_apply(float v, int act) {
   return v;
 }
 
-__global__ void linear_kernel(const float* __restrict__ x, int ldx, int xoff, const float* __restrict__ W, int ldw,
-                              int woff, const float* __restrict__ bias, float* __restrict__ y, int ldy, int R, int I,
-                              int O, int act_in, int act_out) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)R * O) return;
-  const int r = (int)(idx / O), o = (int)(idx - (int64_t)r * O);
-  const float* xr = x + (size_t)r * ldx + xoff;
-  const float* wr = W + (size_t)o * ldw + woff;
-  double accd = 0.0;                         // tiny conditioning MLPs: float64 sum, one rounding
-  for (int i = 0; i < I; ++i) accd += (double)act_apply(xr[i], act_in) * (double)wr[i];
-  float acc = (float)accd;
-  if (bias) acc += bias[o];
-  y[(size_t)r * ldy + o] = act_apply(acc, act_out);
+// y[r][o] = act_out(sum_i act_in(x[r][i]) W[o][i] + bias[o]).  Lane = row r (64 rows per block), wave = 4 outputs, the sum
+// runs over i IN ORDER in float64 (one rounding at the end: every (r, o) is the same serial sum whatever the launch
+// shape).  x goes through LDS transposed ([i][r]: the activation is applied once per element and block, every lane reads
+// its own bank), W[o][i] is wave-uniform: scalar loads.  (Round 1-2's one-thread-per-output kernel read W with a stride
+// of one row per lane and re-applied the activation O times: 65-86 us per call against ~5.)
+constexpr int kLinRows = 64, kLinChunk = 64, kLinOutPerWave = 4;
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, int xoff, const float* __restrict__ W, int ldw,
+                                                     int woff, const float* __restrict__ bias, float* __restrict__ y, int ldy, int R, int I,
+                                                     int O, int act_in, int act_out) {
+  __shared__ float xs[kLinChunk][kLinRows + 1];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r0 = blockIdx.y * kLinRows, r = r0 + lane;
+  const int o0 = (blockIdx.x * 4 + wave) * kLinOutPerWave;
+  double acc[kLinOutPerWave];
+#pragma unroll
+  for (int j = 0; j < kLinOutPerWave; ++j) acc[j] = 0.0;
+  for (int i0 = 0; i0 < I; i0 += kLinChunk) {
+    __syncthreads();
+    // 64 rows x 64 columns: thread t loads column t & 63 of rows t >> 6, + 4, ... (coalesced along i)
+    for (int rr = threadIdx.x >> 6; rr < kLinRows; rr += 4) {
+      const int ii = i0 + lane;
+      float v = 0.0f;
+      if (r0 + rr < R && ii < I) v = act_apply(x[(size_t)(r0 + rr) * ldx + xoff + ii], act_in);
+      xs[lane][rr] = v;
+    }
+    __syncthreads();
+    const int n = min(kLinChunk, I - i0);
+    const float* wr[kLinOutPerWave];
+#pragma unroll
+    for (int j = 0; j < kLinOutPerWave; ++j)             // (wave-uniform; outputs past O recompute the last one and are not stored)
+      wr[j] = W + (size_t)min(o0 + j, O - 1) * ldw + woff + i0;
+    auto step = [&](const int i) {
+      const double xv = (double)xs[i][lane];
+#pragma unroll
+      for (int j = 0; j < kLinOutPerWave; ++j) acc[j] += xv * (double)wr[j][i];
+    };
+    if (n == kLinChunk) {
+#pragma unroll 16
+      for (int i = 0; i < kLinChunk; ++i) step(i);       // (unrolled: the scalar loads of 16 steps are in flight together)
+    } else {
+      for (int i = 0; i < n; ++i) step(i);
+    }
+  }
+  if (r < R) {
+#pragma unroll
+    for (int j = 0; j < kLinOutPerWave; ++j) {
+      const int o = o0 + j;
+      if (o < O) {
+        float a = (float)acc[j];
+        if (bias) a += bias[o];
+        y[(size_t)r * ldy + o] = act_apply(a, act_out);
+      }
+    }
+  }
 }
 
 int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, int woff, const float* bias, float* y,
                   int ldy, int R, int I, int O, int act_in, int act_out, hipStream_t s) {
   PRG_CHECK(x && W && y && R > 0 && I > 0 && O > 0, "linear: bad arguments");
-  linear_kernel<<<ceil_div((int64_t)R * O, 256), 256, 0, s>>>(x, ldx, xoff, W, ldw, woff, bias, y, ldy, R, I, O, act_in,
-                                                             act_out);
+  const dim3 grid(ceil_div(O, 4 * kLinOutPerWave), ceil_div(R, kLinRows));
+  linear_kernel<<<grid, 256, 0, s>>>(x, ldx, xoff, W, ldw, woff, bias, y, ldy, R, I, O, act_in, act_out);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
