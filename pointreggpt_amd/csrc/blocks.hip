@@ -841,11 +841,12 @@ __device__ inline float act_apply(float v, int act) {
 // shape).  x goes through LDS transposed ([i][r]: the activation is applied once per element and block, every lane reads
 // its own bank), W[o][i] is wave-uniform: scalar loads.  (Round 1-2's one-thread-per-output kernel read W with a stride
 // of one row per lane and re-applied the activation O times: 65-86 us per call against ~5.)
-constexpr int kLinRows = 64, kLinChunk = 64, kLinOutPerWave = 4;
+constexpr int kLinRows = 64, kLinChunk = 256, kLinOutPerWave = 2;   // (one LDS fill for I <= 256: 66.5 KB)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, int xoff, const float* __restrict__ W, int ldw,
                                                      int woff, const float* __restrict__ bias, float* __restrict__ y, int ldy, int R, int I,
                                                      int O, int act_in, int act_out) {
-  __shared__ float xs[kLinChunk][kLinRows + 1];
+  extern __shared__ float lin_smem[];
+  float (*xs)[kLinRows + 1] = reinterpret_cast<float (*)[kLinRows + 1]>(lin_smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r0 = blockIdx.y * kLinRows, r = r0 + lane;
   const int o0 = (blockIdx.x * 4 + wave) * kLinOutPerWave;
@@ -854,15 +855,17 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   for (int j = 0; j < kLinOutPerWave; ++j) acc[j] = 0.0;
   for (int i0 = 0; i0 < I; i0 += kLinChunk) {
     __syncthreads();
-    // 64 rows x 64 columns: thread t loads column t & 63 of rows t >> 6, + 4, ... (coalesced along i)
-    for (int rr = threadIdx.x >> 6; rr < kLinRows; rr += 4) {
-      const int ii = i0 + lane;
-      float v = 0.0f;
-      if (r0 + rr < R && ii < I) v = act_apply(x[(size_t)(r0 + rr) * ldx + xoff + ii], act_in);
-      xs[lane][rr] = v;
-    }
-    __syncthreads();
+    // 64 rows x up to 256 columns: thread t loads columns (t & 63) + 64 c of rows t >> 6, + 4, ... (coalesced along i)
     const int n = min(kLinChunk, I - i0);
+    for (int c0 = 0; c0 < n; c0 += 64)
+#pragma unroll 4
+      for (int rr = threadIdx.x >> 6; rr < kLinRows; rr += 4) {
+        const int ic = c0 + lane;
+        float v = 0.0f;
+        if (r0 + rr < R && ic < n) v = act_apply(x[(size_t)(r0 + rr) * ldx + xoff + i0 + ic], act_in);
+        if (ic < kLinChunk) xs[ic][rr] = v;
+      }
+    __syncthreads();
     const float* wr[kLinOutPerWave];
 #pragma unroll
     for (int j = 0; j < kLinOutPerWave; ++j)             // (wave-uniform; outputs past O recompute the last one and are not stored)
@@ -872,12 +875,11 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 #pragma unroll
       for (int j = 0; j < kLinOutPerWave; ++j) acc[j] += xv * (double)wr[j][i];
     };
-    if (n == kLinChunk) {
-#pragma unroll 16
-      for (int i = 0; i < kLinChunk; ++i) step(i);       // (unrolled: the scalar loads of 16 steps are in flight together)
-    } else {
-      for (int i = 0; i < n; ++i) step(i);
-    }
+    int i = 0;
+    for (; i + 16 <= n; i += 16)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) step(i + u);          // (unrolled: the scalar loads of 16 steps are in flight together)
+    for (; i < n; ++i) step(i);
   }
   if (r < R) {
 #pragma unroll
@@ -892,11 +894,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   }
 }
 
+constexpr size_t kLinSmem = sizeof(float) * kLinChunk * (kLinRows + 1);
+
 int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, int woff, const float* bias, float* y,
                   int ldy, int R, int I, int O, int act_in, int act_out, hipStream_t s) {
   PRG_CHECK(x && W && y && R > 0 && I > 0 && O > 0, "linear: bad arguments");
   const dim3 grid(ceil_div(O, 4 * kLinOutPerWave), ceil_div(R, kLinRows));
-  linear_kernel<<<grid, 256, 0, s>>>(x, ldx, xoff, W, ldw, woff, bias, y, ldy, R, I, O, act_in, act_out);
+  static bool attr = false;
+  if (!attr) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinSmem));
+    attr = true;
+  }
+  linear_kernel<<<grid, 256, kLinSmem, s>>>(x, ldx, xoff, W, ldw, woff, bias, y, ldy, R, I, O, act_in, act_out);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
