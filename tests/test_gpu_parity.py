@@ -277,8 +277,20 @@ def test_unet_vs_oracle_odd_batch_and_size(hip):
     t = torch.tensor([0, 417, 999])
     pc = torch.tensor([[56.8, 57.0, 24.4, 24.0]] * 3) + torch.randn((3, 4), generator=g)
     ref = OU.unet_forward(sd, x, t, pc)
-    y = hip.Unet(16, dtype="fp32").load_state_dict(sd)(x.cuda(), t.cuda(), pc.cuda())
+    net = hip.Unet(16, dtype="fp32").load_state_dict(sd)
+    y = net(x.cuda(), t.cuda(), pc.cuda())
     assert maxerr(y, ref.numpy()) <= FP32_TOL
+    # B = 67 at 32x32: more batch rows than one 64-row block of the conditioning Linear kernel, every image its own timestep
+    B = 67
+    x = torch.randn((B, 1, 32, 32), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    pc = torch.tensor([[37.9, 38.0, 16.2, 16.0]] * B) + torch.randn((B, 4), generator=g)
+    ref = OU.unet_forward(sd, x, t, pc)
+    y = net(x.cuda(), t.cuda(), pc.cuda())
+    assert maxerr(y, ref.numpy()) <= FP32_TOL
+    for b in (0, 63, 64, 66):                                # batch-slot invariance across the row-block boundary
+        yb = net(x[b:b + 1].cuda(), t[b:b + 1].cuda(), pc[b:b + 1].cuda())
+        assert torch.equal(yb.cpu(), y[b:b + 1].cpu()), b
 
 
 @pytest.mark.parametrize("dim", [8, 16])
