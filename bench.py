@@ -352,12 +352,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a HIP device (the product has no CPU path)", file=sys.stderr)
         sys.exit(2)
+    # one rank per GPU (the driver's launch).  PRG_BENCH_BACKEND=gloo is a rehearsal aid for boxes with fewer GPUs than ranks:
+    # the ranks then share devices (local rank modulo the device count) and the barrier / MAX reduction run on the host.
+    backend = os.environ.get("PRG_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = torch.device("cpu") if backend == "gloo" else torch.device("cuda", local)
 
     from pointreggpt_amd import geometry as G
     from pointreggpt_amd import synthetic
@@ -458,7 +463,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -541,7 +546,7 @@ def main():
         e2e = e2e_files(a, unet, mask, diff, rank, world, B, S, lanes=[(pp["diff"], pp["mask"]) for pp in pipes[1:]])
         dt_e = e2e["seconds"]
         if dist is not None:
-            tt = torch.tensor([dt_e], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt_e], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_e = float(tt.item())
         e2e.update(value=world * e2e["pairs"] / dt_e, unit="pairs/s on disk (whole job)", seconds_max_over_ranks=dt_e,
@@ -549,11 +554,13 @@ def main():
                    what="Generator.generate --synthetic: memory-cloud z-buffer + MaskUnet + sampler + MaskUnet + unprojection + "
                         "crop / 0.025 voxel grid / PLY + PNG + text files through the C++ writer pool, overlapped with the next batch")
         res["e2e_files"] = e2e
-    if rank == 0 and not a.no_drift and a.dim == 64:
+    # the single-GPU diagnostics (drift against the fixtures, the configs[4] leg, the CPU baseline) belong to the N = 1 line
+    # only: at N > 1 the other ranks would sit in the closing barrier while rank 0 runs them
+    if rank == 0 and world == 1 and not a.no_drift and a.dim == 64:
         res["drift_vs_reference"] = drift_vs_reference([a.dtype] if a.dtype == "mxfp8" else [a.dtype, "mxfp8"], a.dim)
-    if rank == 0 and not a.no_configs4 and not a.sampler_only:
+    if rank == 0 and world == 1 and not a.no_configs4 and not a.sampler_only:
         res["configs4"] = configs4_leg(a, G, synthetic, rank)
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(S, a.dim)
 
     if rank == 0:
