@@ -5,8 +5,8 @@
 // written once and read three times, the 128-channel attention output, the to_out result): it is HBM-bound at 8x the
 // bytes the block needs.  Here every pass re-reads only x (C channels per pixel) and recomputes what it needs with MFMA:
 //
-//   la_kmax   x -> LayerNorm -> k = Wk x^        column maxima per slab            (softmax over pixels needs max_n k)
-//   la_ctx    x -> LayerNorm -> k, v             p = exp(k - max);  sum_n p,  ctx[d][e] += p[n][d] v[n][e]   per slab
+//   la_kmax   x -> LayerNorm -> k = Wk x^        column maxima per slab   (only when the static bound on |k| does not hold)
+//   la_ctx    x -> LayerNorm -> k, v             p = exp(k [- max]);  sum_n p,  ctx[d][e] += p[n][d] v[n][e]   per slab
 //   la_fin    slabs summed in fixed order, ctx / sum / N * 32^-1/2 -> bf16, stored in the k-slot order la_out's MFMA wants
 //   la_out    x -> LayerNorm -> q -> softmax_d -> out = ctx^T q -> y = Wout out + b -> LayerNorm -> + x     -> store
 //
@@ -36,6 +36,8 @@ constexpr int kTilesPerBlock = 8;
 // Linear attention: tiles per block as a function of the image size ONLY (a batch-independent slab structure keeps a
 // scene's result identical for every batch size): 8 from 64 x 64 pixels up, fewer for the small levels, whose launches
 // otherwise fill a quarter of the CUs with blocks that walk four tiles in series (16 x 16: 64 blocks -> 256).
+// (compile-time overrides for A/B builds; measured round 3: 16 or 32 tiles per la_ctx block 73-75 against 72 us, 4 or 16 per
+// la_out block 105-108 against 99 us)
 #ifndef PRG_LA_CTX_TPB
 #define PRG_LA_CTX_TPB 8
 #endif
