@@ -332,13 +332,32 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     const int slot = ptid & 7, row = ptid >> 3;           // 16-byte unit of a 128-byte pixel row; halo rows row + 32 k
     char* const ah = smem + row * ROWB + slot * 16;
     const int Hl = d.Hout, Wl = d.Wout;
-    int hy[KU], hx[KU];                                    // tile-independent halo geometry of this thread's units
+    // Tile-independent halo geometry of this thread's units (round 3: the per-tile address arithmetic was ~27 VALU
+    // instructions per unit — as many per tile as the consumers' whole epilogue).  Unit k sits at a fixed byte offset from
+    // the tile's halo origin, and whether it is padding depends only on which image edges the tile touches: five bit masks
+    // per thread, one AND-NOT per edge and tile.  The loads are raw BUFFER loads from a descriptor whose base lies one halo
+    // row + one pixel before the tensor: every in-image unit has a non-negative offset, a padding unit gets offset
+    // 0xffffffff and the hardware's range check returns zeros — no clamped stand-in address, no select after the load.
+    int voffk[KU];
+    unsigned m_valid = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
 #pragma unroll
     for (int k = 0; k < KU; ++k) {
       const int hp = k * RPP + row;
-      hy[k] = hp / HP;
-      hx[k] = hp - hy[k] * HP;
+      const int hy = hp / HP, hx = hp - hy * HP;
+      const bool valid = hp < HALO;
+      // (tile origins are multiples of 8 / 32: (y0 - 1 + hy) >> ups = (y0 >> ups) + ((hy - 1) >> ups), arithmetic shift)
+      const int dy = (hy - 1) >> d.ups, dx = (hx - 1) >> d.ups;
+      voffk[k] = ((dy + 1) * d.Win + dx + 1) * 128 + slot * 16;
+      m_valid |= (valid ? 1u : 0u) << k;
+      m_top |= (valid && hy == 0 ? 1u : 0u) << k;
+      m_bot |= (valid && hy == TH + 1 ? 1u : 0u) << k;
+      m_left |= (valid && hx == 0 ? 1u : 0u) << k;
+      m_right |= (valid && hx == HP - 1 ? 1u : 0u) << k;
     }
+    const unsigned pad_bytes = (unsigned)(d.Win + 1) * 128u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(L.src0)) - pad_bytes, 0,
+        (int)((size_t)d.B * d.Hin * d.Win * 128 + pad_bytes), 0x00020000);
     // Two register sets: halo h lives in set h & 1.  The loads of halo s+2 are issued BEFORE halo s+1 is transformed and
     // written, so HBM requests are in flight during the prologue arithmetic (with one set the re-issue had to wait for
     // the transform: every CU computed while HBM idled, then every CU loaded — the two times added up).
@@ -351,21 +370,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     auto issue = [&](int s, c64_u32x4(&h)[KU]) {           // loads of halo s (clamped to the last tile: harmless reloads)
       int b, y0, x0;
       c64_tile(first + min(s, nsteps - 1) * stride, tiles_x, tiles_y, b, y0, x0);
-      okmask_nxt = 0;
-      const bf16_t* src = L.src0 + (size_t)b * d.Hin * d.Win * 64 + slot * 8;
-      const int yd = y0 >> d.ups, xd = x0 >> d.ups;        // the tile origin: always mapped (stand-in for padding taps)
+      okmask_nxt = m_valid & ~((y0 == 0 ? m_top : 0u) | (y0 + TH == Hl ? m_bot : 0u) | (x0 == 0 ? m_left : 0u) |
+                               (x0 + TW == Wl ? m_right : 0u));
+      const int soff = __builtin_amdgcn_readfirstlane((((b * d.Hin + (y0 >> d.ups)) * d.Win) + (x0 >> d.ups)) * 128);   // the SGPR offset
 #pragma unroll
-      for (int k = 0; k < KU; ++k) {
-        const int hp = k * RPP + row;
-        int y = y0 - 1 + hy[k], x = x0 - 1 + hx[k];
-        const bool ok = hp < HALO && (unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl;
-        y >>= d.ups;
-        x >>= d.ups;
-        y = ok ? y : yd;                                   // every load is issued unconditionally (no branch per unit)
-        x = ok ? x : xd;
-        h[k] = *reinterpret_cast<const c64_u32x4*>(src + ((size_t)y * d.Win + x) * 64);
-        okmask_nxt |= (ok ? 1u : 0u) << k;
-      }
+      for (int k = 0; k < KU; ++k)
+        h[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((okmask_nxt >> k) & 1u) ? voffk[k] : -1, soff, 0);
       if constexpr (PRO == 1) {
         const float* pa = L.pro_a + (size_t)b * 64 + slot * 8;
         const float* pb = L.pro_b + (size_t)b * 64 + slot * 8;
@@ -402,7 +412,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
             v[j] = c64_pack(lo, hh);
           }
         }
-        if (!((okmask >> k) & 1u)) v = c64_u32x4{0u, 0u, 0u, 0u};
+        if constexpr (PRO != 0) {                          // (PRO == 0: the padding units arrived as zeros)
+          if (!((okmask >> k) & 1u)) v = c64_u32x4{0u, 0u, 0u, 0u};
+        }
         *reinterpret_cast<c64_u32x4*>(dst + k * RPP * ROWB) = v;
       }
     };
