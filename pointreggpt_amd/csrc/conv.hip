@@ -650,7 +650,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mx_kernel(const ConvLaunch<bf1
 // ---------------------------------------------------------------------------------------------
 // generic gather kernel (1x1, 4x4 s2, ragged shapes)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN>
+// ONE: 1x1, stride 1, no padding, no upsampling (the res_convs and the attention projections): output row m reads input
+// pixel m, so a thread's gather address is a constant of the thread plus the chunk's channel offset — no coordinates, no
+// bounds, no 64-bit multiplies per load (round 3: the gather form issued ~20 VALU instructions per MFMA on these shapes).
+template <typename T, int BM, int BN, bool ONE>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel(const ConvLaunch<T> L, const int M, const int tiles_m,
                                                          const int tiles_n, const int fuse_stats, const int wide) {
   constexpr int BK = ConvTile<T>::BK;
@@ -682,16 +685,23 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel
   int a_iy0[AP], a_ix0[AP];
   int64_t a_base[AP];
   bool a_ok[AP];
+  const T* a_p0[AP];                          // ONE: address of channel ku * VEC of this thread's pixel in src0 / src1
+  const T* a_p1[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int m = tm * BM + lrow + i * RPP;
     a_ok[i] = m < M;
     const int mm = a_ok[i] ? m : 0;
-    const int bb = mm / HWo, rem = mm - bb * HWo;
-    const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
-    a_iy0[i] = oy * d.stride - d.pad;
-    a_ix0[i] = ox * d.stride - d.pad;
-    a_base[i] = (int64_t)bb * d.Hin * d.Win;
+    if constexpr (ONE) {
+      a_p0[i] = L.src0 + (int64_t)mm * d.C0 + ku * VEC;
+      a_p1[i] = d.C1 ? L.src1 + (int64_t)mm * d.C1 + ku * VEC - d.C0 : a_p0[i];
+    } else {
+      const int bb = mm / HWo, rem = mm - bb * HWo;
+      const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
+      a_iy0[i] = oy * d.stride - d.pad;
+      a_ix0[i] = ox * d.stride - d.pad;
+      a_base[i] = (int64_t)bb * d.Hin * d.Win;
+    }
   }
 
   Vec16<T> ra[AP], rb[BP];
@@ -699,6 +709,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel
   auto gload = [&](int tap, int kc) {
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int c = kc * BK + ku * VEC;
+    if constexpr (ONE) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        if (a_ok[i] && c < Cin) ra[i] = vec_load((c < d.C0 ? a_p0[i] : a_p1[i]) + kc * BK);
+        else ra[i] = vec_zero<T>();
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
@@ -856,7 +873,9 @@ static int launch_igemm(const ConvLaunch<T>& L, int M, hipStream_t s, int want_s
   if (nsplit) *nsplit = fuse ? HWo / BM : 0;
   size_t lds = (size_t)2 * (BM + BN) * (UPR + 1) * 16;
   if (lds < kEpilogueLds) lds = kEpilogueLds;
-  conv_igemm_kernel<T, BM, BN><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse, wide);
+  const bool one = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ups;
+  if (one) conv_igemm_kernel<T, BM, BN, true><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse, wide);
+  else conv_igemm_kernel<T, BM, BN, false><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse, wide);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
