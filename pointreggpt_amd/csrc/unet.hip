@@ -1506,8 +1506,8 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
     float ms = 0;
     PRG_HIP(hipEventElapsedTime(&ms, t0, t1));
     h->last_total_ms = ms;
-    hipEventDestroy(t0);
-    hipEventDestroy(t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
   }
   return PRG_OK;
 }
