@@ -1077,8 +1077,8 @@ struct prg_sampler {
 namespace prg {
 
 static void sampler_free(prg_sampler* h) {
-  if (h->exec) hipGraphExecDestroy(h->exec);
-  if (h->graph) hipGraphDestroy(h->graph);
+  if (h->exec) (void)hipGraphExecDestroy(h->exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
   h->exec = nullptr;
   h->graph = nullptr;
 }
@@ -1159,21 +1159,21 @@ int prg_unet_create(const prg_unet_config* cfg, const float* weights, int64_t n_
 
 int prg_unet_destroy(prg_unet* h) {
   if (!h) return PRG_OK;
-  hipDeviceSynchronize();
-  if (h->d_flat) hipFree(h->d_flat);
-  if (h->d_packed) hipFree(h->d_packed);
-  if (h->d_stem) hipFree(h->d_stem);
-  if (h->d_attn) hipFree(h->d_attn);
-  if (h->d_kshift) hipFree(h->d_kshift);
-  if (h->d_freqs) hipFree(h->d_freqs);
-  if (h->d_mx) hipFree(h->d_mx);
-  if (h->d_mx_scale) hipFree(h->d_mx_scale);
-  if (h->d_tickets) hipFree(h->d_tickets);
-  if (h->d_gnacc) hipFree(h->d_gnacc);
-  if (h->d_pq_static) hipFree(h->d_pq_static);
-  if (h->d_cond_entries) hipFree(h->d_cond_entries);
-  if (h->d_stem_frag) hipFree(h->d_stem_frag);
-  if (h->arena.base) hipFree(h->arena.base);
+  (void)hipDeviceSynchronize();
+  if (h->d_flat) (void)hipFree(h->d_flat);
+  if (h->d_packed) (void)hipFree(h->d_packed);
+  if (h->d_stem) (void)hipFree(h->d_stem);
+  if (h->d_attn) (void)hipFree(h->d_attn);
+  if (h->d_kshift) (void)hipFree(h->d_kshift);
+  if (h->d_freqs) (void)hipFree(h->d_freqs);
+  if (h->d_mx) (void)hipFree(h->d_mx);
+  if (h->d_mx_scale) (void)hipFree(h->d_mx_scale);
+  if (h->d_tickets) (void)hipFree(h->d_tickets);
+  if (h->d_gnacc) (void)hipFree(h->d_gnacc);
+  if (h->d_pq_static) (void)hipFree(h->d_pq_static);
+  if (h->d_cond_entries) (void)hipFree(h->d_cond_entries);
+  if (h->d_stem_frag) (void)hipFree(h->d_stem_frag);
+  if (h->arena.base) (void)hipFree(h->arena.base);
   delete h;
   return PRG_OK;
 }
@@ -1270,7 +1270,7 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
   }
   std::vector<float> zb(Cout, 0.0f);
   void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_mxd = nullptr, *d_mxs = nullptr, *d_w2 = nullptr;
-  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_mxd, d_mxs, d_w2}) if (p) hipFree(p); };
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_mxd, d_mxs, d_w2}) if (p) (void)hipFree(p); };
   if (hipMalloc(&d_in, M * Cin * 2) != hipSuccess || hipMalloc(&d_out, Mo * Cout * 2) != hipSuccess ||
       (!packed_s2d.empty() && hipMalloc(&d_w2, packed_s2d.size() * 2) != hipSuccess) ||
       hipMalloc(&d_w, packed.size() * 2) != hipSuccess || hipMalloc(&d_b, Cout * 4) != hipSuccess ||
@@ -1278,12 +1278,15 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
     cleanup();
     return fail(PRG_E_NOMEM, "prg_debug_conv3x3: hipMalloc failed");
   }
-  hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
-  if (d_w2) hipMemcpy(d_w2, packed_s2d.data(), packed_s2d.size() * 2, hipMemcpyHostToDevice);
-  hipMemcpy(d_b, bias ? bias : zb.data(), Cout * 4, hipMemcpyHostToDevice);
-  if (dtype == PRG_MXFP8) {
-    hipMemcpy(d_mxd, mxd.data(), mxd.size(), hipMemcpyHostToDevice);
-    hipMemcpy(d_mxs, mxs.data(), mxs.size(), hipMemcpyHostToDevice);
+  bool up = hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+            (!d_w2 || hipMemcpy(d_w2, packed_s2d.data(), packed_s2d.size() * 2, hipMemcpyHostToDevice) == hipSuccess) &&
+            hipMemcpy(d_b, bias ? bias : zb.data(), Cout * 4, hipMemcpyHostToDevice) == hipSuccess;
+  if (up && dtype == PRG_MXFP8)
+    up = hipMemcpy(d_mxd, mxd.data(), mxd.size(), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_mxs, mxs.data(), mxs.size(), hipMemcpyHostToDevice) == hipSuccess;
+  if (!up) {
+    cleanup();
+    return fail(PRG_E_HIP, "prg_debug_conv3x3: hipMemcpy failed");
   }
   int rc = launch_nchw_f32_to_nhwc<bf16_t>(x, reinterpret_cast<bf16_t*>(d_in), B, H * W, Cin, s);
   if (rc == PRG_OK) {
@@ -1299,7 +1302,7 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
     rc = launch_conv<bf16_t>(L, s, nullptr);
   }
   if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<bf16_t>(reinterpret_cast<const bf16_t*>(d_out), out, B, Ho * Wo, Cout, s);
-  hipStreamSynchronize(s);
+  if (hipStreamSynchronize(s) != hipSuccess && rc == PRG_OK) rc = fail(PRG_E_HIP, "prg_debug_conv3x3: stream synchronise failed");
   cleanup();
   return rc;
 }
@@ -1369,13 +1372,13 @@ int prg_sampler_create(prg_unet* unet, const prg_step* steps, int n_steps, int B
 
 int prg_sampler_destroy(prg_sampler* h) {
   if (!h) return PRG_OK;
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   sampler_free(h);
-  for (auto& ev : h->prof.pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-  for (auto& ev : h->prof.step_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  for (auto& ev : h->prof.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto& ev : h->prof.step_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   void* ptrs[] = {h->d_steps, h->d_tpart, h->d_ppart, h->d_scratch, h->d_x, h->d_u, h->d_step, h->d_seeds};
-  for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return PRG_OK;
 }
@@ -1472,7 +1475,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
       rc = sampler_one_step(h, img_cond, noise, out, s);
       hipGraph_t g = nullptr;
       hipError_t ce = hipStreamEndCapture(s, &g);
-      if (rc) { if (g) hipGraphDestroy(g); return rc; }
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
       if (ce != hipSuccess) return fail(PRG_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
       h->graph = g;
       PRG_HIP(hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0));
