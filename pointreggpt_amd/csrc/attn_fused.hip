@@ -356,6 +356,14 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 2 : 1)) void la_out_
   float* lnb = reinterpret_cast<float*>(ot + kTP * kLdO);   // [64][4][2] LayerNorm partial sums
   __bf16* yt = reinterpret_cast<__bf16*>(lnb + kTP * RTL * 2);   // [64][LDW] the normalised y tile (its own buffer: no barrier
                                                              // between a tile's last phase and the next tile's LayerNorm)
+  // to_out's bias and the output LayerNorm's gain live in LDS: as global loads inside the tile loop they sat BEHIND the
+  // next tile's x prefetch in the in-order vmcnt queue, so every tile waited for its successor's HBM latency
+  float* bias_l = reinterpret_cast<float*>(yt + kTP * G::LDW);   // [C]
+  float* outg_l = bias_l + C;                                    // [C]
+  if (threadIdx.x < C) {
+    bias_l[threadIdx.x] = bias[threadIdx.x];
+    outg_l[threadIdx.x] = out_g[threadIdx.x];
+  }                                                              // (visible after the first tile's barrier (1))
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
   const int ntiles = (N + kTP - 1) / kTP;
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 2 : 1)) void la_out_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = yrt[a] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        ya[a][r] += bias[c];
+        ya[a][r] += bias_l[c];
         s1 += ya[a][r];
         s2 = fmaf(ya[a][r], ya[a][r], s2);
       }
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(256, C == 64 ? 3 : (C == 128 ? 2 : 1)) void la_out_
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int c0 = yrt[a] * 32 + 8 * g4 + 4 * hi;
-        const float4 gg = *reinterpret_cast<const float4*>(out_g + c0);
+        const float4 gg = *reinterpret_cast<const float4*>(outg_l + c0);
         uint2 w;
         w.x = pack2((ya[a][4 * g4] - mean) * rstd * gg.x, (ya[a][4 * g4 + 1] - mean) * rstd * gg.y);
         w.y = pack2((ya[a][4 * g4 + 2] - mean) * rstd * gg.z, (ya[a][4 * g4 + 3] - mean) * rstd * gg.w);
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(256) void full_attn_mfma_big_kernel(const bf16_t* _
 template <int C>
 size_t lds_kmax() { return (size_t)kTP * Geo<C>::LDW * 2; }
 template <int C>
-size_t lds_out() { return (size_t)2 * kTP * Geo<C>::LDW * 2 + (size_t)kTP * kLdO * 2 + (size_t)kTP * (C / 32 > 4 ? C / 32 : 4) * 2 * 4; }
+size_t lds_out() { return (size_t)2 * kTP * Geo<C>::LDW * 2 + (size_t)kTP * kLdO * 2 + (size_t)kTP * (C / 32 > 4 ? C / 32 : 4) * 2 * 4 + (size_t)2 * C * 4; }
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
