@@ -494,6 +494,7 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
   if (d.C0 != 64 || d.C1 != 0 || d.Cout != 64 || d.CoutPad != 64 || d.kchunks != 2) return 0;
   if (L.residual || !L.bias) return 0;
+  if (d.ups) return 0;                                       // (no 64 -> 64 Upsample conv exists in the networks: not a tested shape)
   if (d.Wout % TW || d.Hout % TH) return 0;
   const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH;
   const int total = tiles_x * tiles_y * d.B;
