@@ -222,6 +222,57 @@ np.savez({out!r}, y64=y64, y128=y128, y40=y40, y96=y96)
 """
 
 
+_QK_EDGE_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from pointreggpt_amd import weights as W
+from pointreggpt_amd.unet import Unet
+sd = W.synth_state_dict(W.unet_config(64), 8)
+worst = 0.0
+for pre in [k[:-len(".fn.fn.to_qkv.weight")] for k in sd if k.endswith(".fn.fn.to_qkv.weight") and not k.startswith("mid_attn")]:
+    w = sd[pre + ".fn.fn.to_qkv.weight"]
+    g = sd[pre + ".fn.norm.g"].reshape(-1).double()
+    C = w.shape[1]
+    wg = w.reshape(384, C).double() * g[None, :] * 1.4426950408889634
+    bound = float((1.02 * torch.sqrt((wg[:256] ** 2).sum(1) * C)).max())       # what unet.hip computes (log2 units)
+    f = {target} / bound
+    w[:256] *= f                                                                # q and k rows: the static bound becomes `target`
+    worst = max(worst, bound * f)
+net = Unet(64, dtype="bf16").load_state_dict(sd)
+gen = torch.Generator().manual_seed(11)
+x = torch.randn((2, 1, 64, 64), generator=gen)
+pc = torch.tensor([[75.7, 76.0, 32.5, 32.0]] * 2)
+y = net(x.cuda(), torch.tensor([5, 800]).cuda(), pc.cuda()).float().cpu().numpy()
+np.savez({out!r}, y=y, bound=np.float64(worst))
+"""
+
+
+def test_linear_attention_without_shift_at_the_edge_of_the_static_bound(tmp_path):
+    """Round 3 dropped the softmax shift where the static bound |q|, |k| <= 57.7 (log2 units) holds.  Here the q and k rows
+    of every linear-attention block are scaled until that bound is 56 — the static path is still taken, exp2 runs on
+    arguments an order of magnitude larger than with the synthetic weights — and the result must stay finite and agree
+    with (a) the measured-maximum path (PRG_LA_KSHIFT=0: la_kmax pass + shift), (b) the unfused kernels (their own
+    shifted softmax).  At 59 the bound fails and the library itself falls back to (a): same comparison."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for target in (56.0, 59.0):
+        outs = {}
+        for name, env in {"static": {}, "measured": {"PRG_LA_KSHIFT": "0"}, "unfused": {"PRG_FUSED_ATTN": "0"}}.items():
+            out = str(tmp_path / f"{name}_{target}.npz")
+            r = subprocess.run([sys.executable, "-c", _QK_EDGE_SCRIPT.format(root=root, out=out, target=target)],
+                               env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[name] = np.load(out)
+        assert abs(float(outs["static"]["bound"]) - target) < 1e-6
+        assert np.isfinite(outs["static"]["y"]).all()
+        for name in ("measured", "unfused"):
+            d = np.abs(outs["static"]["y"].astype(np.float64) - outs[name]["y"].astype(np.float64))
+            print(f"bound {target}: static vs {name}: max {d.max():.3e} mean {d.mean():.3e}")
+            assert d.max() <= 0.12 and d.mean() <= 0.016, (target, name, d.max(), d.mean())   # the fast-path variants' bound
+
+
 def test_bf16_fast_paths_match_generic_kernels(tmp_path):
     """The wave-specialised 3x3 conv and the fused linear attention are alternative schedules of the same arithmetic:
     switching either off (generic implicit-GEMM conv / unfused LayerNorm-qkv-attention kernels) must give the same
