@@ -353,9 +353,6 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     // this thread's first unit of a weight tile inside a tap's [2][CoutPad][32] slab; rows row + 32 j are 2048 bytes apart
     const unsigned w_voff = (unsigned)((((slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8) * 2);
     const int wj_mask = nwn == 2 ? 3 : 1;                    // Cout = 64: only 64 weight rows exist (the upper ones are re-read)
-    // an always-mapped stand-in for padding taps: the tile origin; MODE 1: one virtual pixel further in (its sub-pixel
-    // (0,0) at the image's top-left tile would be source pixel (-1,-1))
-    const unsigned ld_dummy = (unsigned)(MODE ? 2 * d.Win + 2 : d.Win + 1);
     struct StepInfo { int chunk, it, b, y0, x0; };
     int gC = 0;
     auto advance = [&](StepInfo& si) {                       // past the last step it stays there: harmless reloads
@@ -381,6 +378,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     float4 cf[4], nf[4];                                     // a0..3, a4..7, b0..3, b4..7 of the halo being written / issued
     unsigned hvalid = 0, hvalid_nxt = 0;
     const char* ld_base = nullptr;
+    __amdgpu_buffer_rsrc_t ld_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(L.src0), 0, 0, 0x00020000);
     unsigned ld_cs2 = 0, ld_tedge = 0;
     const float* ld_ca = nullptr;
     const float* ld_cb = nullptr;
@@ -426,6 +424,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
         const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> d.ups)) * d.Win + (si.x0 >> d.ups) - (d.Win + 1);
         ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
       }
+      ld_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ld_base), 0, 0x7ffffff0, 0x00020000);   // (base may lie before the tensor: only in-image offsets are ever in range AND valid)
       if constexpr (PRO) {
         const int c0 = si.chunk * kCH + slot * 8;
         if (pfold) {
@@ -450,12 +449,14 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
         if (pfold) nacc = *reinterpret_cast<const longlong2*>(ld_acc);
       }
     };
+    // Raw BUFFER loads from a descriptor based at the halo origin (round 3): a padding unit gets offset 0xffffffff and the
+    // hardware's range check returns zeros — no always-mapped stand-in pixel, and without a prologue no select before the
+    // LDS write either (conv_c64.hip's producers, same idea).
     auto issue_unit = [&](int k) {                           // k is a compile-time constant at every call site
       const bool ok = (hedge[k] & ld_tedge) == 0 && !(PRG_W256_EXP & 2);
-      const unsigned pix = ok ? hpix[k] : ld_dummy;
-      const unsigned voff = __umul24(pix, ld_cs2) + (unsigned)(slot * 16);
-      hreg[k] = *reinterpret_cast<const w2_u32x4*>(ld_base + voff);
-      hvalid_nxt |= (ok ? 1u : 0u) << k;
+      const unsigned voff = (__umul24(hpix[k], ld_cs2) + (unsigned)(slot * 16)) | (ok ? 0u : 0xffffffffu);   // (branch-free)
+      hreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ld_rsrc, (int)voff, 0, 0);
+      if constexpr (PRO) hvalid_nxt |= (ok ? 1u : 0u) << k;
     };
     auto write_unit = [&](int k, int bufoff) {
       w2_u32x4 v = hreg[k];
@@ -469,7 +470,9 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
           v[j] = w2_pack(lo, hh);
         }
       }
-      if (!((hvalid >> k) & 1u)) v = w2_u32x4{0u, 0u, 0u, 0u};
+      if constexpr (PRO) {                                   // (padding must be zero AFTER the transform; without one it arrived as zeros)
+        if (!((hvalid >> k) & 1u)) v = w2_u32x4{0u, 0u, 0u, 0u};
+      }
       *reinterpret_cast<w2_u32x4*>(Ah0 + bufoff + k * RPP * ROWB) = v;
     };
     // weight tile of phase `ph` (its tap in the packed 3 x 3 layout) and 64-channel chunk
