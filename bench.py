@@ -25,7 +25,9 @@ sys.path.insert(0, ROOT)
 
 UNET_GFLOP = {64: 14.744, 128: 58.976, 256: 236.282}      # per image, SURVEY.md §8d / BASELINE.md §2
 MASK_GFLOP = {64: 14.787, 128: 59.173, 256: 237.096}
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mxfp8": 5000.0}   # dense, MI355X_MICROARCH.md chip table
+# dense, MI355X_MICROARCH.md chip table.  f16x3: the f16 matrix pipe (2.5 PFLOP/s) executes THREE MFMA FLOPs per algorithmic
+# FLOP (hi*hi + hi*lo + lo*hi), so algorithmic TFLOP/s are priced against 2500 / 3
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mxfp8": 5000.0, "f16x3": 2500.0 / 3.0}
 CONV_CLASS = ("MFMA convolutions: conv3x3_w256_kernel (256-pixel x 128-channel tiles, also Downsample) + conv3x3_c64_kernel "
               "(64 -> 64, weights-stationary) + conv3x3_ws_kernel (128-pixel wave-specialised tiles) + conv_igemm_kernel (1x1)")
 
@@ -48,7 +50,7 @@ def parse():
     p.add_argument("--size", type=int, default=128)
     p.add_argument("--timesteps", type=int, default=1000)
     p.add_argument("--sampling-steps", type=int, default=None, help="< timesteps selects DDIM (default: ancestral DDNM)")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "mxfp8"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "mxfp8", "f16x3"])
     p.add_argument("--dim", type=int, default=64)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--sampler-only", action="store_true", help="configs[1]: p_sample_loop only (no geometry / MaskUnet)")

@@ -39,7 +39,11 @@ enum {
 /* storage + MFMA input type of a U-Net handle.  PRG_MXFP8 (BASELINE configs[4]): activations stored in bf16, every 3x3
  * convolution with 64-channel-multiple widths runs on v_mfma_scale_f32_32x32x64_f8f6f4 with OCP e4m3 operands and one
  * E8M0 scale per 32 channels (weights quantised at prg_unet_create, activations while they are staged); the rest = bf16. */
-enum { PRG_F32 = 0, PRG_BF16 = 1, PRG_MXFP8 = 2 };
+/* PRG_F16X3 (round 4): float32 storage and float32 / float64 normalisation arithmetic exactly as PRG_F32, but every
+ * convolution contracts on the f16 matrix pipe with both operands split into two f16 halves (a = hi + lo, three MFMAs per
+ * product tile, 22-bit operands; csrc/conv_split.hip) — the mode that holds the 1e-4 m point-XYZ tolerance of the parity
+ * mode at several times its throughput.                                                                                   */
+enum { PRG_F32 = 0, PRG_BF16 = 1, PRG_MXFP8 = 2, PRG_F16X3 = 3 };
 
 int prg_abi_version(void);
 const char* prg_last_error(void);
@@ -160,6 +164,10 @@ int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* 
  * out (B,Cout,H/2,W/2).                                                                                             */
 int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                         void* stream);
+/* General form for the float32-storage modes (PRG_F32 / PRG_F16X3): K x K kernel (1, 3 or 4), stride 1 or 2, pad = 0 for
+ * K = 1 and 1 otherwise; w (Cout,Cin,K,K), out (B,Cout,Ho,Wo) float32.  Also accepts PRG_BF16 / PRG_MXFP8 for K = 3 / 4.  */
+int prg_debug_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                   int dtype, int K, int stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler: GaussianDiffusion.sample / p_sample_loop / ddim_sample (sd:1283-1409), DDNM replacement included

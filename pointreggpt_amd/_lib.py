@@ -9,7 +9,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("PRG_HIP_LIB", _HERE / "libprg_hip.so"))
 
-PRG_F32, PRG_BF16, PRG_MXFP8 = 0, 1, 2
+PRG_F32, PRG_BF16, PRG_MXFP8, PRG_F16X3 = 0, 1, 2, 3
 
 
 class PrgError(RuntimeError):
@@ -53,6 +53,7 @@ PROTOTYPES = {
     "prg_maskunet_forward": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "prg_debug_conv3x3": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "prg_debug_conv4x4s2": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "prg_debug_conv": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "prg_unet_set_taps": (C.c_int, [_P, _I]),
     "prg_unet_get_tap": (C.c_int, [_P, C.c_char_p, _P, _L, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P]),
     "prg_sampler_create": (C.c_int, [_P, C.POINTER(StepC), _I, _I, _I, C.POINTER(_P)]),

@@ -78,7 +78,17 @@ struct ConvLaunch {
   // channel (2 dy + dx) C + c, tap (1 + by, 1 + bx) = W[.][c][2 by + dy][2 bx + dx]); null = not available.  conv_w256.hip
   const T* w_s2d;
   int s2d_kchunks;
+  // f16x3 mode (handles of dtype PRG_F16X3, T = float; conv_split.hip): the weights split into f16 hi / lo halves,
+  // [tap][32-channel chunk][CoutPad][32 hi | 32 lo]; null = the exact-f32 kernels
+  const uint16_t* w_split;
+  int split_kchunks;
 };
+
+// hi / lo f16 split of a conv weight for the f16x3 mode (layout at ConvLaunch::w_split)
+void pack_conv_weight_split(const float* w_oihw, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out, int* CoutPad,
+                            int* kchunks32);
+// f16x3 kernels: 1 = launched, 0 = shape not covered (the exact-f32 kernels run), < 0 = error
+int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsplit_out);
 
 // OIHW weights of the equivalent convolution described at ConvLaunch::w_s2d, from Conv2d(Cin, Cout, 4, 2, 1) weights
 void s2d_equivalent_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>& out);

@@ -1,0 +1,653 @@
+// conv_split.hip — the convolutions of the `f16x3` precision mode (round 4): float32 storage, every contraction on the
+// f16 matrix pipe with BOTH operands split into two halves on the fly.
+//
+//   a = a_hi + a_lo,  a_hi = f16(a),  a_lo = f16(a - a_hi)      |a - a_hi - a_lo| <= 2^-22 |a|  (f16 subnormals are kept by
+//   a * w ~= a_hi * w_hi + a_hi * w_lo + a_lo * w_hi            v_mfma_f32_32x32x16_f16: probed, tools/micro/f16_split_probe.hip)
+//
+// Three v_mfma_f32_32x32x16_f16 per product tile instead of eight v_mfma_f32_32x32x2_f32: 5.3x fewer matrix-pipe cycles
+// than the exact-f32 parity kernels at 22-bit operands; the dropped a_lo * w_lo term is 2^-22 relative.  The fp32
+// accumulation chain of the matrix pipe is cut at every 32-channel chunk (9 taps x 32 channels = 288 terms) and the partials
+// are added in a second float32 accumulator set: measured on the part against float64 dot products, this sits 4-5x closer to
+// exact than one K-long chain (K = 4608: rms 1.3e-5 vs 4.5e-5 on outputs of rms 62) and as close as a float64 sum of 32-term
+// partials to within 1.5x — i.e. at the distance from exact arithmetic of the reference's own oneDNN convolution.
+//
+// Weights are split once at load (pack_conv_weight_split); activations while the halo / the gather tile is written to LDS
+// (v_cvt_pk_f16_f32, one subtraction: 2.5 VALU instructions per element), after the optional fused GroupNorm + SiLU
+// prologue.  LDS rows are 128 bytes per pixel and 32-channel chunk — 64 B of hi halves, 64 B of lo halves — with the
+// 16-byte XOR swizzle of conv.hip, so the tile shapes, the epilogue (conv_epi.h) and the GroupNorm statistics slabs are the
+// parity kernels' own.  Reference: Block.proj / res_conv / to_qkv / to_out / Downsample / Upsample, sd:583-796.
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "conv_epi.h"
+
+#ifndef PRG_SPLIT_EXP
+#define PRG_SPLIT_EXP 0      // ablation builds (tools/split_ablate.sh): 1 no MFMAs, 2 no split arithmetic, 3 no epilogue, 4 no weight loads, 5 no halo staging in the loop
+#endif
+
+namespace prg {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// 8 consecutive channels -> their hi and lo halves as two 16-byte MFMA operand units
+__device__ inline void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  f16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const f32x2 p = {v[i], v[i + 1]};
+    const f16x2 ph = __builtin_convertvector(p, f16x2);          // v_cvt_pk_f16_f32, round to nearest even
+    const f32x2 r = p - __builtin_convertvector(ph, f32x2);      // exact in float32
+    const f16x2 pl = __builtin_convertvector(r, f16x2);
+    h[i] = ph[0]; h[i + 1] = ph[1];
+    l[i] = pl[0]; l[i + 1] = pl[1];
+  }
+  hi = __builtin_bit_cast(uint4, h);
+  lo = __builtin_bit_cast(uint4, l);
+}
+
+// SiLU of the fused prologue: hardware exp2 / reciprocal (1 ulp each) — ~2e-7 relative, the size of the contraction's own error
+__device__ inline float silu_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
+__device__ inline f16x8 ld_frag(const uint4* p) { return __builtin_bit_cast(f16x8, *p); }
+
+// acc += a * w with split operands: the two cross terms first (small), then the leading term
+__device__ inline void mma3(const f16x8& ah, const f16x8& al, const f16x8& wh, const f16x8& wl, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, c, 0, 0, 0);
+}
+
+// all tiles of a wave: term-major, so that back-to-back MFMAs never wait on the same accumulator
+template <int TM>
+__device__ inline void mma3_tiles(const f16x8 (&ah)[TM], const f16x8 (&al)[TM], const f16x8 (&wh)[2], const f16x8 (&wl)[2],
+                                  f32x16 (&acc)[TM][2]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+}
+
+template <int TM>
+__device__ inline void flush_acc(f32x16 (&acc)[TM][2], f32x16 (&tot)[TM][2]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        tot[i][j][e] += acc[i][j][e];
+        acc[i][j][e] = 0.0f;
+      }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1: halo tile in LDS (structure of conv3x3_halo_kernel, conv.hip)
+// ---------------------------------------------------------------------------------------------
+// Tiles of 128 pixels x 64 channels, four waves, one 32-pixel x 64-channel wave tile each; two workgroups per CU.
+//   * software pipeline: body(tap) = { wait + barrier | stage one pass of the NEXT chunk's halo | prefetch the weight tile
+//     NS taps ahead | issue the twelve fragment loads of the NEXT tap into the other register set | twelve MFMAs of THIS tap };
+//     the loads and the staging arithmetic do not feed the MFMAs behind them, so they run in the matrix pipe's shadow;
+//   * the nine taps of a chunk are unrolled with the tap a compile-time constant: halo rows are 144 bytes (128 + 16 of
+//     padding: conflict-free ds_read_b128 without an XOR swizzle, as in conv_w256.hip), so every fragment address is one
+//     per-lane base register + an immediate; the weight ring slot (tap % 3) and the staging pass are constants too —
+//     the instruction diet that took the loop from 8 VALU + 6 SALU per MFMA to ~2;
+//   * the halo is DOUBLE-BUFFERED in LDS and staged incrementally (pass k of the next chunk loaded at tap k, converted and
+//     written at tap k + 1): eight staging registers instead of the whole halo's 32-48;
+//   * weight tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring
+//     of NS slots, with counted vmcnt waits so that the newest prefetch stays in flight across the barrier.
+// History of the round (level-0 launch, 77 GFLOP): 64 x 64 wave tiles at 256 registers spilled the weight prefetch inside
+// the loop (409 us); three workgroups per CU at 168 registers with just-in-time fragment loads 284 us — and 209 us with the
+// MFMAs compiled out: MFMA 105 + LDS reads 53 + L1/TA 47 + split 21 + epilogue 48 us simply added up, identical workgroups
+// run in lockstep and overlap nothing; the first pipelined version 345 us at 8 VALU + 6 SALU instructions per MFMA
+// (rocprofv3 SQ_INSTS_*: address arithmetic and tap bookkeeping); this structure: DESIGN.md section 4.6.
+template <int N>
+struct IC {
+  static constexpr int value = N;
+};
+
+template <int TH, int TW, int NS>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(
+    const ConvLaunch<float> L, const int tiles_x, const int tiles_y, const int tiles_n, const int fuse_stats) {
+  constexpr int NW = 4, BN = 64, TM = 1;
+  constexpr int CH = 32;                       // channels per chunk: one LDS row = 64 B of hi halves + 64 B of lo halves
+  constexpr int HP = TW + 2, HALO = (TH + 2) * HP;
+  constexpr int PITCH = 144;                   // halo row pitch in bytes
+  constexpr int NH = (HALO + 63) / 64;         // staging passes per chunk (64 halo pixels each)
+  constexpr int HBYTES = HALO * PITCH;
+  constexpr int WPW = BN / 8 / NW;             // global_load_lds wave-instructions (8 rows each) per wave and weight tile
+  static_assert(TH * TW == 128 && NH + 1 <= 8 && (NS == 2 || NS == 3), "tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ah = smem;                                 // [2][HALO] rows of PITCH bytes: units 0-3 hi, 4-7 lo
+  char* const Bs = smem + 2 * HBYTES;                    // [NS][64][128 B], 16-byte units XOR-swizzled by (row >> 1) & 7
+  float* stage = reinterpret_cast<float*>(smem);         // epilogue scratch aliases the main-loop images
+
+  const ConvDesc& d = L.d;
+  const int nblk = tiles_x * tiles_y * tiles_n * d.B;
+  int lin = xcd_remap(blockIdx.x, nblk);
+  const int tn = lin % tiles_n; lin /= tiles_n;
+  const int tx = lin % tiles_x; lin /= tiles_x;
+  const int ty = lin % tiles_y;
+  const int b = lin / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nchunks = (d.C0 + d.C1) / CH;
+  const int Hl = d.Hout, Wl = d.Wout;
+  const int q = tid & 3, prow = tid >> 2;      // this thread stages channels q * 8 .. + 7 of halo pixels prow + 64 k
+
+  int hsrc[NH];                                // source pixel index (or -1: padding / beyond the halo)
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int hp = prow + k * 64;
+    hsrc[k] = -1;
+    if (hp < HALO) {
+      const int hy = hp / HP, hx = hp - hy * HP;
+      int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      if ((unsigned)y < (unsigned)Hl && (unsigned)x < (unsigned)Wl) {
+        if (d.ups) { y >>= 1; x >>= 1; }
+        hsrc[k] = (b * d.Hin + y) * d.Win + x;
+      }
+    }
+  }
+  // fragment addresses: one per-lane base each, everything else immediate
+  const int pix = wave * 32 + l31;
+  const int a_lane = ((pix / TW) * HP + (pix % TW)) * PITCH + hi * 16;            // + buffer + tap offset + step * 32 (+ 64: lo)
+  int b_lane[2][2];                                                                // [step][hi / lo], + ring slot + j * 4096
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int sw = (l31 >> 1) & 7, unit = 2 * st + hi;
+    b_lane[st][0] = l31 * 128 + ((unit ^ sw) << 4);
+    b_lane[st][1] = l31 * 128 + (((4 + unit) ^ sw) << 4);
+  }
+  const int w_lane = prow * PITCH + q * 16;                                        // staging write: + pass * 64 * PITCH (+ 64: lo)
+
+  // one staging pass: load (global -> registers) and, one tap later, prologue + split + write (registers -> LDS)
+  float4 h0, h1;
+  auto halo_load = [&](int chunk, auto K) {   // always issued (padding lanes read the tensor's first bytes and are zeroed when
+    constexpr int k = decltype(K)::value;      // written): the counted vmcnt waits below need a fixed number of loads per body
+    const int c = chunk * CH + q * 8;
+    const bool first = c < d.C0;
+    const float* base = first ? L.src0 : L.src1;
+    const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+    const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
+    h0 = p[0];
+    h1 = p[1];
+  };
+  float pa[8], pb[8];                          // fused prologue coefficients of this thread's 8 channels (chunk being staged)
+  auto pro_load = [&](int chunk) {
+    if (L.pro_a) {
+      const float4* a4 = reinterpret_cast<const float4*>(L.pro_a + (size_t)b * d.C0 + chunk * CH + q * 8);
+      const float4* b4 = reinterpret_cast<const float4*>(L.pro_b + (size_t)b * d.C0 + chunk * CH + q * 8);
+      const float4 a0 = a4[0], a1 = a4[1], b0 = b4[0], b1 = b4[1];
+      pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w; pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+      pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
+    }
+  };
+  auto halo_write = [&](int buf, auto K) {
+    constexpr int k = decltype(K)::value;
+    if (k * 64 + 63 < HALO || prow + k * 64 < HALO) {
+      float v[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      if (L.pro_a) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = silu_fast(fmaf(v[u], pa[u], pb[u]));
+      }
+      if (hsrc[k] < 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = 0.0f;
+      }
+      uint4 vh, vl;
+#if PRG_SPLIT_EXP == 2      // ablation: no split arithmetic
+      vh = __builtin_bit_cast(uint4, h0); vl = __builtin_bit_cast(uint4, h1);
+#else
+      split8(v, vh, vl);
+#endif
+      char* p = Ah + buf * HBYTES + w_lane + k * 64 * PITCH;
+      *reinterpret_cast<uint4*>(p) = vh;
+      *reinterpret_cast<uint4*>(p + 64) = vl;
+    }
+  };
+
+  // Weight tiles: the LDS destination of a global_load_lds wave-instruction is lane-linear (base + lane * 16 = eight 128-byte
+  // rows), so the XOR swizzle the fragment reads apply sits on the per-lane SOURCE address: LDS unit p of row n holds source
+  // unit p ^ ((n >> 1) & 7).
+  const char* wtile = reinterpret_cast<const char*>(L.w_split + (size_t)tn * BN * 64);
+  const size_t wstep = (size_t)d.CoutPad * 128;                                   // bytes between (tap, chunk) tiles
+  int wsrc[WPW];
+#pragma unroll
+  for (int r = 0; r < WPW; ++r) {
+    const int n = (wave * WPW + r) * 8 + (lane >> 3);
+    wsrc[r] = n * 128 + (((lane & 7) ^ ((n >> 1) & 7)) << 4);
+  }
+  auto gload_b = [&](int chunk, int tap, int slot) {
+    const char* p = wtile + (size_t)(tap * L.split_kchunks + chunk) * wstep;
+#pragma unroll
+    for (int r = 0; r < WPW; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
+                                       (__attribute__((address_space(3))) void*)(Bs + (slot * BN + (wave * WPW + r) * 8) * 128), 16, 0, 0);
+  };
+
+  f32x16 acc[2], tot[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[j][e] = 0.0f; tot[j][e] = 0.0f; }
+
+  const int niter = nchunks * 9;
+  // weight tiles 0 .. NS - 1 and chunk 0's halo (all passes in flight at once: one HBM latency per tile, not NH)
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+    if (t < niter) gload_b(t / 9, t % 9, t);
+  pro_load(0);
+  {
+    float4 g0[NH], g1[NH];
+    const bool first = q * 8 < d.C0;
+    const float* base = first ? L.src0 : L.src1;
+    const int Cs = first ? d.C0 : d.C1, cc = first ? q * 8 : q * 8 - d.C0;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      if (hsrc[k] >= 0) {
+        const float4* p = reinterpret_cast<const float4*>(base + (size_t)hsrc[k] * Cs + cc);
+        g0[k] = p[0];
+        g1[k] = p[1];
+      } else {
+        g0[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    auto wr = [&](auto K) {
+      h0 = g0[decltype(K)::value];
+      h1 = g1[decltype(K)::value];
+      halo_write(0, K);
+    };
+    wr(IC<0>()); wr(IC<1>()); wr(IC<2>());
+    if constexpr (NH > 3) wr(IC<3>());
+    if constexpr (NH > 4) wr(IC<4>());
+    if constexpr (NH > 5) wr(IC<5>());
+    if constexpr (NH > 6) wr(IC<6>());
+  }
+
+  f16x8 fa[2][2][2], fw[2][2][4];               // [register set][k16 step][A: hi, lo | W: (hi, lo) x column tile]
+  // fragment loads of (chunk buffer cb, tap T) into register set S; ring slot T % NS (9 taps per chunk and NS = 3) or runtime
+  auto reads = [&](auto SET, auto TAP, int cb, int slot) {
+    constexpr int S = decltype(SET)::value, T = decltype(TAP)::value;
+    constexpr int toff = ((T / 3) * HP + (T % 3)) * PITCH;
+    const char* A = Ah + cb * HBYTES + a_lane + toff;
+    const char* Bb = Bs + slot * (BN * 128);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      fa[S][st][0] = ld_frag(reinterpret_cast<const uint4*>(A + st * 32));
+      fa[S][st][1] = ld_frag(reinterpret_cast<const uint4*>(A + st * 32 + 64));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        fw[S][st][2 * j] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][0] + j * 4096));
+        fw[S][st][2 * j + 1] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][1] + j * 4096));
+      }
+    }
+  };
+  auto mfmas = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#if PRG_SPLIT_EXP == 1      // ablation: no MFMAs (keep the fragment loads alive)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j][0] += (float)(fa[S][st][0][0] + fa[S][st][1][1] + fw[S][st][2 * j][2] + fw[S][st][2 * j + 1][3]);
+#else
+      // term-major: back-to-back MFMAs never wait on the same accumulator; the two cross terms first (small), then hi * hi
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][st][1], fw[S][st][2 * j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][st][0], fw[S][st][2 * j + 1], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][st][0], fw[S][st][2 * j], acc[j], 0, 0, 0);
+#endif
+    }
+  };
+
+  // one tap of chunk c; P = parity of the chunk (register set of tap T = (T + P) & 1)
+  auto body = [&](auto PAR, auto TAP, int c) {
+    constexpr int P = decltype(PAR)::value, T = decltype(TAP)::value, S = (T + P) & 1;
+    const int it = c * 9 + T;
+    const bool more = c + 1 < nchunks;
+    // (1) all but the newest weight prefetch (tile it + 2, issued by the previous body AFTER its halo pass) have landed — tile
+    //     it + 1 in particular, and that halo pass; this wave's fragment loads of `it` and staging ds_writes are done.
+    //     A RAW s_barrier: __syncthreads() makes hipcc drain vmcnt(0) in front of it while an LDS-DMA is in flight, i.e. a
+    //     prefetch distance of zero.  The asm's memory clobber keeps LDS accesses on their side of it.  hipcc floats this
+    //     tap's MFMAs (register-only) to just behind the barrier, in front of the staging code: measured the best order —
+    //     pinning them in front of the wait (accumulators as asm operands) cost 20-35 % (355 / 395 us against 286 us at
+    //     level 0): the wave then issues nothing else for 384 cycles and meets the barrier late.
+    if (NS == 3 && (T + 2 < 9 || more)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // tile it + 1 is visible; nobody still reads tile it's ring slot or the previous chunk's halo
+#if PRG_SPLIT_EXP != 5
+    if (more) {
+      // (2) the next chunk's halo, one pass per tap: written one tap after its load, into the other halo buffer
+      if constexpr (T == 0) pro_load(c + 1);
+      if constexpr (T >= 1 && T <= NH) halo_write((c + 1) & 1, IC<T - 1>());
+      if constexpr (T < NH) halo_load(c + 1, IC<T>());
+    }
+#endif
+#if PRG_SPLIT_EXP != 4
+    // (3) weight tile it + NS into the slot tile `it` just vacated
+    if constexpr (T + NS < 9) gload_b(c, T + NS, NS == 3 ? T % 3 : it & 1);
+    else if (more) gload_b(c + 1, T + NS - 9, NS == 3 ? T % 3 : it & 1);
+#endif
+    // (4) fragments of the next tap into the other register set, (5) the MFMAs of this tap
+    if constexpr (T < 8) reads(IC<1 - S>(), IC<T + 1>(), c & 1, NS == 3 ? (T + 1) % 3 : (it + 1) & 1);
+    else if (more) reads(IC<1 - S>(), IC<0>(), (c + 1) & 1, NS == 3 ? 0 : (it + 1) & 1);
+    mfmas(IC<S>());
+    if constexpr (T == 8) {                    // the 288-term partial of this channel chunk
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { tot[j][e] += acc[j][e]; acc[j][e] = 0.0f; }
+    }
+  };
+  auto chunk_body = [&](auto PAR, int c) {
+    body(PAR, IC<0>(), c); body(PAR, IC<1>(), c); body(PAR, IC<2>(), c);
+    body(PAR, IC<3>(), c); body(PAR, IC<4>(), c); body(PAR, IC<5>(), c);
+    body(PAR, IC<6>(), c); body(PAR, IC<7>(), c); body(PAR, IC<8>(), c);
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  reads(IC<0>(), IC<0>(), 0, 0);
+  for (int c = 0; c < nchunks; c += 2) {
+    chunk_body(IC<0>(), c);
+    if (c + 1 < nchunks) chunk_body(IC<1>(), c + 1);
+  }
+
+  double gs, gq;
+  auto row_to_m = [&](int r) -> int64_t {
+    const int p = wave * 32 + r;
+    return ((int64_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+  };
+#if PRG_SPLIT_EXP == 3        // ablation: no epilogue (one store per lane keeps the accumulators alive)
+  float sum = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sum += tot[0][e] + tot[1][e];
+  L.out[(size_t)row_to_m(l31) * d.Cout + tn * BN + hi] = sum;
+  return;
+#endif
+  f32x16 res[1][2] = {{tot[0], tot[1]}};
+  epilogue_store<float, 1>(L, res, stage + wave * 32 * 68, lane, tn * BN, row_to_m, gs, gq);
+  if (fuse_stats) {
+    const int nsplit = tiles_x * tiles_y;
+    float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
+    epilogue_stats<4, 1>(reinterpret_cast<double*>(stage + NW * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather form (1x1, 4x4 stride 2, small / ragged shapes): structure of conv_igemm_kernel (conv.hip)
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, bool ONE>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaunch<float> L, const int M, const int tiles_m,
+                                                                  const int tiles_n, const int fuse_stats) {
+  constexpr int BK = 32;
+  constexpr int AP = BM / 64, NB = BN * 8 / 256;
+  constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M, TM = WM / 32;
+  static_assert(TM >= 1, "wave tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* As = reinterpret_cast<uint4*>(smem);   // [2][BM][8]
+  uint4* Bs = As + 2 * BM * 8;                  // [2][BN][8]
+  float* stage = reinterpret_cast<float*>(smem);
+
+  const ConvDesc& d = L.d;
+  const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tn = lin % tiles_n, tm = lin / tiles_n;
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 2, q = tid & 3;
+  const int Cin = d.C0 + d.C1;
+  const int Hl = d.ups ? 2 * d.Hin : d.Hin, Wl = d.ups ? 2 * d.Win : d.Win;
+  const int HWo = d.Hout * d.Wout;
+
+  int a_iy0[AP], a_ix0[AP], a_base[AP];
+  bool a_ok[AP];
+  const float* a_p0[AP];
+  const float* a_p1[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = tm * BM + lrow + i * 64;
+    a_ok[i] = m < M;
+    const int mm = a_ok[i] ? m : 0;
+    if constexpr (ONE) {
+      a_p0[i] = L.src0 + (int64_t)mm * d.C0 + q * 8;
+      a_p1[i] = d.C1 ? L.src1 + (int64_t)mm * d.C1 + q * 8 - d.C0 : a_p0[i];
+    } else {
+      const int bb = mm / HWo, rem = mm - bb * HWo;
+      const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
+      a_iy0[i] = oy * d.stride - d.pad;
+      a_ix0[i] = ox * d.stride - d.pad;
+      a_base[i] = bb * d.Hin * d.Win;
+    }
+  }
+
+  float4 ra[AP][2];
+  uint4 rb[NB];
+  const int niter = d.KH * d.KW * L.split_kchunks;
+  auto gload = [&](int tap, int kc) {
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int c = kc * BK + q * 8;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const float* p = nullptr;
+      if constexpr (ONE) {
+        if (a_ok[i] && c < Cin) p = (c < d.C0 ? a_p0[i] : a_p1[i]) + kc * BK;
+      } else {
+        int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl && c < Cin;
+        if (d.ups) { iy >>= 1; ix >>= 1; }
+        if (ok) {
+          const int64_t pix = (int64_t)a_base[i] + (int64_t)iy * d.Win + ix;
+          p = (c < d.C0) ? L.src0 + pix * d.C0 + c : L.src1 + pix * d.C1 + (c - d.C0);
+        }
+      }
+      if (p) {
+        ra[i][0] = reinterpret_cast<const float4*>(p)[0];
+        ra[i][1] = reinterpret_cast<const float4*>(p)[1];
+      } else {
+        ra[i][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const uint4* wt = reinterpret_cast<const uint4*>(L.w_split + ((size_t)(tap * L.split_kchunks + kc) * d.CoutPad + (size_t)tn * BN) * 64);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = wt[tid + j * 256];
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  f32x16 acc[TM][2], tot[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }
+
+  int tap = 0, kc = 0;
+  gload(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    uint4* Ab = As + (it & 1) * BM * 8;
+    uint4* Bb = Bs + (it & 1) * BN * 8;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int r = lrow + i * 64, sw = (r >> 1) & 7;
+      const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+      uint4 vh, vl;
+      split8(v, vh, vl);
+      Ab[r * 8 + (q ^ sw)] = vh;
+      Ab[r * 8 + ((4 + q) ^ sw)] = vl;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int u = tid + j * 256, n = u >> 3, slot = u & 7;
+      Bb[n * 8 + (slot ^ ((n >> 1) & 7))] = rb[j];
+    }
+    __syncthreads();
+    if (++kc == L.split_kchunks) { kc = 0; ++tap; }
+    if (it + 1 < niter) gload(tap, kc);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int unit = 2 * st + hi;
+      f16x8 ah[TM], al[TM], wh[2], wl[2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31, sw = (r >> 1) & 7;
+        ah[i] = ld_frag(Ab + r * 8 + (unit ^ sw));
+        al[i] = ld_frag(Ab + r * 8 + ((4 + unit) ^ sw));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + j * 32 + l31, sw = (n >> 1) & 7;
+        wh[j] = ld_frag(Bb + n * 8 + (unit ^ sw));
+        wl[j] = ld_frag(Bb + n * 8 + ((4 + unit) ^ sw));
+      }
+      mma3_tiles<TM>(ah, al, wh, wl, acc);
+    }
+    if ((it & 7) == 7 || it + 1 == niter) flush_acc<TM>(acc, tot);   // 256-term partials
+  }
+
+  double gs, gq;
+  auto row_to_m = [&](int r) -> int64_t {
+    const int m = tm * BM + wm * WM + r;
+    return m < M ? (int64_t)m : (int64_t)-1;
+  };
+  epilogue_store<float, TM>(L, tot, stage + wave * 32 * 68, lane, tn * BN + wn * 64, row_to_m, gs, gq);
+  if (fuse_stats) {
+    const int nsplit = HWo / BM;
+    const int bimg = (tm * BM) / HWo, slab = tm - bimg * nsplit;
+    float* dst = L.gn_partials + ((size_t)bimg * nsplit + slab) * L.gn_groups * 2;
+    epilogue_stats<WAVES_M, WAVES_N>(reinterpret_cast<double*>(stage + 4 * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout,
+                                     L.gn_groups, dst);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------
+template <int TH, int TW>
+static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse_stats, int* nsplit) {
+  constexpr int HALO = (TH + 2) * (TW + 2);
+  constexpr int NS = (2 * HALO * 144 + 3 * 8192) * 2 <= 160 * 1024 ? 3 : 2;   // weight ring slots: two workgroups must fit a CU
+  const ConvDesc& d = L.d;
+  const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH, tiles_n = d.Cout / 64;
+  size_t lds = (size_t)2 * HALO * 144 + NS * 8192;
+  if (lds < kEpilogueLds) lds = kEpilogueLds;
+  if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
+  static std::atomic<bool> attr_done{false};   // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race between lanes is benign)
+  if (!attr_done.load(std::memory_order_acquire)) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<TH, TW, NS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_done.store(true, std::memory_order_release);
+  }
+  conv3x3_split_kernel<TH, TW, NS><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+template <int BM, int BN>
+static int launch_split_igemm(const ConvLaunch<float>& L, int M, hipStream_t s, int want_stats, int* nsplit) {
+  const ConvDesc& d = L.d;
+  const int tiles_m = ceil_div(M, BM), tiles_n = d.CoutPad / BN;
+  const int HWo = d.Hout * d.Wout;
+  const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
+  const int fuse = want_stats && cpg % 8 == 0 && cpg <= BN && HWo % BM == 0 && HWo / BM <= kGnMaxSplit;
+  if (nsplit) *nsplit = fuse ? HWo / BM : 0;
+  size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
+  if (lds < kEpilogueLds) lds = kEpilogueLds;
+  const bool one = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ups;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_kernel<BM, BN, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_kernel<BM, BN, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_done = true;
+  }
+  if (one) conv_igemm_split_kernel<BM, BN, true><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse);
+  else conv_igemm_split_kernel<BM, BN, false><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+// 1 = launched, 0 = shape not covered (the exact-f32 kernels of conv.hip run it), < 0 = error
+int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsplit_out) {
+  if (!L.w_split) return 0;
+  const ConvDesc& d = L.d;
+  if (d.Cout % 8 || d.C0 % 8 || d.C1 % 8 || L.res_a || L.res_fold.acc || L.pro_fold.acc) return 0;
+  const int64_t M64 = (int64_t)d.B * d.Hout * d.Wout;
+  if ((int64_t)d.B * d.Hin * d.Win >= ((int64_t)1 << 31) || M64 >= ((int64_t)1 << 31)) return 0;
+  const int M = (int)M64;
+  const int want_stats = L.gn_partials != nullptr;
+  int rc = PRG_OK;
+  const bool halo = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.C0 % 32 == 0 && d.C1 % 32 == 0 && d.Cout % 64 == 0;
+  if (halo) {
+    const int H = d.Hout, W = d.Wout;
+    const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
+    auto fuse = [&](int TH, int TW, int BN) {
+      return want_stats && cpg % 8 == 0 && cpg <= BN && (W / TW) * (H / TH) <= kGnMaxSplit;
+    };
+    static const int pref32 = [] { const char* e = std::getenv("PRG_SPLIT_TW32"); return e ? std::atoi(e) : 0; }();
+    if (pref32 && W % 32 == 0 && H % 4 == 0) { rc = launch_split_halo<4, 32>(L, s, fuse(4, 32, 64), gn_nsplit_out); return rc ? rc : 1; }
+    if (W % 16 == 0 && H % 8 == 0) { rc = launch_split_halo<8, 16>(L, s, fuse(8, 16, 64), gn_nsplit_out); return rc ? rc : 1; }
+    if (W % 32 == 0 && H % 4 == 0) { rc = launch_split_halo<4, 32>(L, s, fuse(4, 32, 64), gn_nsplit_out); return rc ? rc : 1; }
+  }
+  if (L.pro_a) return 0;                       // (a fused prologue is only requested where pick_halo<float> = the test above holds)
+  if (d.CoutPad % 128 == 0) rc = launch_split_igemm<128, 128>(L, M, s, want_stats, gn_nsplit_out);
+  else rc = launch_split_igemm<128, 64>(L, M, s, want_stats, gn_nsplit_out);
+  return rc ? rc : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing (host): [tap][32-channel chunk][CoutPad][32 hi | 32 lo] as f16 bit patterns, zero padded
+// ---------------------------------------------------------------------------------------------
+static inline uint16_t f16_bits(_Float16 h) {
+  uint16_t u;
+  std::memcpy(&u, &h, 2);
+  return u;
+}
+void pack_conv_weight_split(const float* w, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out, int* CoutPad, int* kchunks32) {
+  const int cp = (Cout + 63) / 64 * 64;
+  const int kcn = (Cin + 31) / 32;
+  out.assign((size_t)KH * KW * kcn * cp * 64, 0);
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw)
+      for (int kc = 0; kc < kcn; ++kc)
+        for (int n = 0; n < Cout; ++n)
+          for (int k = 0; k < 32; ++k) {
+            const int c = kc * 32 + k;
+            if (c >= Cin) break;
+            const float v = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw];
+            const _Float16 h = (_Float16)v;                       // round to nearest even (compiler-rt / F16C)
+            const _Float16 l = (_Float16)(v - (float)h);
+            const size_t row = ((((size_t)(kh * KW + kw)) * kcn + kc) * cp + n) * 64;
+            out[row + k] = f16_bits(h);
+            out[row + 32 + k] = f16_bits(l);
+          }
+  *CoutPad = cp;
+  *kchunks32 = kcn;
+}
+
+}  // namespace prg

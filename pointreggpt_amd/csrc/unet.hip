@@ -97,6 +97,8 @@ struct ConvP {
   int64_t mx_soff = -1;
   int64_t s2d_off = -1;    // 4x4 / stride 2 convs (bf16): element offset of the equivalent 2x2-tap packing (ConvLaunch::w_s2d)
   int s2d_kchunks = 0;
+  int64_t sp_off = -1;     // f16x3 mode: element offset of the hi / lo f16 split packing (ConvLaunch::w_split)
+  int sp_kchunks = 0;
 };
 struct ResP {
   int cin = 0, cout = 0;
@@ -267,6 +269,7 @@ struct prg_unet {
   float* d_kshift = nullptr;    // fused linear attention: static softmax shifts of the k columns
   uint8_t* d_mx = nullptr;      // MX-fp8 conv weights (dtype PRG_MXFP8): e4m3 data and E8M0 block scales
   uint8_t* d_mx_scale = nullptr;
+  uint16_t* d_split = nullptr;  // f16x3 mode (dtype PRG_F16X3): every conv weight as f16 hi / lo halves (conv_split.hip)
   float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
   int* d_tickets = nullptr;     // [kMaxTicketImages] per-image arrival counters of the conv kernels that fold GroupNorm coefficients (self-resetting)
   // fixed-point GroupNorm statistics (common.h, GnFold; bf16 / mxfp8 handles)
@@ -347,6 +350,8 @@ struct UnetImpl : prg_unet {
     L.mx_pure = 0;
     L.w_s2d = (p.s2d_off >= 0 && stride == 2 && pad == 1) ? reinterpret_cast<const T*>(d_packed) + p.s2d_off : nullptr;
     L.s2d_kchunks = p.s2d_kchunks;
+    L.w_split = (d_split && p.sp_off >= 0) ? d_split + p.sp_off : nullptr;
+    L.split_kchunks = p.sp_kchunks;
     L.gn = o.gn ? *o.gn : GnApply{};
     L.gn_coef_a = o.gn ? o.coef_a : nullptr; L.gn_coef_b = o.gn ? o.coef_b : nullptr;
     L.gn_tickets = (o.gn && gn_fold_enabled()) ? d_tickets : nullptr;
@@ -838,7 +843,7 @@ static void collect_convs(Layout& L, std::vector<ConvP*>& convs) {
 }
 
 template <typename T>
-static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t n, prg_unet** out, bool mx = false) {
+static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t n, prg_unet** out, bool mx = false, bool split = false) {
   std::unique_ptr<UnetImpl<T>> u(new UnetImpl<T>());
   int rc = build_layout(*cfg, u->lay);
   if (rc) return rc;
@@ -895,6 +900,24 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       PRG_HIP(hipMemcpy(u->d_mx, data.data(), data.size(), hipMemcpyHostToDevice));
       PRG_HIP(hipMemcpy(u->d_mx_scale, scales.data(), scales.size(), hipMemcpyHostToDevice));
     }
+  }
+  if (split) {
+    // f16x3 mode: hi / lo f16 halves of every conv weight (standardised first where the Block does), conv_split.hip
+    std::vector<ConvP*> convs;
+    collect_convs(u->lay, convs);
+    std::vector<uint16_t> data, one;
+    std::vector<float> tmp;
+    for (ConvP* p : convs) {
+      const float* w = weights + p->w_flat;
+      if (p->ws) { standardize(w, p->Cout, p->Cin * p->KH * p->KW, tmp); w = tmp.data(); }
+      int cp = 0;
+      pack_conv_weight_split(w, p->Cout, p->Cin, p->KH, p->KW, one, &cp, &p->sp_kchunks);
+      p->sp_off = (int64_t)((data.size() + 127) / 128 * 128);
+      data.resize((size_t)p->sp_off + one.size());
+      std::memcpy(data.data() + p->sp_off, one.data(), one.size() * sizeof(uint16_t));
+    }
+    if (hipMalloc(&u->d_split, data.size() * sizeof(uint16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split weights)");
+    PRG_HIP(hipMemcpy(u->d_split, data.data(), data.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   if (std::is_same<T, bf16_t>::value) {
     // fixed-point GroupNorm statistics (common.h, GnFold): P = gamma, Q = beta of every norm in 16-byte aligned rows (what
@@ -1030,7 +1053,7 @@ static int reserve(prg_unet* h, int B, int S) {
   ++h->arena_gen;
   h->resB = nb;
   h->resS = ns;
-  if (h->dtype != PRG_F32 && h->d_pq_static) {
+  if (h->d_pq_static) {   // (bf16 / mxfp8 handles only)
     // fixed-point GroupNorm accumulators: two norms per ResnetBlock, [slots][resB][groups][2] int64
     if (h->d_gnacc) PRG_HIP(hipFree(h->d_gnacc));
     h->d_gnacc = nullptr;
@@ -1147,12 +1170,13 @@ int64_t prg_unet_param_count(const prg_unet_config* cfg) {
 
 int prg_unet_create(const prg_unet_config* cfg, const float* weights, int64_t n_floats, int dtype, prg_unet** out) {
   PRG_CHECK(cfg && weights && out, "prg_unet_create: null pointer");
-  PRG_CHECK(dtype == PRG_F32 || dtype == PRG_BF16 || dtype == PRG_MXFP8, "prg_unet_create: dtype must be PRG_F32, PRG_BF16 or PRG_MXFP8");
+  PRG_CHECK(dtype == PRG_F32 || dtype == PRG_BF16 || dtype == PRG_MXFP8 || dtype == PRG_F16X3,
+            "prg_unet_create: dtype must be PRG_F32, PRG_BF16, PRG_MXFP8 or PRG_F16X3");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PRG_E_HIP, "prg_unet_create: no HIP device");
   *out = nullptr;
-  int rc = dtype == PRG_F32 ? create_impl<float>(cfg, weights, n_floats, out)
-                            : create_impl<bf16_t>(cfg, weights, n_floats, out, dtype == PRG_MXFP8);
+  int rc = (dtype == PRG_F32 || dtype == PRG_F16X3) ? create_impl<float>(cfg, weights, n_floats, out, false, dtype == PRG_F16X3)
+                                                     : create_impl<bf16_t>(cfg, weights, n_floats, out, dtype == PRG_MXFP8);
   if (rc == PRG_OK) (*out)->dtype = dtype;
   return rc;
 }
@@ -1168,6 +1192,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_freqs) (void)hipFree(h->d_freqs);
   if (h->d_mx) (void)hipFree(h->d_mx);
   if (h->d_mx_scale) (void)hipFree(h->d_mx_scale);
+  if (h->d_split) (void)hipFree(h->d_split);
   if (h->d_tickets) (void)hipFree(h->d_tickets);
   if (h->d_gnacc) (void)hipFree(h->d_gnacc);
   if (h->d_pq_static) (void)hipFree(h->d_pq_static);
@@ -1242,12 +1267,56 @@ int prg_maskunet_forward(prg_unet* h, const float* depth, float* prob, int B, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// float32-storage handles (PRG_F32: the exact-f32 kernels; PRG_F16X3: the split-operand kernels of conv_split.hip)
+static int debug_conv_f32(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                          int dtype, int K, int stride, int pad, hipStream_t s) {
+  const size_t M = (size_t)B * H * W;
+  const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+  const size_t Mo = (size_t)B * Ho * Wo;
+  std::vector<float> packed;
+  std::vector<uint16_t> sp;
+  int cp = 0, kc = 0, cp2 = 0, kc32 = 0;
+  pack_conv_weight<float>(w, Cout, Cin, K, K, packed, &cp, &kc);
+  if (dtype == PRG_F16X3) pack_conv_weight_split(w, Cout, Cin, K, K, sp, &cp2, &kc32);
+  std::vector<float> zb(Cout, 0.0f);
+  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_sp = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_sp}) if (p) (void)hipFree(p); };
+  if (hipMalloc(&d_in, M * Cin * 4) != hipSuccess || hipMalloc(&d_out, Mo * Cout * 4) != hipSuccess ||
+      hipMalloc(&d_w, packed.size() * 4) != hipSuccess || hipMalloc(&d_b, Cout * 4) != hipSuccess ||
+      (!sp.empty() && hipMalloc(&d_sp, sp.size() * 2) != hipSuccess)) {
+    cleanup();
+    return fail(PRG_E_NOMEM, "prg_debug_conv: hipMalloc failed");
+  }
+  if (hipMemcpy(d_w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_b, bias ? bias : zb.data(), Cout * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      (d_sp && hipMemcpy(d_sp, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) != hipSuccess)) {
+    cleanup();
+    return fail(PRG_E_HIP, "prg_debug_conv: hipMemcpy failed");
+  }
+  int rc = launch_nchw_f32_to_nhwc<float>(x, reinterpret_cast<float*>(d_in), B, H * W, Cin, s);
+  if (rc == PRG_OK) {
+    ConvLaunch<float> L{};
+    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = 0; L.d.KH = K; L.d.KW = K; L.d.stride = stride; L.d.pad = pad;
+    L.d.Hout = Ho; L.d.Wout = Wo; L.d.Cout = Cout; L.d.CoutPad = cp; L.d.kchunks = kc;
+    L.src0 = reinterpret_cast<const float*>(d_in); L.w = reinterpret_cast<const float*>(d_w);
+    L.bias = reinterpret_cast<const float*>(d_b); L.out = reinterpret_cast<float*>(d_out);
+    L.gn_groups = 8;
+    L.w_split = reinterpret_cast<const uint16_t*>(d_sp); L.split_kchunks = kc32;
+    rc = launch_conv<float>(L, s, nullptr);
+  }
+  if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<float>(reinterpret_cast<const float*>(d_out), out, B, Ho * Wo, Cout, s);
+  if (hipStreamSynchronize(s) != hipSuccess && rc == PRG_OK) rc = fail(PRG_E_HIP, "prg_debug_conv: stream synchronise failed");
+  cleanup();
+  return rc;
+}
+
 static int debug_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                       int dtype, int K, int stride, void* stream) {
   PRG_CHECK(x && w && out, "prg_debug_conv3x3: null pointer");
   PRG_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0, "prg_debug_conv3x3: bad shape");
-  PRG_CHECK(dtype == PRG_BF16 || dtype == PRG_MXFP8, "prg_debug_conv3x3: dtype must be PRG_BF16 or PRG_MXFP8");
+  PRG_CHECK(dtype == PRG_BF16 || dtype == PRG_MXFP8 || dtype == PRG_F32 || dtype == PRG_F16X3, "prg_debug_conv3x3: bad dtype");
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == PRG_F32 || dtype == PRG_F16X3) return debug_conv_f32(x, w, bias, out, B, Cin, Cout, H, W, dtype, K, stride, K == 1 ? 0 : 1, s);
   const size_t M = (size_t)B * H * W;
   const int Ho = H / stride, Wo = W / stride;
   const size_t Mo = (size_t)B * Ho * Wo;
@@ -1310,6 +1379,14 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
 int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                       int dtype, void* stream) {
   return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, dtype, 3, 1, stream);
+}
+
+int prg_debug_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                   int dtype, int K, int stride, void* stream) {
+  PRG_CHECK((K == 1 || K == 3 || K == 4) && (stride == 1 || stride == 2), "prg_debug_conv: K must be 1, 3 or 4, stride 1 or 2");
+  PRG_CHECK(dtype == PRG_F32 || dtype == PRG_F16X3 || K != 1, "prg_debug_conv: 1x1 convs only in the float32-storage modes");
+  PRG_CHECK(stride == 1 || (H % 2 == 0 && W % 2 == 0), "prg_debug_conv: odd image size");
+  return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, dtype, K, stride, stream);
 }
 
 int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,

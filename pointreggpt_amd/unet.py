@@ -21,7 +21,7 @@ from . import _lib
 from .weights import UnetConfig, maskunet_config, param_spec, synth_state_dict, unet_config
 
 _DTYPES = {"fp32": _lib.PRG_F32, "f32": _lib.PRG_F32, "float32": _lib.PRG_F32, "bf16": _lib.PRG_BF16,
-           "bfloat16": _lib.PRG_BF16, "mxfp8": _lib.PRG_MXFP8}
+           "bfloat16": _lib.PRG_BF16, "mxfp8": _lib.PRG_MXFP8, "f16x3": _lib.PRG_F16X3}
 
 
 def _cfg_c(cfg: UnetConfig) -> _lib.UnetConfigC:
