@@ -41,7 +41,8 @@ def golden():
 
 
 LONG_CHAINS = {"G19_chain1000_ancestral_64": dict(S=64, steps=None, batch=64), "G20_ddim250_128": dict(S=128, steps=250, batch=64),
-               "G21_ddim250_256": dict(S=256, steps=250, batch=16), "G22_chain1000_ancestral_128": dict(S=128, steps=None, batch=64)}
+               "G21_ddim250_256": dict(S=256, steps=250, batch=16), "G22_chain1000_ancestral_128": dict(S=128, steps=None, batch=64),
+               "G21b_ddim250_256": dict(S=256, steps=250, batch=16)}
 
 
 def regenerate_chain_noise(g):

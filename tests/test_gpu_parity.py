@@ -1289,14 +1289,18 @@ def test_bench_contract_line(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
                         "--size", "64", "--sampling-steps", "6", "--profile-transitions", "3", "--e2e-batches", "2", "--c4-batch", "2",
-                        "--c4-steps", "1", "--no-cpu-baseline", "--no-drift"], cwd=tmp_path, capture_output=True, text=True, timeout=1200)
+                        "--c4-steps", "1", "--no-cpu-baseline", "--no-drift", "--parity-transitions", "4"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "e2e_files", "configs4", "workload"):
+              "data", "config", "roofline", "e2e_files", "configs4", "workload", "parity_mode"):
         assert k in j, k
+    pm = j["parity_mode"]
+    assert pm["fp32"]["dtype"] == "fp32" and pm["f16x3"]["dtype"] == "f16x3" and pm["fp32"]["timed_transitions"] == 4
+    assert pm["fp32"]["pairs_per_s"] > 0 and pm["f16x3"]["roofline"]["peak"] == 2500.0 / 3 and pm["fp32"]["roofline"]["peak"] == 157.3
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
     assert j["vs_baseline"] is None and j["dtype"] == "bf16" and j["data"] == "synthetic" and j["unit"] == "pairs/s"
     assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["streams"] == 2
@@ -1307,3 +1311,27 @@ def test_bench_contract_line(tmp_path):
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] > 0
     assert j["e2e_files"]["files_written"] == 9 * 8 * (2 + 2) and j["e2e_files"]["gt_log"]["lines"] >= 0
     assert j["configs4"]["dtype"] == "mxfp8" and j["configs4"]["config"]["image_size"] == 256 and j["configs4"]["roofline"]["peak"] == 5000.0
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (round-3 VERDICT: the flag used to be parsed and
+    ignored).  One device here, so the gloo rehearsal backend lets the ranks share it: exactly one JSON line, n_gpus == 2,
+    value = pairs of both ranks / max-over-ranks time.  Without the rehearsal backend the same command must refuse loudly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8", "--size", "64",
+           "--sampling-steps", "4", "--no-roofline", "--no-e2e-files", "--no-drift", "--no-configs4", "--no-cpu-baseline", "--no-parity-mode"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900, env=dict(env, PRG_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak"
+    assert abs(j["value"] - 2 * 8 / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "HIP device" in r.stderr
