@@ -18,6 +18,7 @@
 // parity kernels' own.  Reference: Block.proj / res_conv / to_qkv / to_out / Downsample / Upsample, sd:583-796.
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -130,7 +131,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int NH = (HALO + 63) / 64;         // staging passes per chunk (64 halo pixels each)
   constexpr int HBYTES = HALO * PITCH;
   constexpr int WPW = BN / 8 / NW;             // global_load_lds wave-instructions (8 rows each) per wave and weight tile
-  static_assert(TH * TW == 128 && NH + 1 <= 8 && (NS == 2 || NS == 3), "tile");
+  constexpr int DIST = 8 - NH;                 // taps between a staging pass's load and its conversion / LDS write (last write at tap 7:
+                                               // tap 8's body already issues the next chunk's first fragment loads)
+  static_assert(TH * TW == 128 && NH <= 4 && (NS == 2 || NS == 3), "tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Ah = smem;                                 // [2][HALO] rows of PITCH bytes: units 0-3 hi, 4-7 lo
@@ -139,8 +142,19 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   const ConvDesc& d = L.d;
   const int nblk = tiles_x * tiles_y * tiles_n * d.B;
-  int lin = xcd_remap(blockIdx.x, nblk);
-  const int tn = lin % tiles_n; lin /= tiles_n;
+  // Workgroup b runs on XCD b % 8 (observed).  With 2 / 4 / 8 output-channel tiles every XCD is pinned to ONE of them, so its
+  // 4 MB L2 holds that tile's weight slice (512 -> 512: 1.2 MB of the 9.4 MB set) instead of streaming the whole set through;
+  // otherwise each XCD gets a contiguous run of tiles (xcd_remap).
+  int tn, lin;
+  if (tiles_n > 1 && 8 % tiles_n == 0 && nblk % 8 == 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = 8 / tiles_n;
+    tn = xcd % tiles_n;
+    lin = idx * per + xcd / tiles_n;
+  } else {
+    lin = xcd_remap(blockIdx.x, nblk);
+    tn = lin % tiles_n;
+    lin /= tiles_n;
+  }
   const int tx = lin % tiles_x; lin /= tiles_x;
   const int ty = lin % tiles_y;
   const int b = lin / tiles_y;
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int w_lane = prow * PITCH + q * 16;                                        // staging write: + pass * 64 * PITCH (+ 64: lo)
 
   // one staging pass: load (global -> registers) and, one tap later, prologue + split + write (registers -> LDS)
-  float4 h0, h1;
+  float4 hh0[NH], hh1[NH];                     // one register pair per pass: a pass is written DIST taps after its load
   auto halo_load = [&](int chunk, auto K) {   // always issued (padding lanes read the tensor's first bytes and are zeroed when
     constexpr int k = decltype(K)::value;      // written): the counted vmcnt waits below need a fixed number of loads per body
     const int c = chunk * CH + q * 8;
@@ -187,8 +201,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const float* base = first ? L.src0 : L.src1;
     const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
     const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
-    h0 = p[0];
-    h1 = p[1];
+    hh0[k] = p[0];
+    hh1[k] = p[1];
   };
   float pa[8], pb[8];                          // fused prologue coefficients of this thread's 8 channels (chunk being staged)
   auto pro_load = [&](int chunk) {
@@ -203,6 +217,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto halo_write = [&](int buf, auto K) {
     constexpr int k = decltype(K)::value;
     if (k * 64 + 63 < HALO || prow + k * 64 < HALO) {
+      const float4 h0 = hh0[k], h1 = hh1[k];
       float v[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
       if (L.pro_a) {
 #pragma unroll
@@ -272,8 +287,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
     }
     auto wr = [&](auto K) {
-      h0 = g0[decltype(K)::value];
-      h1 = g1[decltype(K)::value];
+      hh0[decltype(K)::value] = g0[decltype(K)::value];
+      hh1[decltype(K)::value] = g1[decltype(K)::value];
       halo_write(0, K);
     };
     wr(IC<0>()); wr(IC<1>()); wr(IC<2>());
@@ -338,8 +353,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #if PRG_SPLIT_EXP != 5
     if (more) {
       // (2) the next chunk's halo, one pass per tap: written one tap after its load, into the other halo buffer
+      //     (loaded at taps 0 .. NH - 1, written DIST taps later: the loads come from HBM — ~2 us, two to four taps)
       if constexpr (T == 0) pro_load(c + 1);
-      if constexpr (T >= 1 && T <= NH) halo_write((c + 1) & 1, IC<T - 1>());
+      if constexpr (T >= DIST && T < DIST + NH) halo_write((c + 1) & 1, IC<T - DIST>());
       if constexpr (T < NH) halo_load(c + 1, IC<T>());
     }
 #endif
@@ -561,6 +577,11 @@ static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<TH, TW, NS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr_done.store(true, std::memory_order_release);
+    if (std::getenv("PRG_SPLIT_DEBUG")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_split_kernel<TH, TW, NS>, 256, lds);
+      fprintf(stderr, "conv3x3_split_kernel<%d,%d,%d>: %zu bytes of LDS, %d workgroups per CU\n", TH, TW, NS, lds, nb);
+    }
   }
   conv3x3_split_kernel<TH, TW, NS><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
   PRG_LAUNCH_CHECK();
