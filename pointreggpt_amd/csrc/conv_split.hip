@@ -116,6 +116,15 @@ __device__ inline void flush_acc(f32x16 (&acc)[TM][2], f32x16 (&tot)[TM][2]) {
 // MFMAs compiled out: MFMA 105 + LDS reads 53 + L1/TA 47 + split 21 + epilogue 48 us simply added up, identical workgroups
 // run in lockstep and overlap nothing; the first pipelined version 345 us at 8 VALU + 6 SALU instructions per MFMA
 // (rocprofv3 SQ_INSTS_*: address arithmetic and tap bookkeeping); this structure: DESIGN.md section 4.6.
+#if PRG_SPLIT_EXP == 6
+__device__ unsigned long long g_split_trace[16];   // per-phase cycle totals of workgroup 0 / wave 0 (tools/split_ablate.sh 6)
+#define TRACE_T(n) const long long tt##n = clock64()
+#define TRACE_ADD(i, a, b) if (trace_on) tr[i] += (unsigned long long)((b) - (a))
+#else
+#define TRACE_T(n)
+#define TRACE_ADD(i, a, b)
+#endif
+
 template <int N>
 struct IC {
   static constexpr int value = N;
@@ -335,11 +344,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
   };
 
+#if PRG_SPLIT_EXP == 6
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool trace_on = blockIdx.x == 0 && tid == 0;
+  const long long t_begin = clock64();
+#endif
   // one tap of chunk c; P = parity of the chunk (register set of tap T = (T + P) & 1)
   auto body = [&](auto PAR, auto TAP, int c) {
     constexpr int P = decltype(PAR)::value, T = decltype(TAP)::value, S = (T + P) & 1;
     const int it = c * 9 + T;
     const bool more = c + 1 < nchunks;
+    TRACE_T(0);
     // (1) all but the newest weight prefetch (tile it + 2, issued by the previous body AFTER its halo pass) have landed — tile
     //     it + 1 in particular, and that halo pass; this wave's fragment loads of `it` and staging ds_writes are done.
     //     A RAW s_barrier: __syncthreads() makes hipcc drain vmcnt(0) in front of it while an LDS-DMA is in flight, i.e. a
@@ -350,6 +365,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (NS == 3 && (T + 2 < 9 || more)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // tile it + 1 is visible; nobody still reads tile it's ring slot or the previous chunk's halo
+    TRACE_T(1);
 #if PRG_SPLIT_EXP != 5
     if (more) {
       // (2) the next chunk's halo, one pass per tap: written one tap after its load, into the other halo buffer
@@ -359,6 +375,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if constexpr (T < NH) halo_load(c + 1, IC<T>());
     }
 #endif
+    TRACE_T(2);
 #if PRG_SPLIT_EXP != 4
     // (3) weight tile it + NS into the slot tile `it` just vacated
     if constexpr (T + NS < 9) gload_b(c, T + NS, NS == 3 ? T % 3 : it & 1);
@@ -367,7 +384,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // (4) fragments of the next tap into the other register set, (5) the MFMAs of this tap
     if constexpr (T < 8) reads(IC<1 - S>(), IC<T + 1>(), c & 1, NS == 3 ? (T + 1) % 3 : (it + 1) & 1);
     else if (more) reads(IC<1 - S>(), IC<0>(), (c + 1) & 1, NS == 3 ? 0 : (it + 1) & 1);
+    TRACE_T(3);
     mfmas(IC<S>());
+    TRACE_T(4);
+    TRACE_ADD(0, tt0, tt1); TRACE_ADD(1, tt1, tt2); TRACE_ADD(2, tt2, tt3); TRACE_ADD(3, tt3, tt4);
     if constexpr (T == 8) {                    // the 288-term partial of this channel chunk
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -389,6 +409,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (c + 1 < nchunks) chunk_body(IC<1>(), c + 1);
   }
 
+#if PRG_SPLIT_EXP == 6
+  const long long t_loop = clock64();
+#endif
   double gs, gq;
   auto row_to_m = [&](int r) -> int64_t {
     const int p = wave * 32 + r;
@@ -408,6 +431,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
     epilogue_stats<4, 1>(reinterpret_cast<double*>(stage + NW * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
   }
+#if PRG_SPLIT_EXP == 6
+  if (trace_on) {
+    for (int i = 0; i < 4; ++i) g_split_trace[i] = tr[i];
+    g_split_trace[4] = (unsigned long long)(t_loop - t_begin);
+    g_split_trace[5] = (unsigned long long)(clock64() - t_loop);
+    g_split_trace[6] = (unsigned long long)niter;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -585,6 +616,16 @@ static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse
   }
   conv3x3_split_kernel<TH, TW, NS><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
   PRG_LAUNCH_CHECK();
+#if PRG_SPLIT_EXP == 6
+  {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_split_trace), sizeof(h));
+    fprintf(stderr, "trace Cin %d Cout %d %dx%d: iterations %llu | per iteration: wait+barrier %.0f, staging(+floated MFMAs) %.0f, glds+reads %.0f, "
+            "mfma issue %.0f | loop total %llu, epilogue %llu cycles\n", d.C0 + d.C1, d.Cout, d.Hout, d.Wout, h[6], (double)h[0] / h[6], (double)h[1] / h[6],
+            (double)h[2] / h[6], (double)h[3] / h[6], h[4], h[5]);
+  }
+#endif
   return PRG_OK;
 }
 
