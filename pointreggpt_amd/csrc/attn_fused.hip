@@ -17,6 +17,7 @@
 // MFMA: v_mfma_f32_32x32x16_bf16, D[i][j] = sum_k A[i][k] B[k][j]; lane l supplies A[l&31][8(l>>5)..+7] and
 // B[8(l>>5)..+7][l&31] and receives D[(r&3) + 8(r>>2) + 4(l>>5)][l&31] in register r.
 // The LayerNorm gain of PreNorm is folded into the projection weights on the host (unet.hip).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -844,7 +845,7 @@ int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* 
                 const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, hipStream_t s, const GnFold& fold,
                 const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr, int head_sigmoid = 0) {
   const size_t lds = (size_t)kTP * (CIN + 8 + COUT + 8) * 2;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
   if (!attr) {
     int rc = set_lds(&resblock_tail_fused_kernel<CIN, COUT>, lds);
     if (rc) return rc;
@@ -863,7 +864,7 @@ constexpr bool kPsumDefault = C >= 128;   // (measured: C = 64 58 against 70 us 
 template <int C>
 int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias, const float* out_g, bf16_t* out,
              float* ws, int B, int N, const float* kshift, hipStream_t s) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
   if (!attr) {
     int rc;
     if ((rc = set_lds(&la_kmax_fused_kernel<C>, lds_kmax<C>()))) return rc;
@@ -912,7 +913,7 @@ template <int NT, int QS>
 static int launch_attn_big(const bf16_t* qkv, bf16_t* out, int B, hipStream_t s) {
   constexpr int N = 32 * NT;
   constexpr size_t lds = ((size_t)N * 40 + (size_t)32 * (N + 8)) * 2;
-  static bool attr = false;
+  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
   if (!attr) {
     int rc = set_lds(&full_attn_mfma_big_kernel<NT, QS>, lds);
     if (rc) return rc;

@@ -4,6 +4,8 @@
 // every cross-workgroup reduction is done in a fixed order, so results are run-to-run deterministic.
 //
 // sd = denoising_diffusion_pytorch/successive_ddnm_diffusion.py
+#include <atomic>
+
 #include "blocks.h"
 
 namespace prg {
@@ -900,7 +902,7 @@ int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, in
                   int ldy, int R, int I, int O, int act_in, int act_out, hipStream_t s) {
   PRG_CHECK(x && W && y && R > 0 && I > 0 && O > 0, "linear: bad arguments");
   const dim3 grid(ceil_div(O, 4 * kLinOutPerWave), ceil_div(R, kLinRows));
-  static bool attr = false;
+  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
   if (!attr) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinSmem));
     attr = true;

@@ -177,9 +177,20 @@ struct GnFold {
 
 #if defined(__HIPCC__)
 // one wave total (float) -> the image group's accumulator; `which` 0 = sum, 1 = sumsq
+// A NaN / Inf partial must stay visible (float slabs propagated it; __float2ll_rn would turn it into 0 / a saturated value and
+// the norm would emit finite, wrong numbers): a non-finite partial sets the SIGN bit of the group's sum-of-squares accumulator
+// with an atomic OR — a legitimate sum of squares is non-negative and below 2^61, so concurrent adds never carry into that
+// bit and any number of poisoning waves leaves it set — and every consumer's fold answers NaN for such a group.
+constexpr unsigned long long kGnPoison = 0x8000000000000000ull;
 __device__ inline void gn_acc_add(long long* acc, int G, int b, int g, int which, float v) {
+  long long* p = acc + ((size_t)b * G + g) * 2 + which;
+  if (!(fabsf(v) <= 3.0e38f)) {                 // NaN or Inf
+    __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(acc + ((size_t)b * G + g) * 2 + 1), kGnPoison, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const long long q = __float2ll_rn(v * (which ? kGnSqScale : kGnSumScale));
-  __hip_atomic_fetch_add(acc + ((size_t)b * G + g) * 2 + which, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ inline void gn_fold_stats_raw(long long s_fx, long long q_fx, float inv_n, float& mean, float& rstd) {
   const double m = (double)s_fx * (1.0 / 16777216.0) * (double)inv_n;
@@ -187,6 +198,7 @@ __device__ inline void gn_fold_stats_raw(long long s_fx, long long q_fx, float i
   var = var < 0.0 ? 0.0 : var;
   mean = (float)m;
   rstd = __builtin_amdgcn_rsqf((float)var + 1e-5f);
+  if (q_fx < 0) mean = rstd = __builtin_nanf("");   // poisoned by a non-finite partial (gn_acc_add)
 }
 __device__ inline void gn_fold_stats(const GnFold& f, int b, int g, float& mean, float& rstd) {
   const long long* a = f.acc + ((size_t)b * f.G + g) * 2;

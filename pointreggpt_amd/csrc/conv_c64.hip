@@ -23,6 +23,7 @@
 // The epilogue of tile s therefore runs while the producers already write halo s+2 (round 2 had two barriers and an LDS
 // stage: producers idle during the epilogue, consumers idle during the drain — the two were additive, 81 / 122 us).
 // LDS: 2 halos x 340 rows x 144 B (padded rows: conflict-free ds_read_b128 with immediate tap offsets).
+#include <atomic>
 #include <cstdlib>
 
 #include "conv.h"
@@ -496,6 +497,9 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   if (L.residual || !L.bias) return 0;
   if (d.ups) return 0;                                       // (no 64 -> 64 Upsample conv exists in the networks: not a tested shape)
   if (d.Wout % TW || d.Hout % TH) return 0;
+  // the producers address the input through ONE buffer descriptor with 32-bit byte offsets (pixel index * 128 in an SGPR,
+  // num_records as an int): beyond 2 GiB of input the generic kernel (64-bit addressing) runs instead — B = 256 at 256x256
+  if ((size_t)d.B * d.Hin * d.Win * 128 + 4096 >= ((size_t)1 << 31)) return 0;
   const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH;
   const int total = tiles_x * tiles_y * d.B;
   static int num_cus = 0;
@@ -512,7 +516,7 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
              tiles_x * tiles_y * 2 * split_n <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
-  static bool attr_done[3] = {false, false, false};
+  static std::atomic<bool> attr_done[3];     // zero-initialised; atomic: lanes launch from several host threads
   const GnFold& pf = L.pro_fold;
   const bool fold_ok = pf.acc && pf.P && pf.Q && pf.G * pf.cpg == 64 && pf.cpg % 8 == 0;
   if (pf.acc && !fold_ok) return 0;

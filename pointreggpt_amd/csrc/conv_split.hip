@@ -640,7 +640,7 @@ static int launch_split_igemm(const ConvLaunch<float>& L, int M, hipStream_t s, 
   size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
   if (lds < kEpilogueLds) lds = kEpilogueLds;
   const bool one = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ups;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_kernel<BM, BN, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));

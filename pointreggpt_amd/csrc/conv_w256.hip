@@ -31,6 +31,7 @@
 // constant stride of two source pixels — and the step has four taps ((1,1), (1,2), (2,1), (2,2) of the 3 x 3 frame)
 // instead of nine; the weights are the standard 3 x 3 packing of the equivalent [Cout][4 C][3][3] tensor.  Cout = 64
 // runs with the second channel half of the consumers idle (the shape is HBM-bound).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1051,7 +1052,7 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
                            {reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 1, 0>),
                             reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 2, 0>)}};
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
-  static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
+  static std::atomic<bool> attr_done[2][3];   // zero-initialised; atomic: lanes launch from several host threads
   if (!attr_done[tw == 32][pro]) {
     hipError_t e = hipFuncSetAttribute(fns[tw == 32][pro], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 conv): ") + hipGetErrorString(e));
@@ -1116,7 +1117,7 @@ int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* g
                            {reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 0>), reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 1>),
                             reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 2>)}};
   const size_t lds = tw == 32 ? W2MxGeom<32>::LDS : W2MxGeom<16>::LDS;
-  static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
+  static std::atomic<bool> attr_done[2][3];   // zero-initialised; atomic: lanes launch from several host threads
   if (!attr_done[tw == 32][pro]) {
     hipError_t e = hipFuncSetAttribute(fns[tw == 32][pro], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 mx conv): ") + hipGetErrorString(e));
@@ -1171,7 +1172,7 @@ int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
   const void* fn = tw == 32 ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 1>)
                             : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 1>);
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
-  static bool attr_done[2] = {false, false};
+  static std::atomic<bool> attr_done[2];
   if (!attr_done[tw == 32]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 downsample): ") + hipGetErrorString(e));

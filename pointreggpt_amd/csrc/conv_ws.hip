@@ -32,6 +32,7 @@
 //
 // Covers every 3x3 / stride 1 / pad 1 conv of the U-Nets at dim = 64 (widths multiples of 64): Block.proj, the last
 // down/up convs, Upsample's conv (x2 nearest gather folded into the halo load), skip concat as two sources.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -884,7 +885,7 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
   if (grid > total) grid = total;
   if (grid >= 8) grid &= ~7;                     // multiple of 8: XCD-contiguous runs inside a round
   if (tiles_n > 1 && (grid & 7) != 0) return kWsUnsupported;   // a workgroup must own one channel tile (bias in LDS)
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<TH, TW, BN, PRO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);

@@ -18,6 +18,8 @@ from __future__ import annotations
 import os
 import pickle
 import shutil
+import sys
+import threading
 from pathlib import Path
 from typing import List, Optional
 
@@ -94,10 +96,12 @@ class Generator:
 
     def _poses(self, idxs: List[int], sample_idx: int, pose_seed: Optional[int] = None) -> np.ndarray:
         if self.synthetic_seed is None:
-            if pose_seed is not None:          # reproducible and shard-invariant: the stream restarts per (job, batch, sample)
-                from .sharding import batch_pose_seed
-                np.random.seed(batch_pose_seed(pose_seed, idxs[0], sample_idx))
-            return G.random_sample_pose(len(idxs)).astype(np.float32)      # numpy legacy stream, as the reference
+            if pose_seed is not None:          # reproducible and shard-invariant: a LOCAL legacy stream per (job, batch, sample)
+                from .sharding import batch_pose_seed                      # (the process-wide numpy state is left alone)
+                rs = np.random.RandomState(batch_pose_seed(pose_seed, idxs[0], sample_idx))
+                return G.random_sample_pose(len(idxs), rng=rs).astype(np.float32)
+            with Generator._pose_lock:         # numpy's legacy GLOBAL stream, as the reference (single lane only)
+                return G.random_sample_pose(len(idxs)).astype(np.float32)
         out = []
         for i in idxs:                                                      # shard-invariant per-scene stream
             rng = synthetic.scene_rng(self.synthetic_seed, i)
@@ -110,7 +114,7 @@ class Generator:
     def generate(self, start_scene_index, stop_scene_index, num_samples, memory_voxel_size=0.002,
                  save_voxel_size=0.025, has_refine_step=False, depth_correction=None, mask_threshold=0.99,
                  noise_seed: int = 0, progress: bool = False, writer_threads: int = 0, stats: Optional[dict] = None,
-                 seed_poses: bool = True, lanes: Optional[list] = None):
+                 seed_poses: Optional[bool] = None, lanes: Optional[list] = None):
         """Same sequence as sd:2363-2694.  File output is asynchronous: every batch's clouds / images / text files are
         handed to the library's C++ writer pool (crop, voxel grid, PLY / PNG encoding on worker threads) and are
         produced while the GPU samples the next batch.  A batch's resume marker — the generated cloud of its LAST scene
@@ -122,8 +126,11 @@ class Generator:
         each on its own HIP stream: a batch is still one B-scene launch sequence, but the launch boundaries, ramps and
         drains of one lane (139 kernels per U-Net evaluation) are filled by the other lane's kernels (+7 % pairs/s measured
         at B = 64, 128x128).  A scene's files do not depend on the lane that produced it.
-        ``seed_poses`` (real-data input only): restart numpy's legacy stream per (job seed, batch, sample) so that a run can
-        be re-sharded / resumed reproducibly; False = one global stream like the reference (single lane only)."""
+        ``seed_poses`` (real-data input only): draw the poses from a local legacy stream per (job seed, batch, sample) so that
+        a run can be re-sharded / resumed reproducibly; False = numpy's global stream like the reference (single lane only).
+        Default: True when the caller passes a `noise_seed`, False (the reference's unseeded behaviour) otherwise."""
+        if seed_poses is None:
+            seed_poses = noise_seed != 0 or lanes is not None and len(lanes) > 0
         info_train = None
         if self.synthetic_seed is None:
             with open("./dataset/indoor/metadata/train_info.pkl", "rb") as f:
@@ -156,16 +163,18 @@ class Generator:
         else:
             import threading
             errs = []
+            stop = threading.Event()          # set by the first failing lane: the others stop at their next batch
             dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
 
             def work(k):
                 try:
                     torch.cuda.set_device(dev)
                     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                        results[k] = self._lane(batches[k::n], pairs[k][0], pairs[k][1], wt, n, **kw)
+                        results[k] = self._lane(batches[k::n], pairs[k][0], pairs[k][1], wt, n, stop=stop, **kw)
                         torch.cuda.current_stream().synchronize()
                 except BaseException as e:      # noqa: BLE001 — re-raised on the calling thread
-                    errs.append(e)
+                    errs.append((k, e))
+                    stop.set()
 
             threads = [threading.Thread(target=work, args=(k,)) for k in range(n)]
             for t in threads:
@@ -173,19 +182,20 @@ class Generator:
             for t in threads:
                 t.join()
             if errs:
-                raise errs[0]
+                for k, e in errs[1:]:         # nothing is dropped: later lanes' errors are reported, the first is raised
+                    print("lane {} also failed: {!r}".format(k, e), file=sys.stderr)
+                raise errs[0][1]
+            if stop.is_set():
+                raise RuntimeError("a lane stopped early without an error")
         if stats is not None:
             stats.update(pairs=sum(r[0] for r in results), writer_jobs=sum(r[1] for r in results),
                          writer_threads=sum(r[2] for r in results), lanes=n)
 
-    _pose_lock = None
+    _pose_lock = threading.Lock()      # guards numpy's process-wide legacy stream (seed_poses=False)
 
     def _lane(self, batches, model, depth_correction, writer_threads, n_lanes, *, num_samples, memory_voxel_size,
-              save_voxel_size, has_refine_step, mask_threshold, noise_seed, progress, seed_poses, info_train):
+              save_voxel_size, has_refine_step, mask_threshold, noise_seed, progress, seed_poses, info_train, stop=None):
         """One lane's share of the batches (all of them with a single lane), on the calling thread's current stream."""
-        import threading
-        if Generator._pose_lock is None:
-            Generator._pose_lock = threading.Lock()
         S, dev = self.image_size, self.device
         if writer_threads <= 0 and n_lanes > 1:
             writer_threads = max(2, min(16, (os.cpu_count() or 4) // max(1, int(os.environ.get("WORLD_SIZE", "1"))) // 2) // n_lanes)
@@ -202,6 +212,8 @@ class Generator:
                     marker_prev = None
 
             for idxs in batches:
+                if stop is not None and stop.is_set():
+                    break                      # another lane failed: do not sample this lane's whole share first
                 batch = len(idxs)
                 K = np.zeros((batch, 3, 3), dtype=np.float32)
                 depth0 = np.zeros((batch, 1, S, S), dtype=np.float32)
@@ -233,8 +245,7 @@ class Generator:
                 fragments: List[Optional[np.ndarray]] = [None] * batch
                 poses0 = None
                 for sample_idx in range(num_samples):
-                    with Generator._pose_lock:        # numpy's legacy global stream (real-data input) is process-wide
-                        pose = self._poses(idxs, sample_idx, noise_seed if seed_poses else None)
+                    pose = self._poses(idxs, sample_idx, noise_seed if seed_poses else None)
                     if sample_idx == 0:
                         poses0 = pose
                     pose_dev = torch.from_numpy(pose).to(dev)

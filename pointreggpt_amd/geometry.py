@@ -70,13 +70,15 @@ def param_vector(intrinsic: torch.Tensor) -> torch.Tensor:
     return torch.stack([intrinsic[..., 0, 0], intrinsic[..., 1, 1], intrinsic[..., 0, 2], intrinsic[..., 1, 2]], -1)
 
 
-def random_sample_pose(batch_size: int, center=(0, 0, 3)) -> np.ndarray:
-    """Random camera motion about a pivot 3 m ahead, numpy legacy RNG, same draw order (sd:417-443)."""
-    theta = np.random.rand(batch_size) * (np.pi / 12) - np.pi / 24
-    phi = np.random.rand(batch_size) * (np.pi / 6) - np.pi / 12
+def random_sample_pose(batch_size: int, center=(0, 0, 3), rng=None) -> np.ndarray:
+    """Random camera motion about a pivot 3 m ahead, numpy legacy RNG, same draw order (sd:417-443).  `rng`: a
+    `np.random.RandomState` to draw from instead of numpy's process-wide legacy stream (same algorithm, same values)."""
+    np_random = np.random if rng is None else rng
+    theta = np_random.rand(batch_size) * (np.pi / 12) - np.pi / 24
+    phi = np_random.rand(batch_size) * (np.pi / 6) - np.pi / 12
     rot = Rotation.from_euler("XYZ", np.stack((theta, phi, np.zeros(batch_size)), axis=-1)).as_matrix()
     c = np.array(center)
-    jitter = np.random.randn(batch_size, 3) / 3
+    jitter = np_random.randn(batch_size, 3) / 3
     jitter[:, -1] = 0
     T = np.stack([np.eye(4) for _ in range(batch_size)])
     T[:, :3, :3] = rot

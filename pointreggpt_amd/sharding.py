@@ -28,23 +28,40 @@ def num_to_groups(num: int, divisor: int) -> List[int]:
     return [divisor] * groups + ([rem] if rem > 0 else [])
 
 
-def job_seed() -> int:
-    """A fresh 63-bit seed that is THE SAME on every rank of one launch (no collective needed): derived from the
-    launcher's run id when there is one (torchrun exports TORCHELASTIC_RUN_ID and MASTER_ADDR/PORT identically to all ranks;
-    `--standalone` run ids are random per launch), from fresh entropy in a single-process run.  PRG_JOB_SEED overrides."""
-    import hashlib
+def job_seed(timeout_s: float = 120.0) -> int:
+    """ONE fresh 63-bit seed per launch, the same on every rank.
+
+    * `PRG_JOB_SEED` overrides (reproducing a logged run).
+    * single process: `secrets.randbits(63)`.
+    * WORLD_SIZE > 1: rank 0 DRAWS the seed with `secrets.randbits` and PUBLISHES it through a c10d TCPStore that it hosts on
+      MASTER_ADDR:MASTER_PORT (torchrun exports both to every rank of every node, and this program opens no process group of
+      its own on that port); the other ranks read it.  Nothing is derived from launcher ids or pids, so the value is fresh on
+      every launch — including launches with a fixed `--rdzv_id` and port — and identical across nodes; an elastic restart
+      re-launches the ranks and therefore draws a NEW seed (pass `--noise_seed` / PRG_JOB_SEED to pin one across restarts).
+    Raises when the store cannot be reached: a silent per-rank seed would break the shard-invariance of the noise keys."""
     import secrets
     if os.environ.get("PRG_JOB_SEED"):
         return int(os.environ["PRG_JOB_SEED"]) & ((1 << 63) - 1)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        key = "|".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT",
-                                                        "TORCHELASTIC_RESTART_COUNT"))
-        run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
-        if run_id in ("", "none"):
-            # a fixed run id ('none' is torchrun's default): mix in the launcher's pid, which all ranks share as their parent
-            key += "|ppid=%d" % os.getppid()
-        return int.from_bytes(hashlib.sha256(key.encode()).digest()[:8], "little") & ((1 << 63) - 1)
-    return secrets.randbits(63)
+    rank, world, _ = rank_world()
+    if world <= 1:
+        return secrets.randbits(63)
+    from datetime import timedelta
+
+    import torch.distributed as dist
+    host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT")
+    if not port:
+        raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: pass --noise_seed (or PRG_JOB_SEED) so that all ranks agree on one seed")
+    store = dist.TCPStore(host, int(port), world, is_master=(rank == 0), timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
+    if rank == 0:
+        store.set("prg_job_seed", str(secrets.randbits(63)))
+    seed = int(store.get("prg_job_seed").decode())
+    store.add("prg_job_seed_readers", 1)
+    if rank == 0:                      # keep the store alive until every rank has read it
+        import time
+        t0 = time.time()
+        while int(store.add("prg_job_seed_readers", 0)) < world and time.time() - t0 < timeout_s:
+            time.sleep(0.01)
+    return seed
 
 
 def batch_pose_seed(job_seed_value: int, first_scene_index: int, sample_index: int) -> int:

@@ -1335,3 +1335,111 @@ def test_bench_gpus_flag_spawns_its_own_ranks(tmp_path):
     if torch.cuda.device_count() < 2:
         r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode != 0 and "HIP device" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 4: --num_samples > 1 (sd:2525-2680), NaN visibility of the accumulator statistics, 32-bit guard of the c64 kernel
+# ------------------------------------------------------------------------------------------------------------------
+def test_num_samples_3_against_oracle_sequence(hip, tmp_path):
+    """`--num_samples 3` (generate_dataset.py:26-30): three views are generated from a growing scene memory — every view's
+    fragment is unprojected into the common frame, the fragments are concatenated, the memory cloud is re-voxelised at 2 mm
+    between views, and the final generated cloud is cropped / voxelised in the first view's frame (sd:2525-2680).  The
+    sampler's inputs and outputs are recorded through a spy around `GaussianDiffusion.sample`; EVERYTHING AROUND the sampler
+    is replayed with the oracle (z-buffer projection of the memory cloud, condition, float64 unprojection, inverse pose,
+    dictionary voxel grid) and compared: conditions bit-exact, the final cloud as a point set."""
+    from oracle import geometry as OG
+    from oracle import postprocess as OP
+    from pointreggpt_amd import postprocess as PP, synthetic
+    from pointreggpt_amd.generator import Generator
+    S, B, NSMP, seed = 64, 2, 3, 11
+    net = hip.Unet(16, dtype="fp32").init_synthetic(3)
+    mask = hip.MaskUnet(16, dtype="fp32").init_synthetic(4, final_bias=8.0)       # keep-probability ~1 everywhere: no threshold flips
+    diff = hip.GaussianDiffusion(net, image_size=S, timesteps=1000, sampling_timesteps=4)
+    calls = []
+    real_sample = diff.sample
+
+    def spy(**kw):
+        out = real_sample(**kw)
+        calls.append((kw["img_cond"].detach().cpu().clone(), out.detach().cpu().clone()))
+        return out
+
+    diff.sample = spy
+    gen = Generator(diff, None, batch_size=B, samples_folder=str(tmp_path / "ds" / "data"), synthetic_seed=seed)
+    gen.generate(0, B, NSMP, depth_correction=mask, mask_threshold=0.5, noise_seed=seed)
+    torch.cuda.synchronize()
+    assert len(calls) == NSMP
+    idxs = list(range(B))
+    poses = [gen._poses(idxs, s) for s in range(NSMP)]
+    for j in idxs:
+        d = tmp_path / "ds" / "data" / "scene-{:0>6d}".format(j)
+        for s in range(1, NSMP + 1):
+            for name in ("sample-{:0>6d}.pose.txt", "sample-{:0>6d}.image.png", "sample-{:0>6d}.depth.png"):
+                assert (d / name.format(s)).is_file(), name.format(s)
+            assert np.allclose(np.loadtxt(d / "sample-{:0>6d}.pose.txt".format(s)), np.linalg.inv(poses[s - 1][j]), atol=1e-6)
+        assert (d / "sample-000001.cloud.ply").is_file() and not (d / "sample-000002.cloud.ply").exists()   # ONE generated cloud (sd:2652-2658)
+        depth, K, _ = synthetic.synth_scene(seed, j, S)
+        memory = PP.crop_aabb(OG.point_cloud(depth * 10, K, (0.5, 10)).astype(np.float32)).astype(np.float32)
+        frags = None
+        for s in range(NSMP):
+            cond, img = calls[s]
+            d_o, hit_o = OG.project_cloud(memory, poses[s][j], K, S)             # z-buffer of the moved memory cloud (sd:2531-2552)
+            want = torch.cat([d_o * 0.1, hit_o.float()], dim=1) * 2 - 1
+            assert torch.equal(cond[j:j + 1], want), (j, s, float((cond[j:j + 1] - want).abs().max()))
+            pc = OG.inverse_pose_apply(OG.point_cloud(img[j, 0].numpy() * 10, K, (0.5, 10)), poses[s][j])   # float64, common frame
+            frags = pc if frags is None else np.concatenate([frags, pc], axis=0)
+            if s < NSMP - 1:                                                      # memory update at 2 mm (sd:2661-2680)
+                memory = OP.voxel_down_sample(np.concatenate([memory.astype(np.float64), pc], axis=0), 0.002).astype(np.float32)
+        T = poses[0][j].astype(np.float64)
+        moved = frags @ T[:3, :3].T + T[:3, 3]
+        ref = OP.voxel_down_sample(PP.crop_aabb(moved), 0.025)
+        Ti = np.linalg.inv(T)                                                     # back by inv(T) (sd:2649)
+        ref = ref @ Ti[:3, :3].T + Ti[:3, 3]
+        got = PP.read_ply(str(d / "sample-000001.cloud.ply"))
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        from scipy.spatial import cKDTree                                         # the voxel order is unspecified: compare as point sets
+        dist, nn = cKDTree(got).query(ref, k=1)
+        assert float(dist.max()) <= 1e-9 and len(np.unique(nn)) == len(ref), float(dist.max())
+    diff.close(); net.close(); mask.close()
+
+
+def test_nonfinite_activations_stay_visible_bf16(hip):
+    """the fixed-point GroupNorm accumulators must not turn a NaN / Inf activation into finite, wrong
+    statistics.  An image with an Inf pixel yields a non-finite output; its batch neighbour is untouched (bit for bit)."""
+    S, B = 64, 2
+    net = hip.Unet(64, dtype="bf16").init_synthetic(5, calibrated=True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((B, 1, S, S), generator=g)
+    t = torch.tensor([500, 500])
+    pc = torch.tensor([[75.0, 76.0, 32.5, 32.0]] * B)
+    clean = net(D(x.numpy()), D(t.numpy()), D(pc.numpy())).cpu()
+    assert bool(torch.isfinite(clean).all())
+    x_bad = x.clone()
+    x_bad[0, 0, 10, 10] = float("inf")
+    y = net(D(x_bad.numpy()), D(t.numpy()), D(pc.numpy())).cpu()
+    assert not bool(torch.isfinite(y[0]).all()), "an Inf input pixel vanished inside the GroupNorm statistics"
+    assert torch.equal(y[1], clean[1])
+    net.close()
+
+
+def test_c64_kernel_refuses_inputs_beyond_its_32_bit_offsets(hip):
+    """conv3x3_c64 addresses its input through one buffer descriptor with 32-bit byte offsets.  B = 256 at
+    256x256 x 64 channels is 2 GiB of bf16: the dispatch must hand that shape to a kernel with 64-bit addressing.  The last
+    image (the bytes beyond 2 GiB) is compared with a float64 convolution of the bf16-rounded operands."""
+    B, C, H = 256, 64, 256
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((B, C, H, H), generator=g, device="cuda")
+    gw = torch.Generator().manual_seed(2)
+    w = torch.randn((C, C, 3, 3), generator=gw) / 24.0
+    bias = torch.randn((C,), generator=gw)
+    import ctypes as C_
+    lib = hip.lib.load()
+    out = torch.empty((B, C, H, H), dtype=torch.float32, device="cuda")
+    wh, bh = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(bias.numpy())
+    hip.lib.check(lib.prg_debug_conv3x3(hip.lib.ptr(x), wh.ctypes.data_as(C_.c_void_p), bh.ctypes.data_as(C_.c_void_p), hip.lib.ptr(out),
+                                        B, C, C, H, H, hip.lib.PRG_BF16, hip.lib.stream_ptr()), "prg_debug_conv3x3")
+    for b in (0, B - 1):
+        xb = x[b:b + 1].cpu().to(torch.bfloat16).double()
+        ref = torch.nn.functional.conv2d(xb, w.to(torch.bfloat16).double(), bias.double(), padding=1)
+        err = (out[b:b + 1].cpu().double() - ref).abs()
+        tol = 2.0 ** -8 * ref.abs() + 1e-4 * float(ref.abs().max())
+        assert bool((err <= tol).all()), (b, float((err - tol).max()))
