@@ -1,0 +1,472 @@
+// attn_split.hip — Residual(PreNorm(LinearAttention)) (sd:583-589, 631-639, 737-769) for the `f16x3` precision mode: float32
+// activations in, float32 out, q / k / v never in HBM.  The structure is attn_fused.hip's (three passes that re-read only x
+// and recompute the projections on the matrix pipe), with every contraction as THREE f16 MFMAs on hi/lo-split operands
+// (conv_split.hip: a = hi + lo, 22-bit operands) and float32 everywhere else:
+//
+//   la_ctx   x -> LayerNorm -> k, v;  sweep 1: column maxima of k over the block's slab;  sweep 2 (x again, from L2):
+//            p = exp2(k - max) <= 1, sum_n p, ctx[d][e] += p[n][d] v[n][e]         -> per slab (max, sum, ctx)
+//   la_fin   slabs merged on their own maxima: ctx = sum_s 2^(m_s - M) ctx_s / sum_s 2^(m_s - M) sum_s / N * 32^-1/2,
+//            split into f16 halves in the k-slot order la_out's MFMA wants (float64 sums, fixed slab order)
+//   la_out   x -> LayerNorm -> q -> softmax over d (measured maximum) -> out = ctx^T q -> y = Wout out + b -> LayerNorm -> + x
+//
+// Why not the bf16 kernels' "no shift at all" trick: f16 has no float32 range — exp2(k) with |k| up to 58 overflows it — so
+// every exponential is taken relative to a MEASURED maximum (per slab for k, per pixel for q) and is <= 1; what the f16 halves
+// then drop is below 2^-22 of the largest term of the sum it enters.
+// The unfused float32 path (blocks.hip) moves ~7 GB per level-0 instance at B = 64 (LayerNorm out, the 384-channel qkv tensor
+// written once and read three times, ...): 2.0 ms; this file reads x four times and writes it once.
+// MFMA: v_mfma_f32_32x32x16_f16, D[i][j] = sum_k A[i][k] B[k][j]; lane l supplies A[l&31][8(l>>5)..+7] and
+// B[8(l>>5)..+7][l&31] and receives D[(r&3) + 8(r>>2) + 4(l>>5)][l&31] in register r.
+#include <atomic>
+#include <cstdlib>
+
+#include "blocks.h"
+
+namespace prg {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kTP = 64;              // pixels per tile
+constexpr int kHid = 128;            // heads x dim_head
+constexpr int kLdO = kHid + 8;       // LDS row stride of the 128-wide attention-output rows (halves)
+constexpr float kLnEps = 1e-5f;
+
+__host__ __device__ inline int sp_tpb(int ntiles) {      // tiles per block: a function of the image size only (batch-independent slabs)
+  const int t = ntiles / 8;
+  return t < 1 ? 1 : (t > 8 ? 8 : t);
+}
+
+__device__ inline f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+  return z;
+}
+__device__ inline float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+// acc += A B with both operands split: the two cross terms first (small), then hi * hi
+__device__ inline f32x16 mma3(const h8& ah, const h8& al, const h8& bh, const h8& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+}
+__device__ inline void split1(float v, _Float16& h, _Float16& l) {
+  h = (_Float16)v;
+  l = (_Float16)(v - (float)h);
+}
+#define SPLIT_TO(v, H, L, idx)                \
+  do {                                        \
+    _Float16 sh_, sl_;                        \
+    split1((v), sh_, sl_);                    \
+    (H)[idx] = sh_;                           \
+    (L)[idx] = sl_;                           \
+  } while (0)
+
+template <int C>
+struct SG {
+  static constexpr int LDW = C + 8;       // LDS row stride of C-wide rows (halves): 16 bytes of padding, conflict-free b128 reads
+  static constexpr int VPT = C / 16;      // float4 vectors per thread of a 64 x C tile (4 threads per pixel row)
+  static constexpr int KK = C / 16;       // MFMA k-steps over C
+};
+
+// x tile: global (float32) -> registers -> LayerNorm -> hi / lo f16 tiles in LDS
+template <int C>
+struct XTileF {
+  float4 v[SG<C>::VPT];
+  __device__ inline void load(const float* x, int64_t pix0) {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+#pragma unroll
+    for (int i = 0; i < SG<C>::VPT; ++i) v[i] = *reinterpret_cast<const float4*>(x + (pix0 + row) * C + (part + 4 * i) * 4);
+  }
+  // (x - mean) * rstd (biased variance, two-pass on the registers, eps 1e-5: sd:619-628), split, into xh / xl [row][c]
+  __device__ inline void normalize_to(_Float16* xh, _Float16* xl) const {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float f[SG<C>::VPT][4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SG<C>::VPT; ++i) {
+      f[i][0] = v[i].x; f[i][1] = v[i].y; f[i][2] = v[i].z; f[i][3] = v[i].w;
+      s += (f[i][0] + f[i][1]) + (f[i][2] + f[i][3]);
+    }
+    s = quad_sum(s);
+    const float mean = s * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SG<C>::VPT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[i][j] -= mean;
+        q = fmaf(f[i][j], f[i][j], q);
+      }
+    q = quad_sum(q);
+    const float rstd = 1.0f / __builtin_sqrtf(q * (1.0f / C) + kLnEps);
+#pragma unroll
+    for (int i = 0; i < SG<C>::VPT; ++i) {
+      h4 a, b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) SPLIT_TO(f[i][j] * rstd, a, b, j);
+      *reinterpret_cast<h4*>(xh + row * SG<C>::LDW + (part + 4 * i) * 4) = a;
+      *reinterpret_cast<h4*>(xl + row * SG<C>::LDW + (part + 4 * i) * 4) = b;
+    }
+  }
+};
+
+__device__ inline h8 frag(const _Float16* rows, int ld, int l31, int hi, int kk) {
+  return *reinterpret_cast<const h8*>(rows + l31 * ld + kk * 16 + hi * 8);
+}
+// k-step fragments of rows [r0, r0 + 32) of a row-major [.][COLS] f16 matrix, global -> registers (kept for the whole block)
+template <int COLS>
+__device__ inline void load_wfrags(h8 (&w)[COLS / 16], const uint16_t* mat, int r0, int l31, int hi) {
+#pragma unroll
+  for (int kk = 0; kk < COLS / 16; ++kk)
+    w[kk] = *reinterpret_cast<const h8*>(mat + (size_t)(r0 + l31) * COLS + kk * 16 + hi * 8);
+}
+
+// =====================================================================================================
+// la_ctx: per slab (column maxima of k, sums of p = exp2(k - max), p^T v)
+// =====================================================================================================
+template <int C>
+__global__ __launch_bounds__(256, 2) void la_ctx_split_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wqkv_h,
+                                                              const uint16_t* __restrict__ wqkv_l, float* __restrict__ ctxp,
+                                                              float* __restrict__ sump, float* __restrict__ maxp, int N, int nslab) {
+  using G = SG<C>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  _Float16* xh = reinterpret_cast<_Float16*>(smem);      // [64][LDW]
+  _Float16* xl = xh + kTP * G::LDW;
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int ntiles = N / kTP;
+  const int tpb = sp_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
+  h8 wkh[G::KK], wkl[G::KK], wvh[G::KK], wvl[G::KK];     // k and v rows of head `wave`
+  load_wfrags<C>(wkh, wqkv_h, kHid + 32 * wave, l31, hi);
+  load_wfrags<C>(wkl, wqkv_l, kHid + 32 * wave, l31, hi);
+  load_wfrags<C>(wvh, wqkv_h, 2 * kHid + 32 * wave, l31, hi);
+  load_wfrags<C>(wvl, wqkv_l, 2 * kHid + 32 * wave, l31, hi);
+  XTileF<C> xt;
+  // ---- sweep 1: the slab's maximum of column d = 32 wave + l31 of k (log2 units: the rows carry log2 e) ----
+  float m = -INFINITY;
+  if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP);
+  for (int t = t0; t < t1; ++t) {
+    xt.normalize_to(xh, xl);
+    __syncthreads();
+    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP);
+    else xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP);            // (sweep 2 starts over)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      f32x16 k1 = zero16();
+#pragma unroll
+      for (int kk = 0; kk < G::KK; ++kk)
+        k1 = mma3(frag(xh + pt * 32 * G::LDW, G::LDW, l31, hi, kk), frag(xl + pt * 32 * G::LDW, G::LDW, l31, hi, kk), wkh[kk], wkl[kk], k1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, k1[r]);
+    }
+    __syncthreads();
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  f32x16 kinit;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) kinit[e] = -m;
+  // ---- sweep 2 ----
+  f32x16 ctx = zero16();                               // rows d, column e = l31 of head `wave`
+  f32x16 psum = zero16();                              // rows d (any column)
+  h8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+  for (int t = t0; t < t1; ++t) {
+    xt.normalize_to(xh, xl);
+    __syncthreads();
+    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      f32x16 k1 = kinit, v1 = zero16();
+#pragma unroll
+      for (int kk = 0; kk < G::KK; ++kk) {
+        const h8 fh = frag(xh + pt * 32 * G::LDW, G::LDW, l31, hi, kk), fl = frag(xl + pt * 32 * G::LDW, G::LDW, l31, hi, kk);
+        k1 = mma3(fh, fl, wkh[kk], wkl[kk], k1);
+        v1 = mma3(fh, fl, wvh[kk], wvl[kk], v1);
+      }
+      // p and v feed the context MFMA straight from the accumulator registers: lane (column, half hi) holds in registers
+      // 8 i .. 8 i + 7 exactly the eight pixels that A's row / B's column l31 supplies for k-slots 8 hi .. + 7 of k-step i
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        h8 ph, pl, vh, vl;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+          SPLIT_TO(__builtin_amdgcn_exp2f(k1[8 * i + s2]), ph, pl, s2);
+          SPLIT_TO(v1[8 * i + s2], vh, vl, s2);
+        }
+        ctx = mma3(ph, pl, vh, vl, ctx);
+        psum = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, ones, psum, 0, 0, 0);
+        psum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, ones, psum, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const size_t ph_ = ((size_t)b * 4 + wave) * nslab + slab;
+  if (l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sump[ph_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = psum[r];
+  }
+  if (hi == 0) maxp[ph_ * 32 + l31] = m;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ctxp[ph_ * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = ctx[r];
+}
+
+// =====================================================================================================
+// la_fin: slabs merged on their own maxima (float64, fixed slab order) -> ctx^T as f16 halves [b][h][e][slot(d)]
+// =====================================================================================================
+__global__ __launch_bounds__(256) void la_fin_split_kernel(const float* __restrict__ ctxp, const float* __restrict__ sump,
+                                                           const float* __restrict__ maxp, uint16_t* __restrict__ ctxT_h,
+                                                           uint16_t* __restrict__ ctxT_l, int N, int nslab) {
+  const int h = blockIdx.x, b = blockIdx.y;
+  const size_t ph = ((size_t)b * 4 + h) * nslab;
+  const double scale = 0.17677669529663687 / (double)N;    // 32^-1/2 (q) and 1/N (v)
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const int d = idx >> 5, e = idx & 31;
+    float M = -INFINITY;
+    for (int s2 = 0; s2 < nslab; ++s2) M = fmaxf(M, maxp[(ph + s2) * 32 + d]);
+    double c = 0.0, s = 0.0;
+    for (int s2 = 0; s2 < nslab; ++s2) {
+      const double w = (double)__builtin_amdgcn_exp2f(maxp[(ph + s2) * 32 + d] - M);   // (power of two scale; <= 1)
+      c += w * (double)ctxp[(ph + s2) * 1024 + idx];
+      s += w * (double)sump[(ph + s2) * 32 + d];
+    }
+    const float val = (float)(c / s * scale);
+    _Float16 vh, vl;
+    split1(val, vh, vl);
+    const int slot = (d >> 4) * 16 + ((d >> 2) & 1) * 8 + ((d >> 3) & 1) * 4 + (d & 3);
+    const size_t o = ((size_t)b * 4 + h) * 1024 + e * 32 + slot;
+    ctxT_h[o] = __builtin_bit_cast(uint16_t, vh);
+    ctxT_l[o] = __builtin_bit_cast(uint16_t, vl);
+  }
+}
+
+// =====================================================================================================
+// la_out: q, softmax over d, ctx^T q, to_out conv + bias, LayerNorm, residual
+// =====================================================================================================
+template <int C>
+__global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_out_split_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wqkv_h,
+                                                              const uint16_t* __restrict__ wqkv_l, const uint16_t* __restrict__ wout_h,
+                                                              const uint16_t* __restrict__ wout_l, const float* __restrict__ bias,
+                                                              const float* __restrict__ out_g, const uint16_t* __restrict__ ctxT_h,
+                                                              const uint16_t* __restrict__ ctxT_l, float* __restrict__ out, int N) {
+  using G = SG<C>;
+  constexpr int RT = C / 32;                 // 32-channel row tiles of y
+  static_assert(RT == 2 || RT == 4, "C = 64 or 128");
+  constexpr int NA = RT / 2;                 // y accumulators per wave
+  constexpr int LDY = C + 4;                 // float row stride of the y tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  _Float16* xh = reinterpret_cast<_Float16*>(smem);      // [64][LDW]
+  _Float16* xl = xh + kTP * G::LDW;
+  _Float16* oh = xl + kTP * G::LDW;                      // [64][kLdO]  attention output, pixel-major
+  _Float16* ol = oh + kTP * kLdO;
+  float* lnb = reinterpret_cast<float*>(ol + kTP * kLdO);   // [64][RT][2] LayerNorm partial sums
+  float* yt = lnb + kTP * RT * 2;                           // [64][LDY] the normalised y tile
+  float* bias_l = yt + kTP * LDY;                           // [C]
+  float* outg_l = bias_l + C;                               // [C]
+  if (threadIdx.x < C) {
+    bias_l[threadIdx.x] = bias[threadIdx.x];
+    outg_l[threadIdx.x] = out_g[threadIdx.x];
+  }
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  const int ntiles = N / kTP;
+  const int tpb = sp_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
+  h8 wqh[G::KK], wql[G::KK];                             // q rows of head `wave`
+  load_wfrags<C>(wqh, wqkv_h, 32 * wave, l31, hi);
+  load_wfrags<C>(wql, wqkv_l, 32 * wave, l31, hi);
+  // ctx^T rows e = l31 of head `wave`; k-slot s of half hi in k-step i is d = 16 i + 8 (s >> 2) + 4 hi + (s & 3): exactly the d
+  // of q-accumulator register 8 i + s of a lane in half hi, so q feeds the MFMA without any shuffle
+  h8 cah[2], cal[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    cah[i] = *reinterpret_cast<const h8*>(ctxT_h + (((size_t)b * 4 + wave) * 32 + l31) * 32 + i * 16 + hi * 8);
+    cal[i] = *reinterpret_cast<const h8*>(ctxT_l + (((size_t)b * 4 + wave) * 32 + l31) * 32 + i * 16 + hi * 8);
+  }
+  int yrt[NA], ypt[NA];                                  // y accumulators of this wave: row tile / pixel tile
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    if (RT == 2) { yrt[a] = wave & 1; ypt[a] = wave >> 1; }
+    else { yrt[a] = wave; ypt[a] = a; }
+  }
+  h8 woh[kHid / 16], wol[kHid / 16];                     // to_out rows of this wave's y row tile
+  load_wfrags<kHid>(woh, wout_h, yrt[0] * 32, l31, hi);
+  load_wfrags<kHid>(wol, wout_l, yrt[0] * 32, l31, hi);
+  XTileF<C> xt;
+  if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP);
+  for (int t = t0; t < t1; ++t) {
+    const XTileF<C> xraw = xt;                           // residual
+    xt.normalize_to(xh, xl);
+    __syncthreads();                                                                            // (1) xn ready
+    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP);
+    // q^T[d][px] of head `wave` (log2 units)
+    f32x16 qa[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kk = 0; kk < G::KK; ++kk)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        qa[pt] = mma3(wqh[kk], wql[kk], frag(xh + pt * 32 * G::LDW, G::LDW, l31, hi, kk), frag(xl + pt * 32 * G::LDW, G::LDW, l31, hi, kk), qa[pt]);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      // softmax over the 32 d of pixel pt * 32 + l31: 16 in this lane, 16 in lane ^ 32
+      float mx = qa[pt][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qa[pt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sm = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        qa[pt][r] = __builtin_amdgcn_exp2f(qa[pt][r] - mx);
+        sm += qa[pt][r];
+      }
+      sm += __shfl_xor(sm, 32, 64);
+      const float inv = 1.0f / sm;
+      f32x16 oa = zero16();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        h8 qh, ql;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) SPLIT_TO(qa[pt][8 * i + s2] * inv, qh, ql, s2);
+        oa = mma3(cah[i], cal[i], qh, ql, oa);                                   // rows e, column px
+      }
+      const int px = pt * 32 + l31;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        h4 a, c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SPLIT_TO(oa[4 * g4 + j], a, c, j);
+        *reinterpret_cast<h4*>(oh + px * kLdO + 32 * wave + 8 * g4 + 4 * hi) = a;
+        *reinterpret_cast<h4*>(ol + px * kLdO + 32 * wave + 8 * g4 + 4 * hi) = c;
+      }
+    }
+    __syncthreads();                                                                            // (2) o tile ready, xn free
+    // y^T[c][px] = Wout[c][:] . o[px][:] + bias
+    f32x16 ya[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) ya[a] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < kHid / 16; ++kk)
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        ya[a] = mma3(woh[kk], wol[kk], frag(oh + ypt[a] * 32 * kLdO, kLdO, l31, hi, kk), frag(ol + ypt[a] * 32 * kLdO, kLdO, l31, hi, kk), ya[a]);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      float s1 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = yrt[a] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        ya[a][r] += bias_l[c];
+        s1 += ya[a][r];
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      if (hi == 0) lnb[((ypt[a] * 32 + l31) * RT + yrt[a]) * 2] = s1;
+    }
+    __syncthreads();                                                                            // (3) sums
+    float mean[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int px = ypt[a] * 32 + l31;
+      float s1 = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) s1 += lnb[(px * RT + rt) * 2];
+      mean[a] = s1 * (1.0f / C);
+      float s2 = 0.0f;                                   // two-pass variance, like the reference's x.var()
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dlt = ya[a][r] - mean[a];
+        s2 = fmaf(dlt, dlt, s2);
+      }
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) lnb[(px * RT + yrt[a]) * 2 + 1] = s2;
+    }
+    __syncthreads();                                                                            // (4) squared deviations
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int px = ypt[a] * 32 + l31;
+      float s2 = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) s2 += lnb[(px * RT + rt) * 2 + 1];
+      const float rstd = 1.0f / __builtin_sqrtf(s2 * (1.0f / C) + kLnEps);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c0 = yrt[a] * 32 + 8 * g4 + 4 * hi;
+        const float4 gg = *reinterpret_cast<const float4*>(outg_l + c0);
+        float4 w;
+        w.x = (ya[a][4 * g4] - mean[a]) * rstd * gg.x;
+        w.y = (ya[a][4 * g4 + 1] - mean[a]) * rstd * gg.y;
+        w.z = (ya[a][4 * g4 + 2] - mean[a]) * rstd * gg.z;
+        w.w = (ya[a][4 * g4 + 3] - mean[a]) * rstd * gg.w;
+        *reinterpret_cast<float4*>(yt + px * LDY + c0) = w;
+      }
+    }
+    __syncthreads();                                                                            // (5) y tile ready
+    {
+      const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+#pragma unroll
+      for (int i = 0; i < G::VPT; ++i) {
+        const float4 yv = *reinterpret_cast<const float4*>(yt + row * LDY + (part + 4 * i) * 4);
+        const float4 xv = xraw.v[i];
+        float4 o;
+        o.x = yv.x + xv.x; o.y = yv.y + xv.y; o.z = yv.z + xv.z; o.w = yv.w + xv.w;
+        *reinterpret_cast<float4*>(out + ((int64_t)b * N + (int64_t)t * kTP + row) * C + (part + 4 * i) * 4) = o;
+      }
+    }
+  }
+}
+
+template <int C>
+constexpr size_t lds_ctx() { return (size_t)2 * kTP * SG<C>::LDW * 2; }
+template <int C>
+constexpr size_t lds_out() {
+  return (size_t)2 * kTP * SG<C>::LDW * 2 + (size_t)2 * kTP * kLdO * 2 + (size_t)kTP * (C / 32) * 2 * 4 + (size_t)kTP * (C + 4) * 4 + 2 * C * 4;
+}
+
+template <int C>
+int launch_c(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, const uint16_t* wout_h, const uint16_t* wout_l,
+             const float* bias, const float* out_g, float* out, float* ws, int B, int N, hipStream_t s) {
+  static std::atomic<bool> attr{false};
+  if (!attr) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_out_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out<C>()));
+    attr = true;
+  }
+  const int ntiles = N / kTP, nslab = ceil_div(ntiles, sp_tpb(ntiles));
+  float* ctxp = ws;
+  float* sump = ctxp + (size_t)B * 4 * nslab * 1024;
+  float* maxp = sump + (size_t)B * 4 * nslab * 32;
+  uint16_t* ctxT_h = reinterpret_cast<uint16_t*>(maxp + (size_t)B * 4 * nslab * 32);
+  uint16_t* ctxT_l = ctxT_h + (size_t)B * 4 * 1024;
+  const dim3 grid(nslab, B);
+  la_ctx_split_kernel<C><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv_h, wqkv_l, ctxp, sump, maxp, N, nslab);
+  PRG_LAUNCH_CHECK();
+  la_fin_split_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, maxp, ctxT_h, ctxT_l, N, nslab);
+  PRG_LAUNCH_CHECK();
+  la_out_split_kernel<C><<<grid, 256, lds_out<C>(), s>>>(x, wqkv_h, wqkv_l, wout_h, wout_l, bias, out_g, ctxT_h, ctxT_l, out, N);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+}  // namespace
+
+bool linattn_split_supported(int C, int N) { return C == 64 && N % kTP == 0 && N >= kTP; }
+
+size_t linattn_split_ws_floats(int B, int N) {
+  const int ntiles = N / kTP, nslab = ceil_div(ntiles, sp_tpb(ntiles));
+  return (size_t)B * 4 * nslab * (1024 + 64) + (size_t)B * 4 * 1024 + 64;   // slabs (ctx, sum, max) + ctx^T halves (2 x f16 = 1 float each)
+}
+
+// x, out: (B, N, C) float32.  wqkv_h / _l: f16 halves of [384][C] (PreNorm gain folded in, q and k rows times log2 e);
+// wout_h / _l: [C][128]; bias, out_g: [C] float32.
+int launch_linear_attention_split(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, const uint16_t* wout_h,
+                                  const uint16_t* wout_l, const float* bias, const float* out_g, float* out, float* ws, int B, int N,
+                                  int C, hipStream_t s) {
+  PRG_CHECK(linattn_split_supported(C, N) && x && out && ws, "linear attention (f16x3): unsupported shape");
+  return launch_c<64>(x, wqkv_h, wqkv_l, wout_h, wout_l, bias, out_g, out, ws, B, N, s);
+}
+
+}  // namespace prg

@@ -53,6 +53,12 @@ int launch_linear_attention(const T* qkv, T* out, float* ws, int B, int N, hipSt
 
 // Residual(PreNorm(LinearAttention)) fused for the bf16 path (attn_fused.hip): x, out (B, N, C); wqkv [384][C] bf16 with
 // the PreNorm gain folded in, wout [C][128] bf16.  ws: at least linattn_fused_ws_floats(B, N) floats.
+// f16x3 mode (attn_split.hip): fused Residual(PreNorm(LinearAttention)) on float32 activations, split-f16 contractions
+bool linattn_split_supported(int C, int N);
+size_t linattn_split_ws_floats(int B, int N);
+int launch_linear_attention_split(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, const uint16_t* wout_h,
+                                  const uint16_t* wout_l, const float* bias, const float* out_g, float* out, float* ws, int B, int N,
+                                  int C, hipStream_t s);
 bool linattn_fused_supported(int C);
 size_t linattn_fused_ws_floats(int B, int N);
 // kshift: [128 + 4] static softmax shifts — a bound on |k| per column, then a bound on |q| per head (see unet.hip) — or

@@ -25,6 +25,9 @@
 
 #include "conv_epi.h"
 
+#ifndef PRG_SPLIT_ORDER
+#define PRG_SPLIT_ORDER 0     // 1: fragment loads + weight prefetch in front of the staging code (experiment)
+#endif
 #ifndef PRG_SPLIT_EXP
 #define PRG_SPLIT_EXP 0      // ablation builds (tools/split_ablate.sh): 1 no MFMAs, 2 no split arithmetic, 3 no epilogue, 4 no weight loads, 5 no halo staging in the loop
 #endif
@@ -366,6 +369,26 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // tile it + 1 is visible; nobody still reads tile it's ring slot or the previous chunk's halo
     TRACE_T(1);
+#if PRG_SPLIT_ORDER == 1
+#if PRG_SPLIT_EXP != 4
+    // (3) weight tile it + NS into the slot tile `it` just vacated
+    if constexpr (T + NS < 9) gload_b(c, T + NS, NS == 3 ? T % 3 : it & 1);
+    else if (more) gload_b(c + 1, T + NS - 9, NS == 3 ? T % 3 : it & 1);
+#endif
+    // (4) fragments of the next tap into the other register set, (5) the MFMAs of this tap
+    if constexpr (T < 8) reads(IC<1 - S>(), IC<T + 1>(), c & 1, NS == 3 ? (T + 1) % 3 : (it + 1) & 1);
+    else if (more) reads(IC<1 - S>(), IC<0>(), (c + 1) & 1, NS == 3 ? 0 : (it + 1) & 1);
+    TRACE_T(2);
+#if PRG_SPLIT_EXP != 5
+    if (more) {
+      // (2) the next chunk's halo, one pass per tap: written one tap after its load, into the other halo buffer
+      //     (loaded at taps 0 .. NH - 1, written DIST taps later: the loads come from HBM — ~2 us, two to four taps)
+      if constexpr (T == 0) pro_load(c + 1);
+      if constexpr (T >= DIST && T < DIST + NH) halo_write((c + 1) & 1, IC<T - DIST>());
+      if constexpr (T < NH) halo_load(c + 1, IC<T>());
+    }
+#endif
+#else
 #if PRG_SPLIT_EXP != 5
     if (more) {
       // (2) the next chunk's halo, one pass per tap: written one tap after its load, into the other halo buffer
@@ -384,6 +407,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // (4) fragments of the next tap into the other register set, (5) the MFMAs of this tap
     if constexpr (T < 8) reads(IC<1 - S>(), IC<T + 1>(), c & 1, NS == 3 ? (T + 1) % 3 : (it + 1) & 1);
     else if (more) reads(IC<1 - S>(), IC<0>(), (c + 1) & 1, NS == 3 ? 0 : (it + 1) & 1);
+#endif
     TRACE_T(3);
     mfmas(IC<S>());
     TRACE_T(4);

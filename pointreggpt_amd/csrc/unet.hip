@@ -118,6 +118,7 @@ struct AttnP {
   int64_t out_g = -1, norm_g = -1;
   int64_t fw_qkv = -1, fw_out = -1;   // bf16 element offsets into the fused-attention weight arena (-1: unfused path)
   int64_t kshift = -1;                // float offset of the 128 static softmax shifts in d_kshift (-1: measure the maxima)
+  int64_t sp_qkv = -1, sp_out = -1;   // f16x3 mode: element offsets into d_attn_split of the hi halves (the lo halves follow)
 };
 struct LevelP {
   ResP r0, r1;
@@ -269,6 +270,7 @@ struct prg_unet {
   float* d_kshift = nullptr;    // fused linear attention: static softmax shifts of the k columns
   uint8_t* d_mx = nullptr;      // MX-fp8 conv weights (dtype PRG_MXFP8): e4m3 data and E8M0 block scales
   uint8_t* d_mx_scale = nullptr;
+  uint16_t* d_attn_split = nullptr;   // f16x3 mode: fused linear attention weights as f16 hi / lo halves (attn_split.hip)
   uint16_t* d_split = nullptr;  // f16x3 mode (dtype PRG_F16X3): every conv weight as f16 hi / lo halves (conv_split.hip)
   float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
   int* d_tickets = nullptr;     // [kMaxTicketImages] per-image arrival counters of the conv kernels that fold GroupNorm coefficients (self-resetting)
@@ -557,6 +559,21 @@ struct UnetImpl : prg_unet {
         if (!arena.dry)
           rc = launch_linear_attention_fused(x, d_attn + a.fw_qkv, d_attn + a.fw_out, F(a.out.b_off), F(a.out_g), out, ws, B, N,
                                              a.C, a.kshift >= 0 ? d_kshift + a.kshift : nullptr, s);
+        arena.reset(m);
+        return rc;
+      }
+    }
+    if constexpr (std::is_same<T, float>::value) {
+      if (a.linear && a.sp_qkv >= 0 && d_attn_split && linattn_split_supported(a.C, N)) {
+        float* ws = alloc<float>(linattn_split_ws_floats(B, N));
+        PRG_CHECK(arena.dry || ws, "workspace exhausted (split attention)");
+        int rc = PRG_OK;
+        if (!arena.dry) {
+          const uint16_t* qh = d_attn_split + a.sp_qkv;
+          const uint16_t* oh = d_attn_split + a.sp_out;
+          rc = launch_linear_attention_split(x, qh, qh + (size_t)3 * kHidden * a.C, oh, oh + (size_t)a.C * kHidden, F(a.out.b_off),
+                                             F(a.out_g), out, ws, B, N, a.C, s);
+        }
         arena.reset(m);
         return rc;
       }
@@ -918,6 +935,38 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
     }
     if (hipMalloc(&u->d_split, data.size() * sizeof(uint16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split weights)");
     PRG_HIP(hipMemcpy(u->d_split, data.data(), data.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // fused linear attention (attn_split.hip): to_qkv with the PreNorm gain folded in (q and k rows times log2 e: both only ever
+    // enter a softmax, evaluated with exp2) and to_out, each as f16 hi halves followed by the lo halves.  PRG_SPLIT_ATTN=0: unfused
+    static const int sa_on = [] { const char* e = std::getenv("PRG_SPLIT_ATTN"); return e ? std::atoi(e) : 1; }();
+    std::vector<uint16_t> aw;
+    auto f16bits = [](float v, uint16_t& h, uint16_t& l) {
+      const _Float16 a = (_Float16)v, b = (_Float16)(v - (float)a);
+      std::memcpy(&h, &a, 2);
+      std::memcpy(&l, &b, 2);
+    };
+    auto add_attn = [&](AttnP& a) {
+      if (!sa_on || !a.linear || a.C != 64) return;      // (linattn_split_supported: C = 64; the token count is checked per call)
+      aw.resize((aw.size() + 63) / 64 * 64);
+      a.sp_qkv = (int64_t)aw.size();
+      const size_t nq = (size_t)3 * kHidden * a.C;
+      aw.resize(aw.size() + 2 * nq);
+      for (int o = 0; o < 3 * kHidden; ++o)
+        for (int c = 0; c < a.C; ++c) {
+          const float v = weights[a.qkv.w_flat + (size_t)o * a.C + c] * weights[a.norm_g + c] * (o < 2 * kHidden ? 1.4426950408889634f : 1.0f);
+          f16bits(v, aw[a.sp_qkv + (size_t)o * a.C + c], aw[a.sp_qkv + nq + (size_t)o * a.C + c]);
+        }
+      aw.resize((aw.size() + 63) / 64 * 64);
+      a.sp_out = (int64_t)aw.size();
+      const size_t no = (size_t)a.C * kHidden;
+      aw.resize(aw.size() + 2 * no);
+      for (size_t i = 0; i < no; ++i) f16bits(weights[a.out.w_flat + i], aw[a.sp_out + i], aw[a.sp_out + no + i]);
+    };
+    for (auto& lv : u->lay.downs) add_attn(lv.at);
+    for (auto& lv : u->lay.ups) add_attn(lv.at);
+    if (!aw.empty()) {
+      if (hipMalloc(&u->d_attn_split, aw.size() * sizeof(uint16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split attention weights)");
+      PRG_HIP(hipMemcpy(u->d_attn_split, aw.data(), aw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
   }
   if (std::is_same<T, bf16_t>::value) {
     // fixed-point GroupNorm statistics (common.h, GnFold): P = gamma, Q = beta of every norm in 16-byte aligned rows (what
@@ -1193,6 +1242,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_mx) (void)hipFree(h->d_mx);
   if (h->d_mx_scale) (void)hipFree(h->d_mx_scale);
   if (h->d_split) (void)hipFree(h->d_split);
+  if (h->d_attn_split) (void)hipFree(h->d_attn_split);
   if (h->d_tickets) (void)hipFree(h->d_tickets);
   if (h->d_gnacc) (void)hipFree(h->d_gnacc);
   if (h->d_pq_static) (void)hipFree(h->d_pq_static);
