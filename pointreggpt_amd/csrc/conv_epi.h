@@ -23,7 +23,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // Wave tile = (TM*32) rows x 64 columns.  `stage` = this wave's private LDS scratch of 32 x 68 floats.
 // row_to_m(local_row) -> global output row (pixel index) or -1.  Returns through (gs, gq) this lane's partial
 // (sum, sumsq) over the 8 consecutive channels it stored (cols (lane & 7) * 8 .. + 7 of the wave tile).
-template <typename T, int TM, typename RowMap>
+// PART8 (f16x3 kernels): the lane's eight values of a row are summed in float32 first (16 operations), then added to the
+// float64 accumulators (2 conversions + 2 additions instead of 8 + 16): a partial over 8 values carries ~1e-7 relative error,
+// which the sum over a group's >= 2048 partials averages out far below the 1e-7 the moments need.
+template <typename T, int TM, typename RowMap, bool PART8 = false>
 __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][2], float* stage, int lane,
                                       int col0, RowMap row_to_m, StatAcc<T>& gs, StatAcc<T>& gq) {
   using SA = StatAcc<T>;
@@ -61,10 +64,18 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
         const size_t o = (size_t)m * L.d.Cout + col;
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] += bias[u];
+        if constexpr (PART8) {
+          float s8 = 0.0f, q8 = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if constexpr (std::is_same<SA, double>::value) { gs += (double)v[u]; gq += (double)v[u] * (double)v[u]; }
-          else { gs += v[u]; gq = fmaf(v[u], v[u], gq); }
+          for (int u = 0; u < 8; ++u) { s8 += v[u]; q8 = fmaf(v[u], v[u], q8); }
+          gs += (SA)s8;
+          gq += (SA)q8;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if constexpr (std::is_same<SA, double>::value) { gs += (double)v[u]; gq += (double)v[u] * (double)v[u]; }
+            else { gs += v[u]; gq = fmaf(v[u], v[u], gq); }
+          }
         }
         if (L.residual) {
           float ra[8], rb[8];

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   return;
 #endif
   f32x16 res[1][2] = {{tot[0], tot[1]}};
-  epilogue_store<float, 1>(L, res, stage + wave * 32 * 68, lane, tn * BN, row_to_m, gs, gq);
+  epilogue_store<float, 1, decltype(row_to_m), true>(L, res, stage + wave * 32 * 68, lane, tn * BN, row_to_m, gs, gq);
   if (fuse_stats) {
     const int nsplit = tiles_x * tiles_y;
     float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
