@@ -55,8 +55,27 @@ __device__ inline void split8(const float (&v)[8], uint4& hi, uint4& lo) {
 }
 
 // SiLU of the fused prologue: hardware exp2 / reciprocal (1 ulp each) — ~2e-7 relative, the size of the contraction's own error
+#ifndef PRG_SPLIT_SILU
+#define PRG_SPLIT_SILU 0      // 0: hardware exp2 / rcp; 1: the parity mode's expf + IEEE divide; 2: compensated exponent + one Newton step
+#endif
 __device__ inline float silu_fast(float x) {
+#if PRG_SPLIT_SILU == 1
+  return x / (1.0f + expf(-x));
+#elif PRG_SPLIT_SILU == 2
+  // t = -x log2(e) to ~2^-48 relative: t_hi + t_lo with the constant split in two; exp2(t) = exp2(t_hi) (1 + t_lo ln 2)
+  const float c_hi = -1.4426950216293335f, c_lo = -1.9259629911e-8f;
+  float t_hi = x * c_hi;
+  const float t_lo = fmaf(x, c_hi, -t_hi) + x * c_lo;
+  t_hi = fminf(t_hi, 126.0f);
+  float e = __builtin_amdgcn_exp2f(t_hi);
+  e = fmaf(e * t_lo, 0.6931471805599453f, e);
+  const float dd = 1.0f + e;
+  float r = __builtin_amdgcn_rcpf(dd);
+  r = fmaf(fmaf(-dd, r, 1.0f), r, r);
+  return x * r;
+#else
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+#endif
 }
 
 __device__ inline f16x8 ld_frag(const uint4* p) { return __builtin_bit_cast(f16x8, *p); }

@@ -687,7 +687,7 @@ def _run_long_chain(hip, golden, name, dtype, batch=1):
     return g, rep, img
 
 
-@pytest.mark.parametrize("name", ["G19_chain1000_ancestral_64", "G20_ddim250_128", "G21_ddim250_256", "G22_chain1000_ancestral_128"])
+@pytest.mark.parametrize("name", ["G19_chain1000_ancestral_64", "G20_ddim250_128", "G21_ddim250_256", "G21b_ddim250_256", "G22_chain1000_ancestral_128"])
 def test_long_chain_fp32_north_star(hip, golden, name):
     g, rep, img = _run_long_chain(hip, golden, name, "fp32")
     spread = float(g["xyz_spread_1_vs_8_threads_m"])
@@ -697,13 +697,16 @@ def test_long_chain_fp32_north_star(hip, golden, name):
           f"|hip - exact|max {maxerr(torch.from_numpy(img), g['sampled_exact']) * 10:.3e} m; saturated {rep['saturated_fraction']:.4f}")
     assert rep["same_valid_mask"] and rep["points"][0] == rep["points"][1]
     assert rep["saturated_fraction"] < 0.2
-    if rep["xyz_linf_m"] > max(1e-4, spread):
-        # A chain on which the reference sits farther from exact arithmetic than its own thread-count spread (G21: 4.3e-4 m
-        # from its float64 twin, 1.8e-4 m between 1 and 8 threads — both runs share most of their roundoff): an implementation
-        # that is CLOSER to exact arithmetic cannot also be inside that spread.  Then, as for G12: at most half as far from
-        # exact arithmetic as the reference is, and no farther from the reference than the reference is from exact.
+    if name != "G21_ddim250_256":
+        # the north star, literally (round 4): observed G19 4.5e-6 m, G20 2.8e-5 m, G21b 3.6e-5 m, G22 (the headline chain) 6.0e-6 m
+        assert rep["xyz_linf_m"] <= 1e-4, rep
+    else:
+        # G21 (seed-21 weights at 256x256, kept as the stress case; G21b is the same chain on a calibrated seed): 16.6 % of the
+        # REFERENCE's own in-painted pixels end on the clamp and the reference sits 4.3e-4 m from its float64 twin, farther than its
+        # 1-vs-8-thread spread (1.8e-4 m) — an implementation that is CLOSER to exact arithmetic cannot also be inside that spread.
+        # There: at most half as far from exact arithmetic as the reference is, and no farther from it than it is from exact.
         e_exact = maxerr(torch.from_numpy(img), g["sampled_exact"])
-        print(f"{name}: outside the reference's thread spread; |hip - exact| {e_exact:.3e} vs |reference - exact| {float(g['depth_ref_to_exact']):.3e} (depth)")
+        print(f"{name}: |hip - exact| {e_exact:.3e} vs |reference - exact| {float(g['depth_ref_to_exact']):.3e} (depth)")
         assert e_exact <= 0.5 * float(g["depth_ref_to_exact"]), (e_exact, float(g["depth_ref_to_exact"]))
         assert rep["xyz_linf_m"] <= 1.1 * float(g["xyz_ref_to_exact_m"]), rep
 
@@ -719,12 +722,15 @@ LONG_DRIFT_BOUNDS = {("G19_chain1000_ancestral_64", "bf16"): (0.08, 0.02, 0.08),
                      # run and not in the other differs by metres, so the maximum / L-infinity are not bounded here — the mean is;
                      # observed bf16 mean 4.5 cm / median 1.2 cm, mxfp8 mean 8.9 cm / median 4.0 cm)
                      ("G21_ddim250_256", "bf16"): (None, 0.09, None), ("G21_ddim250_256", "mxfp8"): (None, 0.18, None),
+                     # G21 on a calibrated seed (round 4): bounds set from the first run below
+                     # observed: bf16 max 0.84 / mean 0.0257 / xyz 0.88 m, mxfp8 0.92 / 0.0439 / 0.90 (the maximum is a depth-discontinuity pixel)
+                     ("G21b_ddim250_256", "bf16"): (None, 0.052, None), ("G21b_ddim250_256", "mxfp8"): (None, 0.09, None),
                      # the headline chain itself (round 4): 1000-step ancestral DDNM @128x128, B = 64
                      # observed: bf16 0.052 / 0.0107 / 0.053, mxfp8 0.277 / 0.059 / 0.289
                      ("G22_chain1000_ancestral_128", "bf16"): (0.11, 0.022, 0.11), ("G22_chain1000_ancestral_128", "mxfp8"): (0.56, 0.12, 0.58)}
 
 
-@pytest.mark.parametrize("name", ["G19_chain1000_ancestral_64", "G20_ddim250_128", "G21_ddim250_256", "G22_chain1000_ancestral_128"])
+@pytest.mark.parametrize("name", ["G19_chain1000_ancestral_64", "G20_ddim250_128", "G21_ddim250_256", "G21b_ddim250_256", "G22_chain1000_ancestral_128"])
 @pytest.mark.parametrize("dtype", ["bf16", "mxfp8"])
 def test_long_chain_reduced_precision_drift_in_metres(hip, golden, name, dtype):
     """The throughput modes on the same chains, at the benchmarked batch sizes (B = 64 at 64x64 / 128x128, B = 16 at 256x256:
