@@ -259,3 +259,34 @@ def test_downsample_equals_two_by_two_taps_over_space_to_depth():
             weq[:, (2 * dy + dx) * C:(2 * dy + dx + 1) * C, 1 + by, 1 + bx] = w[:, :, ky, kx]
     got = torch.nn.functional.conv2d(v, weq, None, padding=1)[:, :, :H // 2, :Wd // 2]
     assert float((got - ref).abs().max()) < 1e-12
+
+
+def test_job_seed_is_drawn_once_and_published_to_every_rank():
+    """the job seed is drawn on rank 0 (secrets.randbits) and published through a c10d store on
+    MASTER_ADDR:MASTER_PORT — identical on every rank of a launch, fresh on the next launch even with the SAME rendezvous id
+    and port, independent of launcher pids / restart counters; PRG_JOB_SEED pins it."""
+    import socket
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); from pointreggpt_amd import sharding; print(sharding.job_seed())" % ROOT
+
+    def launch(extra=None):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       TORCHELASTIC_RUN_ID="fixed-id", TORCHELASTIC_RESTART_COUNT=str(r))
+            env.pop("PRG_JOB_SEED", None)
+            env.update(extra or {})
+            procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+        return [int(o[0].strip().splitlines()[-1]) for o in outs]
+
+    a, b = launch(), launch()
+    assert a[0] == a[1] and b[0] == b[1], (a, b)
+    assert a[0] != b[0], "two launches with the same rendezvous id must not share a seed"
+    assert 0 <= a[0] < (1 << 63)
+    assert launch({"PRG_JOB_SEED": "1234"}) == [1234, 1234]
