@@ -7,7 +7,7 @@ writes ./<dataset_name>/data/scene-XXXXXX/{sample-000000.cloud.ply, sample-00000
 sample-*.pose.txt, *.png}.  The hot path runs on the MI355X HIP library.  Additive flags (defaults = the reference's
 hard-coded literals, generate_dataset.py:32-55):
   --image_size 256  --timesteps 1000  --sampling_timesteps 250  --batch_size 4  --dim 64
-  --dtype fp32|bf16|mxfp8   fp32 (default: the reference runs with amp=False, generate_dataset.py:54) is the parity mode;
+  --dtype fp32|f16x3|bf16|mxfp8   f16x3 = float32 storage, split-f16 MFMA contractions: the parity tolerance at 3x the speed; fp32 (default: the reference runs with amp=False, generate_dataset.py:54) is the parity mode;
                             bf16 = BASELINE configs[1-3] throughput mode; mxfp8 = configs[4] (3x3 convs on block-scaled fp8 MFMA)
   --data_root /path/to/3DMatch-RGBD/train
   --streams 2         lanes per GPU: batches are dealt round-robin to N host threads / HIP streams with their own network
@@ -37,7 +37,7 @@ def main():
     p.add_argument("--sampling_timesteps", default=250, type=int)
     p.add_argument("--batch_size", default=4, type=int)
     p.add_argument("--dim", default=64, type=int)
-    p.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "mxfp8"],
+    p.add_argument("--dtype", default="fp32", choices=["fp32", "f16x3", "bf16", "mxfp8"],
                    help="arithmetic of the two U-Nets: fp32 = parity mode (the reference's amp=False), bf16 / mxfp8 = throughput modes")
     p.add_argument("--streams", default=2, type=int,
                    help="concurrent lanes per GPU (own network handles + HIP stream + host thread each; batches dealt round-robin)")
