@@ -5,7 +5,7 @@
 set -e
 TAG=$1
 ROOT=$GRAFT_REPO_ROOT
-ARGS="--steps 1 --warmup 0 --streams 1 --sampling-steps 2 --no-cpu-baseline --no-roofline --no-e2e-files --no-drift --no-configs4"
+ARGS="--steps 1 --warmup 0 --streams 1 --sampling-steps 2 --no-cpu-baseline --no-roofline --no-e2e-files --no-drift --no-configs4 --no-parity-mode"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_$C -o r -- python $ROOT/bench.py $ARGS > $ROOT/gpurun_out/${TAG}_$C.log 2>&1 || true
