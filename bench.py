@@ -401,7 +401,7 @@ def configs4_leg(a, G, synthetic, rank):
     return res
 
 
-def parity_mode_leg(a, G, synthetic, rank, dt):
+def parity_mode_leg(a, G, synthetic, rank, dt, shape=None):
     """The headline workload (full pipeline, B x S x S, ancestral DDNM) in a float32-storage precision mode: `fp32` = the parity
     mode (exact-f32 MFMA, float64 partial sums) and `f16x3` = the same storage and normalisation arithmetic with every
     convolution as three f16 MFMAs on hi/lo-split operands.  `parity_transitions` ancestral transitions are timed (the first
@@ -409,10 +409,13 @@ def parity_mode_leg(a, G, synthetic, rank, dt):
     from pointreggpt_amd.diffusion import GaussianDiffusion
     from pointreggpt_amd.unet import MaskUnet, Unet
     B, S, T = a.batch, a.size, a.timesteps
+    steps = None
+    if shape is not None:                      # (batch, image size, DDIM steps): the shipped setting, generate_dataset.py:34-49
+        B, S, steps = shape
     dev = torch.device("cuda", torch.cuda.current_device())
     unet = Unet(a.dim, dtype=dt).init_synthetic(seed=1, calibrated=True)
     mask = MaskUnet(a.dim, dtype=dt).init_synthetic(seed=2, calibrated=True)
-    diff = GaussianDiffusion(unet, image_size=S, timesteps=T)
+    diff = GaussianDiffusion(unet, image_size=S, timesteps=T, sampling_timesteps=steps)
     full = len(diff.step_table())
     nt = min(a.parity_transitions, full)
     rows = diff.step_table()[:nt]
@@ -446,15 +449,16 @@ def parity_mode_leg(a, G, synthetic, rank, dt):
     t_s = ev[0].elapsed_time(ev[1]) * 1e-3
     t_full = (t_all - t_s) + t_s * (full / nt)
     tflop_pair = (full * UNET_GFLOP.get(S, 58.976 * (S / 128) ** 2) + 2 * MASK_GFLOP.get(S, 59.173 * (S / 128) ** 2)) / 1e3
-    res = {"dtype": dt, "pairs_per_s": B / t_full, "unit": "pairs/s", "batch": B, "image_size": S, "sampler": "ancestral-ddnm",
+    res = {"dtype": dt, "pairs_per_s": B / t_full, "unit": "pairs/s", "batch": B, "image_size": S,
+           "sampler": "ddim" if steps else "ancestral-ddnm",
            "timed_transitions": nt, "extrapolated_to": full, "seconds_timed": t_all, "seconds_sampler_timed": t_s,
            "ms_per_transition": t_s / nt * 1e3, "streams": 1, "tflop_per_pair": tflop_pair,
-           "how": f"full pipeline on one stream, one warm-up batch, one timed batch of {nt} ancestral transitions (hipGraph replay); "
+           "how": f"full pipeline on one stream, one warm-up batch, one timed batch of {nt} transitions (hipGraph replay); "
                   f"pairs/s = B / (non-sampler time + sampler time x {full}/{nt})"}
     if not a.no_roofline:
         npr = min(10, nt)
         prow = rows[:npr]
-        pdiff = GaussianDiffusion(unet, image_size=S, timesteps=T)
+        pdiff = GaussianDiffusion(unet, image_size=S, timesteps=T, sampling_timesteps=steps)
         pdiff.step_table = lambda: prow
         bt = batches[1]
         rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
@@ -736,6 +740,8 @@ def main():
         # test_long_chain_fp32_north_star), at the headline shape: what "correct" costs next to the bf16 headline
         pm = {dt: parity_mode_leg(a, G, synthetic, rank, dt) for dt in ("fp32", "f16x3")}
         pm["f16x3_vs_fp32"] = pm["f16x3"]["pairs_per_s"] / pm["fp32"]["pairs_per_s"]
+        # ... and at the shipped setting (256x256, 250-step DDIM: configs[4]'s shape, generate_dataset.py:34-49) in the tolerance-holding mode
+        pm["f16x3_256_ddim250"] = parity_mode_leg(a, G, synthetic, rank, "f16x3", shape=(a.c4_batch, 256, 250))
         pm["headline_vs_fp32"] = value / pm["fp32"]["pairs_per_s"]
         pm["tolerance"] = ("point-XYZ L-infinity vs the reference: fp32 5.96e-6 m / f16x3 8.0e-6 m on G22 (this workload's chain), "
                            "2.8e-5 / 6.2e-5 m on G20 (250-step DDIM): drift_vs_reference below, tests -m gpu")
