@@ -158,9 +158,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int NW = 4, BN = 64, TM = 1;
   constexpr int CH = 32;                       // channels per chunk: one LDS row = 64 B of hi halves + 64 B of lo halves
   constexpr int HP = TW + 2, HALO = (TH + 2) * HP;
-  constexpr int PITCH = 144;                   // halo row pitch in bytes
+  constexpr int PITCH = 144;                   // halo pixel pitch in bytes (128 + 16: consecutive pixels on distinct 16-byte slots)
+  // halo ROW stride: a multiple of 256 bytes (16 slots).  A 16-wide tile puts lanes 16-31 of a fragment load one halo row below
+  // lanes 0-15; with the natural stride (18 x 144 B = 2 slots mod 16) two lanes of every ds_read_b128 lane group met on a bank
+  // (SQ_LDS_BANK_CONFLICT above SQ_ACTIVE_INST_LDS); with a stride of 0 mod 16 slots the two half rows interleave exactly.
+  constexpr int RSTRIDE = (HP * PITCH + 255) / 256 * 256;
   constexpr int NH = (HALO + 63) / 64;         // staging passes per chunk (64 halo pixels each)
-  constexpr int HBYTES = HALO * PITCH;
+  constexpr int HBYTES = (TH + 2) * RSTRIDE;
   constexpr int WPW = BN / 8 / NW;             // global_load_lds wave-instructions (8 rows each) per wave and weight tile
   constexpr int DIST = 8 - NH;                 // taps between a staging pass's load and its conversion / LDS write (last write at tap 7:
                                                // tap 8's body already issues the next chunk's first fragment loads)
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   // fragment addresses: one per-lane base each, everything else immediate
   const int pix = wave * 32 + l31;
-  const int a_lane = ((pix / TW) * HP + (pix % TW)) * PITCH + hi * 16;            // + buffer + tap offset + step * 32 (+ 64: lo)
+  const int a_lane = (pix / TW) * RSTRIDE + (pix % TW) * PITCH + hi * 16;         // + buffer + tap offset + step * 32 (+ 64: lo)
   int b_lane[2][2];                                                                // [step][hi / lo], + ring slot + j * 4096
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
@@ -221,7 +225,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     b_lane[st][0] = l31 * 128 + ((unit ^ sw) << 4);
     b_lane[st][1] = l31 * 128 + (((4 + unit) ^ sw) << 4);
   }
-  const int w_lane = prow * PITCH + q * 16;                                        // staging write: + pass * 64 * PITCH (+ 64: lo)
+  int w_lane[NH];                                                                  // staging write address of pass k (+ 64: lo)
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int hp = prow + k * 64;
+    w_lane[k] = (hp / HP) * RSTRIDE + (hp % HP) * PITCH + q * 16;
+  }
 
   // one staging pass: load (global -> registers) and, one tap later, prologue + split + write (registers -> LDS)
   float4 hh0[NH], hh1[NH];                     // one register pair per pass: a pass is written DIST taps after its load
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #else
       split8(v, vh, vl);
 #endif
-      char* p = Ah + buf * HBYTES + w_lane + k * 64 * PITCH;
+      char* p = Ah + buf * HBYTES + w_lane[k];
       *reinterpret_cast<uint4*>(p) = vh;
       *reinterpret_cast<uint4*>(p + 64) = vl;
     }
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // fragment loads of (chunk buffer cb, tap T) into register set S; ring slot T % NS (9 taps per chunk and NS = 3) or runtime
   auto reads = [&](auto SET, auto TAP, int cb, int slot) {
     constexpr int S = decltype(SET)::value, T = decltype(TAP)::value;
-    constexpr int toff = ((T / 3) * HP + (T % 3)) * PITCH;
+    constexpr int toff = (T / 3) * RSTRIDE + (T % 3) * PITCH;
     const char* A = Ah + cb * HBYTES + a_lane + toff;
     const char* Bb = Bs + slot * (BN * 128);
 #pragma unroll
@@ -480,6 +489,356 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     g_split_trace[4] = (unsigned long long)(t_loop - t_begin);
     g_split_trace[5] = (unsigned long long)(clock64() - t_loop);
     g_split_trace[6] = (unsigned long long)niter;
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1, Cout % 128 == 0: the WAVE-SPECIALISED form (second half of round 4)
+// ---------------------------------------------------------------------------------------------
+// The symmetric kernel above is LDS-read bound at one ds_read_b128 per MFMA (32 x 64 wave tiles: larger ones do not fit its 256
+// registers beside the staging state) and its two identical workgroups per CU run in lockstep.  Here a 512-thread workgroup owns
+// a CU and its waves have DIFFERENT jobs, so the phases really overlap:
+//   waves 0-3  CONSUMERS, one per SIMD: 64 pixels x 64 channels each (2 x 2 over the 128-pixel x 128-channel tile): per tap 16
+//              fragment loads for 24 MFMAs (0.67 per MFMA), double-buffered per k16 step — step 1's fragments load beside step
+//              0's MFMAs, the NEXT tap's step 0 beside step 1's; they never touch global memory, never convert, and their
+//              barrier carries no wait at all;
+//   waves 4-5  HALO producers: all passes of the next chunk's halo loaded at tap 0 (48 registers: they have no accumulators),
+//              prologue + split + ds_write at taps 2-7 into the other halo buffer;
+//   waves 6-7  WEIGHT producers: global_load_lds of tile t + 3 into a ring of four, `s_waitcnt vmcnt(8)` = tile t + 2 landed.
+//              Their own waves because vmcnt retires IN ORDER: behind the halo's HBM loads a counted wait on the weight
+//              prefetch would wait for HBM.
+// One raw s_barrier per tap for the eight waves; invariant at barrier(t): weight tiles t and t + 1 are in LDS (so a consumer may
+// fetch tile t + 1's first fragments before barrier(t + 1)), tile t - 1's slot is free.  The epilogue is wave-local (each
+// consumer transposes its own tile through a private LDS stage; GroupNorm partial sums per (tile, pixel half) slab): no
+// workgroup barrier after the one that ends the main loop.
+template <int NS>
+__global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaunch<float> L, const int tiles_x, const int tiles_y,
+                                                                  const int tiles_n, const int fuse_stats) {
+  constexpr int TH = 8, TW = 16, BN = 128, CH = 32;
+  constexpr int HP = TW + 2, HALO = (TH + 2) * HP, PITCH = 144;
+  constexpr int RSTRIDE = (HP * PITCH + 255) / 256 * 256, HBYTES = (TH + 2) * RSTRIDE;   // (row stride 0 mod 16 slots: see above)
+  constexpr int NHP = (HALO * 4 + 127) / 128;            // halo staging passes of the 128 halo-producer threads (6)
+  constexpr int WPW = BN / 8 / 2;                        // global_load_lds instructions per weight-producer wave and tile (8)
+  static_assert(NS == 4 && NHP <= 6, "ring");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ah = smem;                                 // [2][HALO] rows of PITCH bytes
+  char* const Bs = smem + 2 * HBYTES;                    // [NS][128][128 B], units XOR-swizzled by (row >> 1) & 7
+
+  const ConvDesc& d = L.d;
+  const int nblk = tiles_x * tiles_y * tiles_n * d.B;
+  int tn, lin;
+  if (tiles_n > 1 && 8 % tiles_n == 0 && nblk % 8 == 0) {  // every XCD pinned to one output-channel tile (its weight slice stays in L2)
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = 8 / tiles_n;
+    tn = xcd % tiles_n;
+    lin = idx * per + xcd / tiles_n;
+  } else {
+    lin = xcd_remap(blockIdx.x, nblk);
+    tn = lin % tiles_n;
+    lin /= tiles_n;
+  }
+  const int tx = lin % tiles_x; lin /= tiles_x;
+  const int ty = lin % tiles_y;
+  const int b = lin / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nchunks = (d.C0 + d.C1) / CH, niter = nchunks * 9;
+  const size_t wstep = (size_t)d.CoutPad * 128;
+  const char* wtile = reinterpret_cast<const char*>(L.w_split + (size_t)tn * BN * 64);
+
+  if (wave >= 6) {
+    // ------------------------------------------------ weight producers ------------------------------------------------
+    const int pw = wave - 6;
+    int wsrc[WPW];
+#pragma unroll
+    for (int r = 0; r < WPW; ++r) {
+      const int n = (pw * WPW + r) * 8 + (lane >> 3);
+      wsrc[r] = n * 128 + (((lane & 7) ^ ((n >> 1) & 7)) << 4);
+    }
+    auto gload_b = [&](int it) {
+      const int c = it / 9, tap = it - 9 * c;
+      const char* p = wtile + (size_t)(tap * L.split_kchunks + c) * wstep;
+      char* dst = Bs + ((it & (NS - 1)) * BN + pw * WPW * 8) * 128;
+#pragma unroll
+      for (int r = 0; r < WPW; ++r)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
+                                         (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
+    };
+    gload_b(0);
+    if (niter > 1) gload_b(1);
+    if (niter > 2) gload_b(2);
+    // tiles 0 and 1 landed (tile 2 may fly on)
+    if (niter > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int it = 0; it < niter; ++it) {
+      if (it + 3 < niter) {
+        gload_b(it + 3);                                   // into tile it - 1's slot, free since barrier(it)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WPW) : "memory");   // tile it + 2 landed -> barrier(it + 1)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    return;
+  }
+  if (wave >= 4) {
+    // ------------------------------------------------- halo producers -------------------------------------------------
+    const int pt = tid - 256, q = pt & 3, prow = pt >> 2;  // channels q * 8 .. + 7 of halo pixels prow + 32 k
+    int hsrc[NHP];
+#pragma unroll
+    for (int k = 0; k < NHP; ++k) {
+      const int hp = prow + k * 32;
+      hsrc[k] = -1;
+      if (hp < HALO) {
+        const int hy = hp / HP, hx = hp - hy * HP;
+        int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        if ((unsigned)y < (unsigned)d.Hout && (unsigned)x < (unsigned)d.Wout) {
+          if (d.ups) { y >>= 1; x >>= 1; }
+          hsrc[k] = (b * d.Hin + y) * d.Win + x;
+        }
+      }
+    }
+    float4 g0[NHP], g1[NHP];
+    auto load_chunk = [&](int chunk) {
+      const int c = chunk * CH + q * 8;
+      const bool first = c < d.C0;
+      const float* base = first ? L.src0 : L.src1;
+      const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+#pragma unroll
+      for (int k = 0; k < NHP; ++k) {
+        const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
+        g0[k] = p[0];
+        g1[k] = p[1];
+      }
+    };
+    float pa[8], pb[8];
+    auto pro_load = [&](int chunk) {
+      if (L.pro_a) {
+        const float4* a4 = reinterpret_cast<const float4*>(L.pro_a + (size_t)b * d.C0 + chunk * CH + q * 8);
+        const float4* b4 = reinterpret_cast<const float4*>(L.pro_b + (size_t)b * d.C0 + chunk * CH + q * 8);
+        const float4 a0 = a4[0], a1 = a4[1], b0 = b4[0], b1 = b4[1];
+        pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w; pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+        pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
+      }
+    };
+    auto write_pass = [&](int buf, auto K) {
+      constexpr int k = decltype(K)::value;
+      const int hp = prow + k * 32;
+      if (hp < HALO) {
+        float v[8] = {g0[k].x, g0[k].y, g0[k].z, g0[k].w, g1[k].x, g1[k].y, g1[k].z, g1[k].w};
+        if (L.pro_a) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = silu_fast(fmaf(v[u], pa[u], pb[u]));
+        }
+        if (hsrc[k] < 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = 0.0f;
+        }
+        uint4 vh, vl;
+        split8(v, vh, vl);
+        char* p = Ah + buf * HBYTES + (hp / HP) * RSTRIDE + (hp % HP) * PITCH + q * 16;
+        *reinterpret_cast<uint4*>(p) = vh;
+        *reinterpret_cast<uint4*>(p + 64) = vl;
+      }
+    };
+    pro_load(0);
+    load_chunk(0);
+    write_pass(0, IC<0>()); write_pass(0, IC<1>()); write_pass(0, IC<2>());
+    write_pass(0, IC<3>()); write_pass(0, IC<4>()); write_pass(0, IC<5>());
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + 1 < nchunks;
+      const int nb = (c + 1) & 1;
+      // tap 0: the next chunk's coefficients and ALL its halo loads; taps 2 .. 7: one pass each converted and written (the
+      // other halo buffer was last read during the previous chunk's tap 8, i.e. before barrier(9 c)); tap 8: nothing —
+      // the consumers fetch the next chunk's first fragments during it
+      if (more) { pro_load(c + 1); load_chunk(c + 1); }
+      asm volatile("s_barrier" ::: "memory");                                   // -> barrier(9 c + 1)
+      asm volatile("s_barrier" ::: "memory");                                   // -> barrier(9 c + 2)
+      if (more) write_pass(nb, IC<0>());
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) write_pass(nb, IC<1>());
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) write_pass(nb, IC<2>());
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) write_pass(nb, IC<3>());
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) write_pass(nb, IC<4>());
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) write_pass(nb, IC<5>());
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // -> barrier(9 c + 8)
+      asm volatile("s_barrier" ::: "memory");                                   // -> barrier(9 c + 9)
+    }
+    return;
+  }
+  // ---------------------------------------------------- consumers -----------------------------------------------------
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int a_lane[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = wm * 64 + i * 32 + l31;
+    a_lane[i] = (pix / TW) * RSTRIDE + (pix % TW) * PITCH + hi * 16;
+  }
+  int b_lane[2][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int sw = (l31 >> 1) & 7, unit = 2 * st + hi;
+    b_lane[st][0] = wn * 8192 + l31 * 128 + ((unit ^ sw) << 4);
+    b_lane[st][1] = wn * 8192 + l31 * 128 + (((4 + unit) ^ sw) << 4);
+  }
+  f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }
+  f16x8 fa[2][4], fw[2][4];                              // [k16 step][A: (hi, lo) x row tile | W: (hi, lo) x column tile]
+  auto reads = [&](auto ST, auto TAP, int cb, int slot) {
+    constexpr int st = decltype(ST)::value, T = decltype(TAP)::value;
+    constexpr int toff = (T / 3) * RSTRIDE + (T % 3) * PITCH;
+    const char* A = Ah + cb * HBYTES + toff + st * 32;
+    const char* Bb = Bs + slot * (BN * 128);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[st][2 * i] = ld_frag(reinterpret_cast<const uint4*>(A + a_lane[i]));
+      fa[st][2 * i + 1] = ld_frag(reinterpret_cast<const uint4*>(A + a_lane[i] + 64));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fw[st][2 * j] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][0] + j * 4096));
+      fw[st][2 * j + 1] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][1] + j * 4096));
+    }
+  };
+  auto mfmas = [&](auto ST) {
+    constexpr int st = decltype(ST)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i + 1], fw[st][2 * j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j + 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j], acc[i][j], 0, 0, 0);
+  };
+#if PRG_SPLIT_EXP == 6
+  unsigned long long ws_wait = 0;
+  const bool ws_trace = blockIdx.x == 0 && tid == 0;
+#endif
+  auto body = [&](auto TAP, int c) {
+    constexpr int T = decltype(TAP)::value;
+    const int it = c * 9 + T;
+    const bool more = c + 1 < nchunks;
+    // barrier #it (tap 0 runs straight after the prologue's barrier #0): weight tiles it, it + 1 are in LDS, tile it - 1's slot
+    // is free for the producers, this chunk's halo is complete.  No wait: a consumer's outstanding fragment loads read only
+    // images that stay valid for another tap.
+#if PRG_SPLIT_EXP == 6
+    const long long tb0 = clock64();
+    if (T > 0 || c > 0) asm volatile("s_barrier" ::: "memory");
+    const long long tb1 = clock64();
+    if (ws_trace) { ws_wait += (unsigned long long)(tb1 - tb0); }
+#else
+    if (T > 0 || c > 0) asm volatile("s_barrier" ::: "memory");
+#endif
+    reads(IC<1>(), TAP, c & 1, it & (NS - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<0>());
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (T < 8) reads(IC<0>(), IC<T + 1>(), c & 1, (it + 1) & (NS - 1));
+    else if (more) reads(IC<0>(), IC<0>(), (c + 1) & 1, (it + 1) & (NS - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<1>());
+    if constexpr (T == 8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
+    }
+  };
+#if PRG_SPLIT_EXP == 6
+  const long long tw0 = clock64();
+#endif
+  asm volatile("s_barrier" ::: "memory");                // the producers' prologue: chunk 0's halo, weight tiles 0 and 1
+#if PRG_SPLIT_EXP == 6
+  const long long tw1 = clock64();
+#endif
+  reads(IC<0>(), IC<0>(), 0, 0);
+  for (int c = 0; c < nchunks; ++c) {
+    body(IC<0>(), c); body(IC<1>(), c); body(IC<2>(), c); body(IC<3>(), c); body(IC<4>(), c);
+    body(IC<5>(), c); body(IC<6>(), c); body(IC<7>(), c); body(IC<8>(), c);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier(niter): every consumer is done with the LDS images
+#if PRG_SPLIT_EXP == 6
+  const long long tw2 = clock64();
+#endif
+  // wave-local epilogue: 32 x 64 sub-tiles through this wave's private stage (rows of 68 floats), bias, statistics, 16-byte stores
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * 68;
+  const int cc = lane & 7, rr = lane >> 3;
+  const int col = tn * BN + wn * 64 + cc * 8;
+  float bias[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) bias[u] = L.bias ? L.bias[col + u] : 0.0f;
+  double gs = 0.0, gq = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * hi) * 68 + j * 32 + l31] = tot[i][j][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: program order + this wait is all the LDS hand-off needs)
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = pass * 8 + rr;
+      const int p = wm * 64 + i * 32 + r;
+      const size_t m = ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+      const float4 v0 = *reinterpret_cast<const float4*>(stage + r * 68 + cc * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(stage + r * 68 + cc * 8 + 4);
+      float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3], v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
+      float s8 = 0.0f, q8 = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s8 += v[u]; q8 = fmaf(v[u], v[u], q8); }
+      gs += (double)s8;
+      gq += (double)q8;
+      float* o = L.out + m * d.Cout + col;
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads above are done before the next sub-tile overwrites the stage
+  }
+  if (fuse_stats) {
+    // lanes with equal (lane & 7) stored the same 8-channel chunk: fold the 8 row-lanes, then the chunks of a group
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      gs += __shfl_xor(gs, o, 64);
+      gq += __shfl_xor(gq, o, 64);
+    }
+    const int cpg = d.Cout / L.gn_groups;                // 16, 32 or 64 here: 2, 4 or 8 chunks per group
+    for (int o = 1; o < cpg / 8; o <<= 1) {
+      gs += __shfl_xor(gs, o, 64);
+      gq += __shfl_xor(gq, o, 64);
+    }
+    if (lane < 8 && (lane & (cpg / 8 - 1)) == 0) {
+      const int nsplit = tiles_x * tiles_y * 2;
+      const int g = col / cpg;
+      float* dst = L.gn_partials + (((size_t)b * nsplit + (ty * tiles_x + tx) * 2 + wm) * L.gn_groups + g) * 2;
+      dst[0] = (float)gs;
+      dst[1] = (float)gq;
+    }
+  }
+#if PRG_SPLIT_EXP == 6
+  if (ws_trace) {
+    g_split_trace[8] = ws_wait;
+    g_split_trace[9] = (unsigned long long)(tw1 - tw0);
+    g_split_trace[10] = (unsigned long long)(tw2 - tw1);
+    g_split_trace[11] = (unsigned long long)(clock64() - tw2);
+    g_split_trace[12] = (unsigned long long)niter;
   }
 #endif
 }
@@ -640,10 +999,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
 template <int TH, int TW>
 static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse_stats, int* nsplit) {
   constexpr int HALO = (TH + 2) * (TW + 2);
-  constexpr int NS = (2 * HALO * 144 + 3 * 8192) * 2 <= 160 * 1024 ? 3 : 2;   // weight ring slots: two workgroups must fit a CU
+  constexpr int RSTRIDE = ((TW + 2) * 144 + 255) / 256 * 256, HB = (TH + 2) * RSTRIDE;
+  constexpr int NS = (2 * HB + 3 * 8192) * 2 <= 160 * 1024 ? 3 : 2;   // weight ring slots: two workgroups must fit a CU
   const ConvDesc& d = L.d;
   const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH, tiles_n = d.Cout / 64;
-  size_t lds = (size_t)2 * HALO * 144 + NS * 8192;
+  size_t lds = (size_t)2 * HB + NS * 8192;
   if (lds < kEpilogueLds) lds = kEpilogueLds;
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
   static std::atomic<bool> attr_done{false};   // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race between lanes is benign)
@@ -667,6 +1027,31 @@ static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse
     fprintf(stderr, "trace Cin %d Cout %d %dx%d: iterations %llu | per iteration: wait+barrier %.0f, staging(+floated MFMAs) %.0f, glds+reads %.0f, "
             "mfma issue %.0f | loop total %llu, epilogue %llu cycles\n", d.C0 + d.C1, d.Cout, d.Hout, d.Wout, h[6], (double)h[0] / h[6], (double)h[1] / h[6],
             (double)h[2] / h[6], (double)h[3] / h[6], h[4], h[5]);
+  }
+#endif
+  return PRG_OK;
+}
+
+static int launch_split_ws(const ConvLaunch<float>& L, hipStream_t s, int fuse_stats, int* nsplit) {
+  constexpr int NS = 4, HB = 10 * ((18 * 144 + 255) / 256 * 256);
+  const ConvDesc& d = L.d;
+  const int tiles_x = d.Wout / 16, tiles_y = d.Hout / 8, tiles_n = d.Cout / 128;
+  const size_t lds = (size_t)2 * HB + NS * 128 * 128;
+  if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * 2 : 0;
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done.load(std::memory_order_acquire)) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done.store(true, std::memory_order_release);
+  }
+  conv3x3_split_ws_kernel<NS><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
+  PRG_LAUNCH_CHECK();
+#if PRG_SPLIT_EXP == 6
+  {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_split_trace), sizeof(h));
+    fprintf(stderr, "ws trace Cin %d Cout %d %dx%d: taps %llu | prologue wait %llu | loop %llu cycles = %.0f per tap, of which at the barrier %.0f | "
+            "epilogue %llu\n", d.C0 + d.C1, d.Cout, d.Hout, d.Wout, h[12], h[9], h[10], (double)h[10] / h[12], (double)h[8] / h[12], h[11]);
   }
 #endif
   return PRG_OK;
@@ -714,6 +1099,13 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
     auto fuse = [&](int TH, int TW, int BN) {
       return want_stats && cpg % 8 == 0 && cpg <= BN && (W / TW) * (H / TH) <= kGnMaxSplit;
     };
+    // Cout % 128 == 0: the wave-specialised kernel (128-pixel x 128-channel tiles, one workgroup per CU); PRG_SPLIT_WS=0: never
+    static const int ws_on = [] { const char* e = std::getenv("PRG_SPLIT_WS"); return e ? std::atoi(e) : 1; }();
+    if (ws_on && d.Cout % 128 == 0 && W % 16 == 0 && H % 8 == 0 && !L.residual) {
+      const int tiles = (W / 16) * (H / 8) * 2;
+      const int f = want_stats && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 && tiles <= kGnMaxSplit;
+      if (f || !want_stats) { rc = launch_split_ws(L, s, f, gn_nsplit_out); return rc ? rc : 1; }
+    }
     static const int pref32 = [] { const char* e = std::getenv("PRG_SPLIT_TW32"); return e ? std::atoi(e) : 0; }();
     if (pref32 && W % 32 == 0 && H % 4 == 0) { rc = launch_split_halo<4, 32>(L, s, fuse(4, 32, 64), gn_nsplit_out); return rc ? rc : 1; }
     if (W % 16 == 0 && H % 8 == 0) { rc = launch_split_halo<8, 16>(L, s, fuse(8, 16, 64), gn_nsplit_out); return rc ? rc : 1; }
