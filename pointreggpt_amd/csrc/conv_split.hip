@@ -25,6 +25,9 @@
 
 #include "conv_epi.h"
 
+#ifndef PRG_SPLIT_EPI
+#define PRG_SPLIT_EPI 1       // 1: direct-store epilogue of the symmetric kernel (no LDS stage); 0: the shared transposing epilogue
+#endif
 #ifndef PRG_SPLIT_ORDER
 #define PRG_SPLIT_ORDER 0     // 1: fragment loads + weight prefetch in front of the staging code (experiment)
 #endif
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   L.out[(size_t)row_to_m(l31) * d.Cout + tn * BN + hi] = sum;
   return;
 #endif
+#if PRG_SPLIT_EPI == 0
   f32x16 res[1][2] = {{tot[0], tot[1]}};
   epilogue_store<float, 1, decltype(row_to_m), true>(L, res, stage + wave * 32 * 68, lane, tn * BN, row_to_m, gs, gq);
   if (fuse_stats) {
@@ -483,6 +487,70 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
     epilogue_stats<4, 1>(reinterpret_cast<double*>(stage + NW * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
   }
+#else
+  // DIRECT epilogue: the accumulator layout already has lanes 0-31 = 32 consecutive channels of ONE pixel (register e of half hi
+  // is pixel row (e & 3) + 8 (e >> 2) + 4 hi), so a dword store per register writes two full 128-byte lines per wave-instruction —
+  // no LDS transpose, no barrier; the GroupNorm partial sums come from lane reductions (a group's channels are adjacent lanes).
+  (void)stage; (void)gs; (void)gq;
+  {
+    const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 8;
+    float sj[2], qj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = tn * BN + j * 32 + l31;
+      const float bv = L.bias ? L.bias[ch] : 0.0f;
+      float s1 = 0.0f, q1 = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        const size_t m = ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+        const float v = tot[j][e] + bv;
+        L.out[m * d.Cout + ch] = v;
+        s1 += v;
+        q1 = fmaf(v, v, q1);
+      }
+      sj[j] = s1;
+      qj[j] = q1;
+    }
+    if (fuse_stats) {
+      // a lane holds (sum, sumsq) of ONE channel over its 16 pixels: fold the two pixel halves, then the cpg adjacent channels
+      double* red = reinterpret_cast<double*>(smem + 2 * HBYTES + NS * BN * 128);      // [4 waves][2 j][4][2] beyond the images
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        double sd = (double)sj[j], qd = (double)qj[j];
+        sd += __shfl_xor(sd, 32, 64);
+        qd += __shfl_xor(qd, 32, 64);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {                 // the 8 channels of a granule are 8 adjacent lanes
+          sd += __shfl_xor(sd, o, 64);
+          qd += __shfl_xor(qd, o, 64);
+        }
+        if (hi == 0 && (l31 & 7) == 0) {                  // (8-channel granules: cpg is a multiple of 8 on this path)
+          red[((wave * 2 + j) * 4 + (l31 >> 3)) * 2] = sd;
+          red[((wave * 2 + j) * 4 + (l31 >> 3)) * 2 + 1] = qd;
+        }
+      }
+      __syncthreads();
+      // groups of this tile's 64 channels: 64 / cpg of them; thread g sums the four waves (fixed order) and the granules of a group
+      const int ng = 64 / cpg;
+      if (tid < ng) {
+        const int gran0 = tid * (cpg / 8), ngran = cpg / 8;
+        double ss = 0, qq = 0;
+        for (int w = 0; w < 4; ++w)
+          for (int k = 0; k < ngran; ++k) {
+            const int gr = gran0 + k;                       // granule 0..7 of the tile: column tile gr >> 2, lanes 8 (gr & 3) .. + 7
+            ss += red[((w * 2 + (gr >> 2)) * 4 + (gr & 3)) * 2];
+            qq += red[((w * 2 + (gr >> 2)) * 4 + (gr & 3)) * 2 + 1];
+          }
+        const int nsplit = tiles_x * tiles_y;
+        float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
+        const int g = (tn * BN) / cpg + tid;
+        dst[g * 2] = (float)ss;
+        dst[g * 2 + 1] = (float)qq;
+      }
+    }
+  }
+#endif
 #if PRG_SPLIT_EXP == 6
   if (trace_on) {
     for (int i = 0; i < 4; ++i) g_split_trace[i] = tr[i];
@@ -778,58 +846,58 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 #if PRG_SPLIT_EXP == 6
   const long long tw2 = clock64();
 #endif
-  // wave-local epilogue: 32 x 64 sub-tiles through this wave's private stage (rows of 68 floats), bias, statistics, 16-byte stores
-  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * 68;
-  const int cc = lane & 7, rr = lane >> 3;
-  const int col = tn * BN + wn * 64 + cc * 8;
-  float bias[8];
+  // DIRECT epilogue (as in the symmetric kernel): register e of lane half hi is pixel row (e & 3) + 8 (e >> 2) + 4 hi, lanes 0-31
+  // are 32 consecutive channels: a dword store per register writes two full 128-byte lines per wave-instruction; GroupNorm partial
+  // sums by lane reductions (a group's channels are adjacent lanes), one slab per (tile, pixel half): no LDS, no barrier.
+  {
+    const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 64;          // 16, 32 or 64 when the statistics are fused
+    double sd[2], qd[2];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) bias[u] = L.bias ? L.bias[col + u] : 0.0f;
-  double gs = 0.0, gq = 0.0;
+    for (int j = 0; j < 2; ++j) {
+      const int ch = tn * BN + wn * 64 + j * 32 + l31;
+      const float bv = L.bias ? L.bias[ch] : 0.0f;
+      float s1 = 0.0f, q1 = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * hi) * 68 + j * 32 + l31] = tot[i][j][e];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: program order + this wait is all the LDS hand-off needs)
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int r = pass * 8 + rr;
-      const int p = wm * 64 + i * 32 + r;
-      const size_t m = ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
-      const float4 v0 = *reinterpret_cast<const float4*>(stage + r * 68 + cc * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(stage + r * 68 + cc * 8 + 4);
-      float v[8] = {v0.x + bias[0], v0.y + bias[1], v0.z + bias[2], v0.w + bias[3], v1.x + bias[4], v1.y + bias[5], v1.z + bias[6], v1.w + bias[7]};
-      float s8 = 0.0f, q8 = 0.0f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { s8 += v[u]; q8 = fmaf(v[u], v[u], q8); }
-      gs += (double)s8;
-      gq += (double)q8;
-      float* o = L.out + m * d.Cout + col;
-      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        for (int e = 0; e < 16; ++e) {
+          const int p = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          const size_t m = ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+          const float v = tot[i][j][e] + bv;
+          L.out[m * d.Cout + ch] = v;
+          s1 += v;
+          q1 = fmaf(v, v, q1);
+        }
+      sd[j] = (double)s1;
+      qd[j] = (double)q1;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads above are done before the next sub-tile overwrites the stage
-  }
-  if (fuse_stats) {
-    // lanes with equal (lane & 7) stored the same 8-channel chunk: fold the 8 row-lanes, then the chunks of a group
+    if (fuse_stats) {
+      const int width = cpg < 32 ? cpg : 32;
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-      gs += __shfl_xor(gs, o, 64);
-      gq += __shfl_xor(gq, o, 64);
-    }
-    const int cpg = d.Cout / L.gn_groups;                // 16, 32 or 64 here: 2, 4 or 8 chunks per group
-    for (int o = 1; o < cpg / 8; o <<= 1) {
-      gs += __shfl_xor(gs, o, 64);
-      gq += __shfl_xor(gq, o, 64);
-    }
-    if (lane < 8 && (lane & (cpg / 8 - 1)) == 0) {
+      for (int j = 0; j < 2; ++j) {
+        sd[j] += __shfl_xor(sd[j], 32, 64);
+        qd[j] += __shfl_xor(qd[j], 32, 64);
+        for (int o = 1; o < width; o <<= 1) {
+          sd[j] += __shfl_xor(sd[j], o, 64);
+          qd[j] += __shfl_xor(qd[j], o, 64);
+        }
+      }
       const int nsplit = tiles_x * tiles_y * 2;
-      const int g = col / cpg;
-      float* dst = L.gn_partials + (((size_t)b * nsplit + (ty * tiles_x + tx) * 2 + wm) * L.gn_groups + g) * 2;
-      dst[0] = (float)gs;
-      dst[1] = (float)gq;
+      float* slab = L.gn_partials + ((size_t)b * nsplit + (ty * tiles_x + tx) * 2 + wm) * L.gn_groups * 2;
+      if (cpg == 64) {
+        if (lane == 0) {
+          const int g = (tn * BN + wn * 64) / 64;
+          slab[g * 2] = (float)(sd[0] + sd[1]);
+          slab[g * 2 + 1] = (float)(qd[0] + qd[1]);
+        }
+      } else if (hi == 0 && (l31 & (width - 1)) == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int g = (tn * BN + wn * 64 + j * 32 + l31) / cpg;
+          slab[g * 2] = (float)sd[j];
+          slab[g * 2 + 1] = (float)qd[j];
+        }
+      }
     }
   }
 #if PRG_SPLIT_EXP == 6
@@ -1003,7 +1071,7 @@ static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse
   constexpr int NS = (2 * HB + 3 * 8192) * 2 <= 160 * 1024 ? 3 : 2;   // weight ring slots: two workgroups must fit a CU
   const ConvDesc& d = L.d;
   const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH, tiles_n = d.Cout / 64;
-  size_t lds = (size_t)2 * HB + NS * 8192;
+  size_t lds = (size_t)2 * HB + NS * 8192 + 512;      // (+ the statistics scratch of the direct epilogue)
   if (lds < kEpilogueLds) lds = kEpilogueLds;
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
   static std::atomic<bool> attr_done{false};   // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race between lanes is benign)
