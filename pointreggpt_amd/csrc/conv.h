@@ -82,7 +82,70 @@ struct ConvLaunch {
   // [tap][32-channel chunk][CoutPad][32 hi | 32 lo]; null = the exact-f32 kernels
   const uint16_t* w_split;
   int split_kchunks;
+  // h16 (bf16 mode, round 4): the tensor between the two convs of a ResnetBlock only ever feeds conv2's fused GroupNorm + SiLU
+  // prologue, so it is stored as IEEE f16 instead of bf16 — the prologue then runs in PACKED f16 (v_pk_fma_f16, v_exp_f16,
+  // v_rcp_f16: two channels per instruction, no unpack / repack) and conv2 contracts f16 operands
+  // (v_mfma_f32_32x32x16_f16, the bf16 instruction's rate) against an f16 packing of its weights.
+  //   out_f16: this launch stores f16 bit patterns into `out` (conv1);  in_f16: src0 holds f16, the prologue is pro_fold's and
+  //   w_f16 is the f16 twin of `w`, same layout (conv2).  Only the kernels that conv_h16_pair_ok() probes implement them.
+  //   probe: try_launch_* return 1 where they would launch, without launching.
+  int out_f16 = 0, in_f16 = 0, probe = 0;
+  const uint16_t* w_f16 = nullptr;
 };
+
+#if defined(__HIPCC__)
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+// two floats -> packed f16 (v_cvt_pk_f16_f32, round to nearest even): the h16 output format
+__device__ inline uint32_t h16_pack(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  const f32x2 p = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(p, h16x2));
+}
+// GroupNorm affine + SiLU on one 16-byte unit = four packed f16 channel pairs (the h16 input format).  Per pair: v_pk_fma_f16,
+// v_pk_mul_f16, two v_exp_f16 (the second writes the upper half of the same register through SDWA: no repack), v_pk_add_f16, two
+// v_rcp_f16, v_pk_mul_f16 — eight instructions against fourteen on the bf16 / float32 path.  exp2 overflow (y < -11) ends in
+// rcp(inf) = 0 = SiLU's limit.  The transcendentals are inline asm (hipcc repacks with v_pack_b32_f16 otherwise), which hides
+// them from the hazard recogniser: gfx950 needs one wait state between a transcendental / a dst_sel write and a VALU consumer
+// of its result (LLVM: hasTransForwardingHazard, hasDstSelForwardingHazard) — the trailing s_nop of each block.
+typedef __attribute__((ext_vector_type(4))) unsigned int h16_u32x4;
+#define PRG_H16_TRANS4(OP)                                                                                             \
+  asm(OP "_e32 %0, %4\n\t" OP "_e32 %1, %5\n\t" OP "_e32 %2, %6\n\t" OP "_e32 %3, %7\n\t"                            \
+      OP "_sdwa %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                                  \
+      OP "_sdwa %1, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                                  \
+      OP "_sdwa %2, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                                  \
+      OP "_sdwa %3, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"                           \
+      : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)                                                                      \
+      : "v"(i0), "v"(i1), "v"(i2), "v"(i3))
+__device__ inline h16_u32x4 h16_silu8(h16_u32x4 x, const h16x2 (&a)[4], const h16x2 (&b)[4]) {
+  const h16x2 nl2e = {(_Float16)-1.4426950408889634f, (_Float16)-1.4426950408889634f}, one = {(_Float16)1.0f, (_Float16)1.0f};
+  h16x2 y[4];
+  uint32_t i0, i1, i2, i3, o0, o1, o2, o3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t w = x[j];   // (hipcc 7.2: __builtin_bit_cast of the vector ELEMENT x[j] reads element 0 for every j)
+    y[j] = __builtin_elementwise_fma(__builtin_bit_cast(h16x2, w), a[j], b[j]);
+  }
+  i0 = __builtin_bit_cast(uint32_t, y[0] * nl2e); i1 = __builtin_bit_cast(uint32_t, y[1] * nl2e);
+  i2 = __builtin_bit_cast(uint32_t, y[2] * nl2e); i3 = __builtin_bit_cast(uint32_t, y[3] * nl2e);
+  PRG_H16_TRANS4("v_exp_f16");
+  i0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, o0) + one); i1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, o1) + one);
+  i2 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, o2) + one); i3 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, o3) + one);
+  PRG_H16_TRANS4("v_rcp_f16");
+  h16_u32x4 r;
+  r[0] = __builtin_bit_cast(uint32_t, y[0] * __builtin_bit_cast(h16x2, o0));
+  r[1] = __builtin_bit_cast(uint32_t, y[1] * __builtin_bit_cast(h16x2, o1));
+  r[2] = __builtin_bit_cast(uint32_t, y[2] * __builtin_bit_cast(h16x2, o2));
+  r[3] = __builtin_bit_cast(uint32_t, y[3] * __builtin_bit_cast(h16x2, o3));
+  return r;
+}
+#undef PRG_H16_TRANS4
+#endif
+
+// f16 twin of pack_conv_weight<bf16_t> (same [tap][32-channel chunk][CoutPad][32] layout, IEEE f16 bits, round to nearest even)
+void pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out);
+// true when conv1 (L1, asked to store f16) and conv2 (L2, asked to read f16 through its folded prologue) of a ResnetBlock would both
+// run on kernels that implement the h16 format, L1 with fixed-point statistics; nothing is launched
+bool conv_h16_pair_ok(const ConvLaunch<bf16_t>& L1, const ConvLaunch<bf16_t>& L2);
 
 // hi / lo f16 split of a conv weight for the f16x3 mode (layout at ConvLaunch::w_split)
 void pack_conv_weight_split(const float* w_oihw, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out, int* CoutPad,

@@ -20,6 +20,7 @@
 // lines per 8 lanes) instead of 2-byte pieces, bias / residual are added on the way, and the per-(image, tile,
 // group) GroupNorm partial sums of the output are emitted in a fixed order (deterministic) for the consumer.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <type_traits>
 
@@ -802,6 +803,35 @@ static inline int try_ws(ConvLaunch<float>&, hipStream_t, int*, int*, int*) { re
 static inline int try_split(const ConvLaunch<float>& L, hipStream_t s, int* n) { return try_launch_conv_split(L, s, n); }
 static inline int try_split(const ConvLaunch<bf16_t>&, hipStream_t, int*) { return 0; }
 
+// h16 (conv.h): would both convs of a ResnetBlock take kernels that implement the f16 format?  The same try_launch_* functions
+// the dispatch below calls, in the same order, in probe mode (they stop where they would launch).
+bool conv_h16_pair_ok(const ConvLaunch<bf16_t>& L1in, const ConvLaunch<bf16_t>& L2in) {
+  // PRG_H16: 0 off; bit 0 pairs whose conv2 runs on the 64 -> 64 kernel, bit 1 on the 256-pixel kernel, bit 2 conv1 on the
+  // wave-specialised kernel (debugging aid; default 7 = everything)
+  static const int mask = [] { const char* e = std::getenv("PRG_H16"); return e ? std::atoi(e) : 7; }();
+  if (!mask) return false;
+  ConvLaunch<bf16_t> L1 = L1in, L2 = L2in;
+  if (L1.w_mx || L2.w_mx || !L2.w_f16 || !L1.gn_acc || !L2.pro_fold.acc) return false;
+  L1.probe = L2.probe = 1;
+  L1.out_f16 = 1;
+  L2.in_f16 = 1;
+  int ns = 0, cd = 0, ad = 0;
+  int r = try_launch_conv3x3_c64(L1, nullptr, &ns, &cd, &ad);
+  if (r == 0) r = try_launch_conv3x3_w256(L1, nullptr, &ns, &ad);
+  if (r == 0 && (mask & 4)) r = try_launch_conv3x3_ws(L1, nullptr, &ns, &ad);
+  static const int verbose = [] { const char* e = std::getenv("PRG_H16_VERBOSE"); return e ? std::atoi(e) : 0; }();
+  const int r1 = r, ad1 = ad;
+  int r2 = 0;
+  if (r1 == 1 && ad1) {
+    r2 = (mask & 1) ? try_launch_conv3x3_c64(L2, nullptr, &ns, &cd, &ad) : 0;
+    if (r2 == 0 && (mask & 2)) r2 = try_launch_conv3x3_w256(L2, nullptr, &ns, &ad);
+  }
+  if (verbose)
+    std::fprintf(stderr, "h16 probe: %d+%d -> %d @ %dx%d B=%d: conv1 %d (acc %d), conv2 %d\n", L1.d.C0, L1.d.C1, L1.d.Cout, L1.d.Hout, L1.d.Wout,
+                 L1.d.B, r1, ad1, r2);
+  return r1 == 1 && ad1 && r2 == 1;
+}
+
 template <typename T>
 int launch_conv(const ConvLaunch<T>& Lin, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
   if (coef_done) *coef_done = 0;
@@ -834,6 +864,7 @@ int launch_conv(const ConvLaunch<T>& Lin, hipStream_t s, int* gn_nsplit_out, int
     if (r < 0) return r;
     if (r == 1) return PRG_OK;
   }
+  PRG_CHECK(!L.out_f16 && !L.in_f16, "conv: an h16 launch reached a kernel without the f16 format (conv_h16_pair_ok disagrees with the dispatch)");
   if (int rc = materialize_prologue(L, s)) return rc;       // the generic kernels below read coefficient tables
   {
     const int r = try_split(L, s, gn_nsplit_out);           // f16x3 mode: split-operand kernels (conv_split.hip)
@@ -896,6 +927,25 @@ void pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, std::ve
 }
 template void pack_conv_weight<float>(const float*, int, int, int, int, std::vector<float>&, int*, int*);
 template void pack_conv_weight<bf16_t>(const float*, int, int, int, int, std::vector<bf16_t>&, int*, int*);
+
+void pack_conv_weight_f16(const float* w, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out) {
+  constexpr int BK = 32;
+  const int cp = (Cout + 63) / 64 * 64;
+  const int kcn = (Cin + BK - 1) / BK;
+  out.assign((size_t)KH * KW * kcn * cp * BK, 0);
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw)
+      for (int kc = 0; kc < kcn; ++kc)
+        for (int n = 0; n < Cout; ++n)
+          for (int k = 0; k < BK; ++k) {
+            const int c = kc * BK + k;
+            if (c >= Cin) break;
+            const _Float16 h = (_Float16)w[(((size_t)n * Cin + c) * KH + kh) * KW + kw];   // round to nearest even
+            uint16_t bits;
+            std::memcpy(&bits, &h, 2);
+            out[((((size_t)(kh * KW + kw)) * kcn + kc) * cp + n) * BK + k] = bits;
+          }
+}
 
 // e4m3fn (OCP): 1-4-3, bias 7, max 448, no infinities; round to nearest even, saturating
 uint8_t f32_to_e4m3(float v) {

@@ -33,6 +33,7 @@ namespace prg {
 typedef __attribute__((ext_vector_type(8))) __bf16 c64_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float c64_f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int c64_u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 c64_f16x8;
 
 namespace {
 
@@ -146,7 +147,9 @@ __device__ inline void c64_fold_coefficients(const ConvLaunch<bf16_t>& L, int im
   L.gn_coef_b[(size_t)img * 64 + c] = bb;
 }
 
-template <int PRO>   // 0: no prologue; 1: GroupNorm coefficient tables (pro_a / pro_b); 2: coefficients folded here from pro_fold
+// PRO 0: no prologue; 1: GroupNorm coefficient tables (pro_a / pro_b); 2: coefficients folded here from pro_fold; 3: as 2 on an
+// f16 input with f16 weights (the h16 format, conv.h: packed-f16 prologue, v_mfma_f32_32x32x16_f16).  O16: f16 output.
+template <int PRO, bool O16>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
                                                           const int flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const bf16_t* p = L.w + ((size_t)(tap * d.kchunks + (c >> 1)) * d.CoutPad + wn * 32 + l31) * 32 + (c & 1) * 16 + hi * 8;
+        const bf16_t* const wsrc = PRO == 3 ? reinterpret_cast<const bf16_t*>(L.w_f16) : L.w;
+        const bf16_t* p = wsrc + ((size_t)(tap * d.kchunks + (c >> 1)) * d.CoutPad + wn * 32 + l31) * 32 + (c & 1) * 16 + hi * 8;
         wf[tap][c] = *reinterpret_cast<const c64_bf16x8*>(p);
       }
     float* const bias_lds = reinterpret_cast<float*>(smem + 2 * AH_BYTES);
@@ -188,6 +192,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     const int gn_per = fuse_stats ? (64 / L.gn_groups) >> 3 : 1;   // 8-channel chunks per group (1, 2, 4 or 8)
     // LDS byte offset of pixel (row 4 wm + pt, column l31), tap (0,0), k-step 0: rows are HP * ROWB apart
     const unsigned x0off = (unsigned)(((wm * 4) * HP + l31) * ROWB + hi * 16);
+    auto mma = [](const c64_bf16x8& a, const c64_bf16x8& b, const c64_f32x16& c) -> c64_f32x16 {
+      if constexpr (PRO == 3)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c64_f16x8, a), __builtin_bit_cast(c64_f16x8, b), c, 0, 0, 0);
+      else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    };
     c64_barrier();                                         // halo 0 is in LDS (producers' prologue)
     for (int s = 0; s < nsteps; ++s) {
       const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
@@ -213,26 +223,26 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int pt = 0; pt < 4; ++pt)
-                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+                acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
               __builtin_amdgcn_sched_barrier(0);
             } else if constexpr ((PRG_C64_EXP & 128) != 0) { // variant: leave the interleave to the compiler
 #pragma unroll
               for (int pt = 0; pt < 4; ++pt) {
                 fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
-                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+                acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
               }
             } else {
 #pragma unroll
               for (int pt = 0; pt < 4; ++pt) {
                 fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
-                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+                acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
                 __builtin_amdgcn_sched_barrier(0);
               }
             }
           } else {
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt)
-              acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][c], fx[cur][pt], acc[pt], 0, 0, 0);
+              acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
           }
         }
       }
@@ -271,8 +281,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
               V[q] += v[r];
               V[4 + q] = fmaf(v[r], v[r], V[4 + q]);
             }
-            pk[2 * q] = c64_pack(v[0], v[1]);
-            pk[2 * q + 1] = c64_pack(v[2], v[3]);
+            pk[2 * q] = O16 ? h16_pack(v[0], v[1]) : c64_pack(v[0], v[1]);
+            pk[2 * q + 1] = O16 ? h16_pack(v[2], v[3]) : c64_pack(v[2], v[3]);
           }
           // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: swapping the upper half
           // of chunk 2m with the lower half of chunk 2m+1 leaves lane half 0 with all 8 channels of chunk 2m, half 1 with
@@ -312,7 +322,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           const int grp = (wn * 4 + q) / gn_per;
           if (L.gn_acc) {
             // fixed-point accumulators (common.h): one no-return 64-bit integer atomic per wave total
-            gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, i >> 2, D);
+            // (`which` made opaque here: its loop-invariant scale select otherwise lives in a VGPR across the MFMA loop — with the
+            //  f16 epilogue that was the 257th register, and the spill's reload put an s_waitcnt vmcnt(0) behind the tile's stores)
+            int which = i >> 2;
+            asm volatile("" : "+v"(which));
+            gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, which, D);
           } else {
             // agent-scope (write-through, sc1) store: the workgroup that completes the image reads these from another CU
             __hip_atomic_store(&L.gn_partials[(((size_t)tb * nsplit + slab) * L.gn_groups + grp) * 2 + (i >> 2)], D,
@@ -367,6 +381,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     int done_in_img = 0;                                   // tiles of the current image this workgroup has finished
     unsigned okmask = 0, okmask_nxt = 0;
     float4 ca[2], cb[2], ca_n[2], cb_n[2];
+    h16x2 ah2[4], bh2[4];                                  // PRO == 3: the coefficients as packed f16 channel pairs
     longlong2 fs_n = make_longlong2(0, 0);                  // PRO == 2: (sum, sumsq) of the 8-channel unit's group, fixed point
     auto issue = [&](int s, c64_u32x4(&h)[KU]) {           // loads of halo s (clamped to the last tile: harmless reloads)
       int b, y0, x0;
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         cb_n[0] = *reinterpret_cast<const float4*>(pb);
         cb_n[1] = *reinterpret_cast<const float4*>(pb + 4);
       }
-      if constexpr (PRO == 2) {
+      if constexpr (PRO >= 2) {
         // the raw material of the coefficients: this unit's group statistics and its folded gain / bias (P, Q); the
         // arithmetic happens in adopt(), a step later, when the loads have long landed
         const GnFold& f = L.pro_fold;
@@ -405,7 +420,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
 #pragma unroll
       for (int k = 0; k < KU; ++k) {
         c64_u32x4 v = h[k];
-        if constexpr (PRO && !(PRG_C64_EXP & 32)) {
+        if constexpr (PRO == 3 && !(PRG_C64_EXP & 32)) {
+          v = h16_silu8(v, ah2, bh2);
+        } else if constexpr (PRO && !(PRG_C64_EXP & 32)) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float lo = c64_silu(fmaf(c64_lo(v[j]), a8[2 * j], b8[2 * j]));
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
       if constexpr (PRO == 1) {
         ca[0] = ca_n[0]; ca[1] = ca_n[1]; cb[0] = cb_n[0]; cb[1] = cb_n[1];
       }
-      if constexpr (PRO == 2) {                            // A = rstd P, B = Q - mean A
+      if constexpr (PRO >= 2) {                            // A = rstd P, B = Q - mean A
         float mean, rstd;
         gn_fold_stats_raw(fs_n.x, fs_n.y, L.pro_fold.inv_n, mean, rstd);
 #pragma unroll
@@ -432,6 +449,16 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           ca[h2] = make_float4(rstd * ca_n[h2].x, rstd * ca_n[h2].y, rstd * ca_n[h2].z, rstd * ca_n[h2].w);
           cb[h2] = make_float4(fmaf(-mean, ca[h2].x, cb_n[h2].x), fmaf(-mean, ca[h2].y, cb_n[h2].y),
                                fmaf(-mean, ca[h2].z, cb_n[h2].z), fmaf(-mean, ca[h2].w, cb_n[h2].w));
+        }
+        if constexpr (PRO == 3) {
+          typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            ah2[2 * h2] = __builtin_convertvector((f32x2){ca[h2].x, ca[h2].y}, h16x2);
+            ah2[2 * h2 + 1] = __builtin_convertvector((f32x2){ca[h2].z, ca[h2].w}, h16x2);
+            bh2[2 * h2] = __builtin_convertvector((f32x2){cb[h2].x, cb[h2].y}, h16x2);
+            bh2[2 * h2 + 1] = __builtin_convertvector((f32x2){cb[h2].z, cb[h2].w}, h16x2);
+          }
         }
       }
     };
@@ -516,18 +543,21 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
              tiles_x * tiles_y * 2 * split_n <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
-  static std::atomic<bool> attr_done[3];     // zero-initialised; atomic: lanes launch from several host threads
+  static std::atomic<bool> attr_done[5];     // zero-initialised; atomic: lanes launch from several host threads
   const GnFold& pf = L.pro_fold;
   const bool fold_ok = pf.acc && pf.P && pf.Q && pf.G * pf.cpg == 64 && pf.cpg % 8 == 0;
   if (pf.acc && !fold_ok) return 0;
-  const int pro = fold_ok ? 2 : (L.pro_a ? 1 : 0);
-  if (!attr_done[pro]) {
-    const void* fn = pro == 2 ? reinterpret_cast<const void*>(&conv3x3_c64_kernel<2>)
-                   : pro == 1 ? reinterpret_cast<const void*>(&conv3x3_c64_kernel<1>)
-                              : reinterpret_cast<const void*>(&conv3x3_c64_kernel<0>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS);
+  if (L.in_f16 && !(fold_ok && L.w_f16)) return 0;           // h16 input: only through the folded prologue, with f16 weights
+  const int pro = L.in_f16 ? 3 : fold_ok ? 2 : (L.pro_a ? 1 : 0);
+  if (L.out_f16 && pro != 0) return 0;                       // h16 output: conv1 of a ResnetBlock (no prologue)
+  const int variant = L.out_f16 ? 4 : pro;
+  const void* const fns[5] = {reinterpret_cast<const void*>(&conv3x3_c64_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_c64_kernel<1, false>),
+                              reinterpret_cast<const void*>(&conv3x3_c64_kernel<2, false>), reinterpret_cast<const void*>(&conv3x3_c64_kernel<3, false>),
+                              reinterpret_cast<const void*>(&conv3x3_c64_kernel<0, true>)};
+  if (!attr_done[variant]) {
+    hipError_t e = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(c64 conv): ") + hipGetErrorString(e));
-    attr_done[pro] = true;
+    attr_done[variant] = true;
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 * split_n : 0;
   // the image-completing workgroup folds the statistics into the coefficients itself (no gn_coeff launch)
@@ -543,9 +573,12 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   static const int interleave_env = [] { const char* e = std::getenv("PRG_C64_INTERLEAVE"); return e ? std::atoi(e) : -1; }();
   const int interleave = interleave_env >= 0 ? interleave_env : (fold ? 0 : 1);
   const int flags = (fuse ? 1 : 0) | (interleave ? 2 : 0);
-  if (pro == 2) conv3x3_c64_kernel<2><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
-  else if (pro == 1) conv3x3_c64_kernel<1><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
-  else conv3x3_c64_kernel<0><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  if (L.probe) return 1;
+  if (variant == 4) conv3x3_c64_kernel<0, true><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  else if (pro == 3) conv3x3_c64_kernel<3, false><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  else if (pro == 2) conv3x3_c64_kernel<2, false><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  else if (pro == 1) conv3x3_c64_kernel<1, false><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
+  else conv3x3_c64_kernel<0, false><<<dim3(grid), 512, C64_LDS, s>>>(Lk, tiles_x, tiles_y, flags);
   PRG_LAUNCH_CHECK();
   return 1;
 }

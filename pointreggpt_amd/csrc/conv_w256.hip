@@ -42,6 +42,7 @@ namespace prg {
 typedef __attribute__((ext_vector_type(8))) __bf16 w2_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float w2_f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int w2_u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 w2_f16x8;
 
 namespace {
 
@@ -125,7 +126,9 @@ __device__ constexpr int w2_toff(int p) { return MODE ? (1 + p / 2) * HP + 1 + p
 template <int MODE>
 __device__ constexpr int w2_tapid(int p) { return MODE ? (1 + p / 2) * 3 + 1 + p % 2 : p; }
 
-template <int TW, int PRO, int MODE>   // PRO 0: no prologue, 1: coefficient tables, 2: coefficients folded in-kernel (pro_fold)
+// PRO 0: no prologue, 1: coefficient tables, 2: coefficients folded in-kernel (pro_fold), 3: as 2 on an f16 input with f16
+// weights (the h16 format of conv.h: packed-f16 prologue, v_mfma_f32_32x32x16_f16).  L.out_f16: f16 output (run-time flag).
+template <int TW, int PRO, int MODE>
 __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
                                                            const int tiles_n, const int fuse_stats) {
   using G = W2Geom<TW>;
@@ -177,7 +180,14 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     w2_bf16x8 fw[2][2], fx[2][4];
 #define W2_LW(SET, CT, RING, CALL) fw[SET][CT] = *reinterpret_cast<const w2_bf16x8*>(wr + (RING) * BW + (CT) * 32 * ROWB + (CALL) * 32)
 #define W2_LX(SET, PT, BASE, TOFF, CALL) fx[SET][PT] = *reinterpret_cast<const w2_bf16x8*>(BASE + (PT) * PTB + (TOFF) * ROWB + (CALL) * 32)
-#define W2_MM(SET, CT, PT) acc[CT][PT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[SET][CT], fx[SET][PT], acc[CT][PT], 0, 0, 0)
+#define W2_MM(SET, CT, PT)                                                                                                              \
+  do {                                                                                                                                    \
+    if constexpr (PRO == 3)                                                                                                               \
+      acc[CT][PT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(w2_f16x8, fw[SET][CT]), __builtin_bit_cast(w2_f16x8, fx[SET][PT]), \
+                                                           acc[CT][PT], 0, 0, 0);                                                         \
+    else                                                                                                                                  \
+      acc[CT][PT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[SET][CT], fx[SET][PT], acc[CT][PT], 0, 0, 0);                              \
+  } while (0)
 #define W2_SB() __builtin_amdgcn_sched_barrier(0)
     w2_barrier<true>();                                      // halo 0 and weight tiles 0, 1 are in LDS; the bias too
     {
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
                                 ((((size_t)tb * d.Hout + ty0 + prow) * d.Wout + tx0 + pcol) * d.Cout + tm.tn * BN + wn * 64 + 8 * hi) * 2;
             const size_t optb = (size_t)GROWS * d.Wout * d.Cout * 2;   // bytes between the wave's pixel groups
             float V[16];                                     // [sum | sum of squares][ct][q]
+            const bool o16 = L.out_f16 != 0;                  // (wave-uniform; MODE 1 = Downsample never stores f16)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
               float bv[4][4];
@@ -263,8 +274,13 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
                     V[8 + ct * 4 + q] = fmaf(v[r], v[r], V[8 + ct * 4 + q]);
                     acc[ct][pt][4 * q + r] = 0.0f;
                   }
-                  pk[2 * q] = w2_pack(v[0], v[1]);
-                  pk[2 * q + 1] = w2_pack(v[2], v[3]);
+                  if (!MODE && o16) {
+                    pk[2 * q] = h16_pack(v[0], v[1]);
+                    pk[2 * q + 1] = h16_pack(v[2], v[3]);
+                  } else {
+                    pk[2 * q] = w2_pack(v[0], v[1]);
+                    pk[2 * q + 1] = w2_pack(v[2], v[3]);
+                  }
                 }
                 // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: swapping the upper
                 // half of chunk 2m with the lower half of chunk 2m+1 leaves lane half 0 with all 8 channels of chunk 2m and
@@ -349,7 +365,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
       hedge[k] = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) |
                  (hp >= G::HALO ? 16u : 0u) | (hy == 1 ? 32u : 0u) | (hx == 1 ? 64u : 0u);
     }
-    const bf16_t* const wbase = MODE ? L.w_s2d : L.w;
+    const bf16_t* const wbase = MODE ? L.w_s2d : PRO == 3 ? reinterpret_cast<const bf16_t*>(L.w_f16) : L.w;
     const int wkch = MODE ? L.s2d_kchunks : d.kchunks;
     // this thread's first unit of a weight tile inside a tap's [2][CoutPad][32] slab; rows row + 32 j are 2048 bytes apart
     const unsigned w_voff = (unsigned)((((slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8) * 2);
@@ -385,9 +401,10 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     const float* ld_cb = nullptr;
     // pro_fold (common.h, GnFold): ld_ca / ld_cb point at P / Q and the coefficients are folded here from the image group's
     // fixed-point statistics (ld_acc) when a halo's coefficients are adopted: A = rstd P, B = Q - mean A
-    constexpr bool pfold = PRO == 2;
+    constexpr bool pfold = PRO >= 2;
     const long long* ld_acc = nullptr;
     longlong2 nacc = make_longlong2(0, 0);
+    h16x2 ah2[4], bh2[4];                                    // PRO == 3: the adopted coefficients as packed f16 channel pairs
     auto fold_inplace = [&](float4* c) {
       if constexpr (PRO) {
         if (pfold) {
@@ -398,6 +415,16 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
             c[h2] = make_float4(rstd * c[h2].x, rstd * c[h2].y, rstd * c[h2].z, rstd * c[h2].w);
             c[2 + h2] = make_float4(fmaf(-mean, c[h2].x, c[2 + h2].x), fmaf(-mean, c[h2].y, c[2 + h2].y),
                                     fmaf(-mean, c[h2].z, c[2 + h2].z), fmaf(-mean, c[h2].w, c[2 + h2].w));
+          }
+        }
+        if constexpr (PRO == 3) {
+          typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            ah2[2 * h2] = __builtin_convertvector((f32x2){c[h2].x, c[h2].y}, h16x2);
+            ah2[2 * h2 + 1] = __builtin_convertvector((f32x2){c[h2].z, c[h2].w}, h16x2);
+            bh2[2 * h2] = __builtin_convertvector((f32x2){c[2 + h2].x, c[2 + h2].y}, h16x2);
+            bh2[2 * h2 + 1] = __builtin_convertvector((f32x2){c[2 + h2].z, c[2 + h2].w}, h16x2);
           }
         }
       }
@@ -461,7 +488,9 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     };
     auto write_unit = [&](int k, int bufoff) {
       w2_u32x4 v = hreg[k];
-      if constexpr (PRO && !(PRG_W256_EXP & 16)) {
+      if constexpr (PRO == 3 && !(PRG_W256_EXP & 16)) {
+        v = h16_silu8(v, ah2, bh2);
+      } else if constexpr (PRO && !(PRG_W256_EXP & 16)) {
         const float a8[8] = {cf[0].x, cf[0].y, cf[0].z, cf[0].w, cf[1].x, cf[1].y, cf[1].z, cf[1].w};
         const float b8[8] = {cf[2].x, cf[2].y, cf[2].z, cf[2].w, cf[3].x, cf[3].y, cf[3].z, cf[3].w};
 #pragma unroll
@@ -1045,14 +1074,20 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
                    tiles_x * tiles_y * 2 <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
   ConvLaunch<bf16_t> Lk = L;
-  if (int rc = w256_prepare_fold(Lk, s)) return rc;
-  const int pro = Lk.pro_fold.acc ? 2 : (L.pro_a ? 1 : 0);
-  const void* fns[2][3] = {{reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 1, 0>),
-                            reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 2, 0>)},
+  if (L.in_f16) {                                            // h16 input: only through the in-kernel fold, with f16 weights
+    const GnFold& f = L.pro_fold;
+    if (!(f.acc && f.P && f.Q && f.cpg % 8 == 0 && f.G * f.cpg == d.C0 && d.C1 == 0 && L.w_f16)) return 0;
+  }
+  if (L.out_f16 && (L.pro_a || L.pro_fold.acc)) return 0;   // h16 output: conv1 of a ResnetBlock (no prologue)
+  if (!L.probe)
+    if (int rc = w256_prepare_fold(Lk, s)) return rc;
+  const int pro = L.in_f16 ? 3 : Lk.pro_fold.acc ? 2 : (L.pro_a ? 1 : 0);
+  const void* fns[2][4] = {{reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 1, 0>),
+                            reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 2, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 3, 0>)},
                            {reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 1, 0>),
-                            reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 2, 0>)}};
+                            reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 2, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 3, 0>)}};
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
-  static std::atomic<bool> attr_done[2][3];   // zero-initialised; atomic: lanes launch from several host threads
+  static std::atomic<bool> attr_done[2][4];   // zero-initialised; atomic: lanes launch from several host threads
   if (!attr_done[tw == 32][pro]) {
     hipError_t e = hipFuncSetAttribute(fns[tw == 32][pro], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 conv): ") + hipGetErrorString(e));
@@ -1060,12 +1095,15 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
   if (acc_done) *acc_done = (fuse && L.gn_acc) ? 1 : 0;
+  if (L.probe) return 1;
   if (tw == 32) {
-    if (pro == 2) conv3x3_w256_kernel<32, 2, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro == 3) conv3x3_w256_kernel<32, 3, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else if (pro == 2) conv3x3_w256_kernel<32, 2, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
     else if (pro == 1) conv3x3_w256_kernel<32, 1, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
     else conv3x3_w256_kernel<32, 0, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
   } else {
-    if (pro == 2) conv3x3_w256_kernel<16, 2, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    if (pro == 3) conv3x3_w256_kernel<16, 3, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
+    else if (pro == 2) conv3x3_w256_kernel<16, 2, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
     else if (pro == 1) conv3x3_w256_kernel<16, 1, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
     else conv3x3_w256_kernel<16, 0, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
   }

@@ -763,6 +763,7 @@ __global__ __launch_bounds__(768) void conv3x3_ws_kernel(const ConvLaunch<bf16_t
           // through the wave's LDS stage, 16-byte stores; the 8 channels of chunk (ct, q) are shared by the whole wave.
           char* const stg = stage + wave * (64 * 128);
           float V[16];   // [sum | sum of squares][ct][q]
+          const bool o16 = L.out_f16 != 0;
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -779,9 +780,9 @@ __global__ __launch_bounds__(768) void conv3x3_ws_kernel(const ConvLaunch<bf16_t
                   s += v[r];
                   sq = fmaf(v[r], v[r], sq);
                 }
-                uint2 w;
-                w.x = pack_bf16(v[0], v[1]);
-                w.y = pack_bf16(v[2], v[3]);
+                uint2 w;                                   // (o16: the h16 output format of conv.h, wave-uniform)
+                w.x = o16 ? h16_pack(v[0], v[1]) : pack_bf16(v[0], v[1]);
+                w.y = o16 ? h16_pack(v[2], v[3]) : pack_bf16(v[2], v[3]);
                 // row = pixel, 16-byte unit = ct*4 + q (XOR-swizzled), half = hi
                 const int px = pt * 32 + lpx;
                 *reinterpret_cast<uint2*>(stg + px * 128 + (((ct * 4 + q) ^ ((px >> 1) & 7)) << 4) + hi * 8) = w;
@@ -893,6 +894,7 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
     attr_done = true;
   }
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * G::WAVES_M : 0;
+  if (L.probe) return PRG_OK;
   static const int trace_at = [] { const char* e = std::getenv("PRG_WS_TRACE"); return e ? std::atoi(e) : -1; }();
   static int launch_no = 0;
   unsigned long long* tbuf = nullptr;
@@ -940,6 +942,7 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
   if (d.C0 % kCH || d.C1 % kCH || d.Cout % 64) return 0;
   if (L.residual || !L.bias) return 0;
+  if (L.in_f16 || (L.out_f16 && L.pro_a)) return 0;          // h16 (conv.h): f16 OUTPUT only, from a launch without prologue
   {
     const int tn128 = d.Cout % 128 == 0 ? d.Cout / 128 : d.Cout / 64;   // Cout tiles of the configuration chosen below
     if (tn128 != 1 && tn128 != 2 && tn128 != 4 && tn128 != 8) return 0;  // every workgroup must own ONE channel tile

@@ -99,6 +99,7 @@ struct ConvP {
   int s2d_kchunks = 0;
   int64_t sp_off = -1;     // f16x3 mode: element offset of the hi / lo f16 split packing (ConvLaunch::w_split)
   int sp_kchunks = 0;
+  int64_t h16_off = -1;    // bf16 mode, second conv of a ResnetBlock: element offset of the f16 twin of the packing (ConvLaunch::w_f16)
 };
 struct ResP {
   int cin = 0, cout = 0;
@@ -272,6 +273,7 @@ struct prg_unet {
   uint8_t* d_mx_scale = nullptr;
   uint16_t* d_attn_split = nullptr;   // f16x3 mode: fused linear attention weights as f16 hi / lo halves (attn_split.hip)
   uint16_t* d_split = nullptr;  // f16x3 mode (dtype PRG_F16X3): every conv weight as f16 hi / lo halves (conv_split.hip)
+  uint16_t* d_h16 = nullptr;    // bf16 mode: f16 twins of the ResnetBlocks' second convs (the h16 format, conv.h)
   float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
   int* d_tickets = nullptr;     // [kMaxTicketImages] per-image arrival counters of the conv kernels that fold GroupNorm coefficients (self-resetting)
   // fixed-point GroupNorm statistics (common.h, GnFold; bf16 / mxfp8 handles)
@@ -327,6 +329,8 @@ struct UnetImpl : prg_unet {
     int* acc_done = nullptr;        // out: 1 = the launch accumulated into gn_acc
     const GnFold* fold = nullptr;   // prologue coefficients folded by the consumer (pro_a / pro_b = scratch tables)
     const GnFold* res_fold = nullptr;   // activated residual folded in the 1x1 conv's epilogue (instead of res_a / res_b)
+    bool out_f16 = false;           // h16 (conv.h): the output is stored as f16 / the input is f16 and the conv takes its f16 weights
+    bool in_f16 = false;
   };
 
   ConvDesc make_desc(const ConvP& p, int C0, int C1, int B, int Hin, int Win, int stride, int pad, int ups) const {
@@ -340,8 +344,8 @@ struct UnetImpl : prg_unet {
     return d;
   }
 
-  int conv(const ConvP& p, const T* s0, int C0, const T* s1, int C1, int B, int Hin, int Win, int stride, int pad,
-           int ups, const ConvOpt& o, T* out, hipStream_t s) {
+  ConvLaunch<T> make_launch(const ConvP& p, const T* s0, int C0, const T* s1, int C1, int B, int Hin, int Win, int stride, int pad,
+                            int ups, const ConvOpt& o, T* out) const {
     ConvLaunch<T> L;
     L.d = make_desc(p, C0, C1, B, Hin, Win, stride, pad, ups);
     L.src0 = s0; L.src1 = s1; L.w = W(p); L.bias = F(p.b_off); L.residual = o.residual; L.out = out;
@@ -360,6 +364,15 @@ struct UnetImpl : prg_unet {
     L.gn_acc = o.gn_acc;
     L.pro_fold = o.fold ? *o.fold : GnFold{};
     L.res_fold = o.res_fold ? *o.res_fold : GnFold{};
+    L.out_f16 = o.out_f16 ? 1 : 0;
+    L.in_f16 = o.in_f16 ? 1 : 0;
+    L.w_f16 = (d_h16 && p.h16_off >= 0) ? d_h16 + p.h16_off : nullptr;
+    return L;
+  }
+
+  int conv(const ConvP& p, const T* s0, int C0, const T* s1, int C1, int B, int Hin, int Win, int stride, int pad,
+           int ups, const ConvOpt& o, T* out, hipStream_t s) {
+    const ConvLaunch<T> L = make_launch(p, s0, C0, s1, C1, B, Hin, Win, stride, pad, ups, o, out);
     PRG_CHECK(C0 + C1 == p.Cin, "conv: channel mismatch");
     if (o.gn_nsplit) *o.gn_nsplit = 0;
     if (o.coef_done) *o.coef_done = 0;
@@ -449,8 +462,6 @@ struct UnetImpl : prg_unet {
     o1.gn_partials = part1; o1.gn_nsplit = &ns1;
     o1.gn = &g1; o1.coef_a = coefA; o1.coef_b = coefB; o1.coef_done = &cd1;
     o1.gn_acc = acc1; o1.acc_done = &ad1;
-    if ((rc = conv(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, o1, h1, s))) return rc;
-    if (!arena.dry && ns1 == 0 && (rc = launch_gn_stats<T>(h1, part1, B, HW, r.cout, G, &ns1, s))) return rc;
     // conv2's own statistics fold into a second coefficient pair (coefA / coefB are still being read by its prologue)
     ConvOpt o2;
     o2.gn_partials = part2; o2.gn_nsplit = &ns2;
@@ -464,6 +475,23 @@ struct UnetImpl : prg_unet {
     const bool fuse_pro = conv_supports_prologue<T>(make_desc(r.c2, r.cout, 0, B, H, Wd, 1, 1, 0)) &&
                           (fuse_min < 0 || (fuse_min > 0 && r.cout >= fuse_min)) && r.cout <= fuse_max;
     GnFold f1{}, f2{};
+    // h16 (conv.h): h1 only ever feeds conv2's fused prologue — stored as f16 when both launches land on kernels that implement it
+    // (probed with the launches' own descriptors: PRG_H16=0, PRG_CONV_C64=0, ... and uncovered shapes fall back to bf16 h1)
+    bool h16 = false;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (!arena.dry && acc1 && fuse_pro && d_h16 && r.c2.h16_off >= 0) {
+        const GnFold fp = make_fold(acc1, r.cout, HW, c1 && c1->ss_a, r.ss_off, r.pq1);
+        ConvOpt p2 = o2;
+        p2.fold = &fp; p2.pro_a = coefA; p2.pro_b = coefB;
+        h16 = conv_h16_pair_ok(make_launch(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, o1, h1),
+                               make_launch(r.c2, h1, r.cout, nullptr, 0, B, H, Wd, 1, 1, 0, p2, out));
+      }
+    }
+    o1.out_f16 = h16;
+    o2.in_f16 = h16;
+    if ((rc = conv(r.c1, s0, C0, s1, C1, B, H, Wd, 1, 1, 0, o1, h1, s))) return rc;
+    if (!arena.dry && ns1 == 0 && (rc = launch_gn_stats<T>(h1, part1, B, HW, r.cout, G, &ns1, s))) return rc;
+    PRG_CHECK(!h16 || ad1, "resblock: the h16 probe promised fixed-point statistics");
     if (!arena.dry) {
       if (ad1) {
         f1 = make_fold(acc1, r.cout, HW, c1 && c1->ss_a, r.ss_off, r.pq1);
@@ -918,6 +946,31 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       PRG_HIP(hipMemcpy(u->d_mx_scale, scales.data(), scales.size(), hipMemcpyHostToDevice));
     }
   }
+  if (std::is_same<T, bf16_t>::value && !mx) {
+    // h16 (conv.h): f16 twins of the ResnetBlocks' second convs (3 x 3, Cin = Cout, 64-channel multiples), standardised like the
+    // bf16 packing; conv2 takes them when the block's h1 tensor is stored as f16
+    Layout& Lm = u->lay;
+    std::vector<ResP*> rs;
+    for (auto& lv : Lm.downs) { rs.push_back(&lv.r0); rs.push_back(&lv.r1); }
+    for (auto& lv : Lm.ups) { rs.push_back(&lv.r0); rs.push_back(&lv.r1); }
+    rs.push_back(&Lm.mid1); rs.push_back(&Lm.mid2); rs.push_back(&Lm.fin);
+    std::vector<uint16_t> data, one;
+    std::vector<float> tmp;
+    for (ResP* r : rs) {
+      ConvP* p = &r->c2;
+      if (!(p->KH == 3 && p->KW == 3 && p->Cin == p->Cout && p->Cin % 64 == 0)) continue;
+      const float* w = weights + p->w_flat;
+      if (p->ws) { standardize(w, p->Cout, p->Cin * 9, tmp); w = tmp.data(); }
+      pack_conv_weight_f16(w, p->Cout, p->Cin, 3, 3, one);
+      p->h16_off = (int64_t)((data.size() + 127) / 128 * 128);
+      data.resize((size_t)p->h16_off + one.size());
+      std::memcpy(data.data() + p->h16_off, one.data(), one.size() * sizeof(uint16_t));
+    }
+    if (!data.empty()) {
+      if (hipMalloc(&u->d_h16, data.size() * sizeof(uint16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(h16 weights)");
+      PRG_HIP(hipMemcpy(u->d_h16, data.data(), data.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+  }
   if (split) {
     // f16x3 mode: hi / lo f16 halves of every conv weight (standardised first where the Block does), conv_split.hip
     std::vector<ConvP*> convs;
@@ -1242,6 +1295,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_mx) (void)hipFree(h->d_mx);
   if (h->d_mx_scale) (void)hipFree(h->d_mx_scale);
   if (h->d_split) (void)hipFree(h->d_split);
+  if (h->d_h16) (void)hipFree(h->d_h16);
   if (h->d_attn_split) (void)hipFree(h->d_attn_split);
   if (h->d_tickets) (void)hipFree(h->d_tickets);
   if (h->d_gnacc) (void)hipFree(h->d_gnacc);

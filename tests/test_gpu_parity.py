@@ -301,7 +301,10 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                 # sum_n p of la_ctx on the matrix pipe at every width / as float additions at every width
                 "la_psum": {"PRG_LA_PSUM": "1"}, "la_ssum": {"PRG_LA_PSUM": "0"},
                 # ... and the accumulators with every eligible shape on the 256-pixel kernel (its in-kernel fold at every width)
-                "gn_acc_w256_all": {"PRG_W256_MIN_TILES": "1", "PRG_GN_ACC": "1"}}
+                "gn_acc_w256_all": {"PRG_W256_MIN_TILES": "1", "PRG_GN_ACC": "1"},
+                # round 4: h1 (the tensor between a ResnetBlock's two convs) as bf16 with the float32 prologue instead of f16 with
+                # the packed-f16 prologue and f16 MFMA operands in conv2 (conv.h, "h16")
+                "no_h16": {"PRG_H16": "0"}}
     for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
@@ -310,7 +313,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
     for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256", "no_res_epilogue", "no_head_fuse",
-                 "no_gn_acc", "gn_acc_w256_all", "la_psum", "la_ssum"):
+                 "no_gn_acc", "gn_acc_w256_all", "la_psum", "la_ssum", "no_h16"):
         for k in ("y64", "y128", "y40", "y96"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()

@@ -1,0 +1,17 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+PRG_H16=7 bash tools/prof.sh h16_on --streams 1 --no-parity-mode > $O/h16_on_summary.txt 2>&1
+cd $GRAFT_REPO_ROOT
+PRG_H16=0 bash tools/prof.sh h16_off --streams 1 --no-parity-mode > $O/h16_off_summary.txt 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/prof_seq.py $O/h16_on/r_kernel_trace.csv $O/h16_off/r_kernel_trace.csv conv > $O/h16_ab_seq.txt 2>&1
+grep -E "c64|sum" $O/h16_ab_seq.txt
+rm -rf $O/h16_on $O/h16_off
+BA="--steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e-files --no-drift --no-configs4 --no-parity-mode"
+rm -f $O/h16_ab.txt
+for i in 1 2; do
+  PRG_H16=7 python bench.py $BA 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.readlines()[-1]); print('h16=7', round(r['value'],3))" | tee -a $O/h16_ab.txt
+  PRG_H16=0 python bench.py $BA 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.readlines()[-1]); print('h16=0', round(r['value'],3))" | tee -a $O/h16_ab.txt
+done
+python -m pytest tests -m gpu -q -x > $O/h16_fulltests.log 2>&1; echo "pytest rc=$?" >> $O/h16_fulltests.log; tail -4 $O/h16_fulltests.log

@@ -38,6 +38,24 @@ __global__ __launch_bounds__(256) void k(float* out, long long* clk, int iters) 
     } else if (KIND == 7) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+    } else if (KIND == 8) {       // round 4 (h16): the f16 conversions and packed / transcendental f16 instructions
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+    } else if (KIND == 9) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+    } else if (KIND == 10) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(bx), "v"(bx));
+    } else if (KIND == 11) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_exp_f16 %0, %0" : "+v"(a[i]));
+    } else if (KIND == 12) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f16_sdwa %0, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a[i]));
+    } else if (KIND == 13) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(a[i]));
     }
   }
   long long t1 = clock64();
@@ -67,5 +85,11 @@ int main() {
   run<7>("v_rcp_f32", 16, out, clk);
   run<4>("v_cvt_pk_bf16_f32", 16, out, clk);
   run<5>("v_add_f32 dpp quad", 16, out, clk);
+  run<8>("v_cvt_pk_f16_f32", 16, out, clk);
+  run<9>("v_cvt_pkrtz_f16_f32", 16, out, clk);
+  run<13>("v_cvt_f16_f32", 16, out, clk);
+  run<10>("v_pk_fma_f16", 16, out, clk);
+  run<11>("v_exp_f16", 16, out, clk);
+  run<12>("v_rcp_f16 sdwa hi", 16, out, clk);
   return 0;
 }
