@@ -959,7 +959,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
   }
 
   float4 ra[AP][2];
-  uint4 rb[NB];
+  typedef __attribute__((ext_vector_type(4))) unsigned int rb_t;   // (a native vector: hipcc kept an array of the uint4 STRUCT in scratch — every weight load waited on, stored, reloaded)
+  rb_t rb[NB];
   const int niter = d.KH * d.KW * L.split_kchunks;
   auto gload = [&](int tap, int kc) {
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
     }
     const uint4* wt = reinterpret_cast<const uint4*>(L.w_split + ((size_t)(tap * L.split_kchunks + kc) * d.CoutPad + (size_t)tn * BN) * 64);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = wt[tid + j * 256];
+    for (int j = 0; j < NB; ++j) rb[j] = reinterpret_cast<const rb_t*>(wt)[tid + j * 256];
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int u = tid + j * 256, n = u >> 3, slot = u & 7;
-      Bb[n * 8 + (slot ^ ((n >> 1) & 7))] = rb[j];
+      *reinterpret_cast<rb_t*>(Bb + n * 8 + (slot ^ ((n >> 1) & 7))) = rb[j];
     }
     __syncthreads();
     if (++kc == L.split_kchunks) { kc = 0; ++tap; }
