@@ -29,7 +29,9 @@ MASK_GFLOP = {64: 14.787, 128: 59.173, 256: 237.096}
 # FLOP (hi*hi + hi*lo + lo*hi), so algorithmic TFLOP/s are priced against 2500 / 3
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mxfp8": 5000.0, "f16x3": 2500.0 / 3.0}
 CONV_CLASS = ("MFMA convolutions: conv3x3_w256_kernel (256-pixel x 128-channel tiles, also Downsample) + conv3x3_c64_kernel "
-              "(64 -> 64, weights-stationary) + conv3x3_ws_kernel (128-pixel wave-specialised tiles) + conv_igemm_kernel (1x1)")
+              "(64 -> 64, weights-stationary) + conv3x3_ws_kernel (128-pixel wave-specialised tiles) + conv_igemm_kernel (1x1); "
+              "the second conv of every ResnetBlock reads an f16 tensor through a packed-f16 GroupNorm+SiLU prologue and contracts "
+              "f16 operands (v_mfma_f32_32x32x16_f16, the bf16 instruction's rate; 'h16', DESIGN 4.7)")
 
 
 def conv_sources_hash():

@@ -554,16 +554,28 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel
     }
   }
 
-  Vec16<T> ra[AP], rb[BP];
+  // TWO register stages (round 4): the loads of iteration it + 2 are issued while iteration it computes, so a load has two
+  // iterations (two barriers, 16 MFMAs per wave) to land instead of one — with one stage the 8 MFMAs of an iteration covered
+  // a fraction of the L2 / HBM latency and the 1x1 convs ran at 0.3-0.4 PFLOP/s
+  // (native 16-byte vectors: arrays of the Vec16 / uint4 STRUCTS are split into 16-bit pieces or kept in scratch by hipcc 7.2)
+  typedef __attribute__((ext_vector_type(4))) unsigned int stg_t;
+  auto ldg = [](const T* p) { return *reinterpret_cast<const stg_t*>(p); };
+  stg_t ra0[AP], rb0[BP], ra1[AP], rb1[BP];
+  unsigned ok0 = 0, ok1 = 0;                               // bit i: unit i of the stage is inside the tensor
   const int niter = d.KH * d.KW * d.kchunks;
-  auto gload = [&](int tap, int kc) {
+  auto gload = [&](stg_t(&ra)[AP], stg_t(&rb)[BP], unsigned& okm, int tap, int kc) {
+    okm = 0;
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int c = kc * BK + ku * VEC;
     if constexpr (ONE) {
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        if (a_ok[i] && c < Cin) ra[i] = vec_load((c < d.C0 ? a_p0[i] : a_p1[i]) + kc * BK);
-        else ra[i] = vec_zero<T>();
+        // branch-free (an always-mapped stand-in address; the unit is zeroed by its mask when it is staged): with loads under a
+        // branch hipcc's s_waitcnt placement falls back to vmcnt(0) and the second register stage would buy nothing
+        const bool ok = a_ok[i] && c < Cin;
+        const T* p = (c < d.C0 ? a_p0[i] : a_p1[i]) + kc * BK;
+        ra[i] = ldg(ok ? p : L.src0);
+        okm |= (ok ? 1u : 0u) << i;
       }
     } else
 #pragma unroll
@@ -571,17 +583,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel
       int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
       const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl && c < Cin;
       if (d.ups) { iy >>= 1; ix >>= 1; }
-      if (ok) {
-        const int64_t pix = a_base[i] + (int64_t)iy * d.Win + ix;
-        const T* p = (c < d.C0) ? L.src0 + pix * d.C0 + c : L.src1 + pix * d.C1 + (c - d.C0);
-        ra[i] = vec_load(p);
-      } else {
-        ra[i] = vec_zero<T>();
-      }
+      const int64_t pix = ok ? a_base[i] + (int64_t)iy * d.Win + ix : 0;
+      const T* p = (c < d.C0) ? L.src0 + pix * d.C0 + c : L.src1 + pix * d.C1 + (c - d.C0);
+      ra[i] = ldg(ok ? p : L.src0);                        // (branch-free, as above)
+      okm |= (ok ? 1u : 0u) << i;
     }
     const T* wt = L.w + ((size_t)(tap * d.kchunks + kc) * d.CoutPad + (size_t)tn * BN) * BK;
 #pragma unroll
-    for (int j = 0; j < BP; ++j) rb[j] = vec_load(wt + (size_t)(j * 256 + tid) * VEC);
+    for (int j = 0; j < BP; ++j) rb[j] = ldg(wt + (size_t)(j * 256 + tid) * VEC);
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -597,18 +606,36 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   Wide<T, TM> wacc;
-  int tap = 0, kc = 0;
-  gload(0, 0);
-  for (int it = 0; it < niter; ++it) {
+  // coordinates of the NEXT load to issue; past the end they stay on the last chunk (harmless reloads that nobody stages): the
+  // loop body then has no branch between a load and its use and the compiler's s_waitcnt vmcnt(N) counts are exact — with the
+  // re-issue under `if (it + 2 < niter)` it waited for vmcnt(0) at every staging write
+  int tap = 0, kc = 0, nxt = 0;
+  auto advance = [&]() {
+    const bool more = nxt + 1 < niter;
+    nxt += more ? 1 : 0;
+    const int k2 = kc + 1, wrap = k2 == d.kchunks;
+    kc = more ? (wrap ? 0 : k2) : kc;
+    tap = more ? tap + wrap : tap;
+  };
+  gload(ra0, rb0, ok0, tap, kc);
+  advance();
+  gload(ra1, rb1, ok1, tap, kc);
+  advance();
+  // one iteration: stage `it` (registers loaded two iterations ago) -> LDS buffer it & 1, barrier, re-issue the registers for
+  // iteration it + 2, then the MFMAs
+  auto step = [&](stg_t(&ra)[AP], stg_t(&rb)[BP], unsigned& okm, int it) {
     uint4* Ab = As + (it & 1) * BM * PITCH;
     uint4* Bb = Bs + (it & 1) * BN * PITCH;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) Ab[(lrow + i * RPP) * PITCH + ku] = *reinterpret_cast<const uint4*>(&ra[i]);
+    for (int i = 0; i < AP; ++i) {
+      const unsigned m = 0u - ((okm >> i) & 1u);           // all ones / zero: padding, rows past M, channels past Cin
+      *reinterpret_cast<stg_t*>(Ab + (lrow + i * RPP) * PITCH + ku) = ra[i] & m;
+    }
 #pragma unroll
-    for (int j = 0; j < BP; ++j) Bb[(lrow + j * RPP) * PITCH + ku] = *reinterpret_cast<const uint4*>(&rb[j]);
+    for (int j = 0; j < BP; ++j) *reinterpret_cast<stg_t*>(Bb + (lrow + j * RPP) * PITCH + ku) = rb[j];
     __syncthreads();
-    if (++kc == d.kchunks) { kc = 0; ++tap; }
-    if (it + 1 < niter) gload(tap, kc);
+    gload(ra, rb, okm, tap, kc);
+    advance();
     if constexpr (Wide<T>::on) clear_acc<TM>(acc);   // parity mode: 16-term partials summed in float64
 #pragma unroll
     for (int call = 0; call < CALLS; ++call) {
@@ -624,7 +651,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_igemm_kernel
         for (int j = 0; j < 2; ++j) Mma<T>::mma(fa[i], fb[j], acc[i][j], hi);
     }
     wacc.add(acc);
+  };
+  for (int it = 0; it + 1 < niter; it += 2) {
+    step(ra0, rb0, ok0, it);
+    step(ra1, rb1, ok1, it + 1);
   }
+  if (niter & 1) step(ra0, rb0, ok0, niter - 1);
   wacc.finish(acc);
 
   if (wide) {
@@ -754,6 +786,10 @@ int materialize_prologue(ConvLaunch<bf16_t>& L, hipStream_t s) {
 }
 static int materialize_prologue(ConvLaunch<float>&, hipStream_t) { return PRG_OK; }
 
+static int mx_pure_env() {
+  static const int pure = [] { const char* e = std::getenv("PRG_MX_PURE"); return e ? std::atoi(e) : 0; }();
+  return pure;
+}
 static int try_mx(ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done) {
   if (!L.w_mx || !L.w_mx_scale) return 0;
   {
@@ -763,8 +799,7 @@ static int try_mx(ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int*
   // Shapes the 256-pixel MX kernel does not cover (the 64-channel convs, launches with few tiles): by default the bf16
   // kernels run them (those shapes are HBM- / VALU-bound: fp8 operands buy nothing there); PRG_MX_PURE=1 keeps every 3x3
   // conv on MX operands through the simple halo-tile kernel below.
-  static const int pure = [] { const char* e = std::getenv("PRG_MX_PURE"); return e ? std::atoi(e) : 0; }();
-  if (!pure && !L.mx_pure) return 0;
+  if (!mx_pure_env() && !L.mx_pure) return 0;
   const ConvDesc& d = L.d;
   HaloPick<bf16_t> hp;
   if (!pick_halo<bf16_t>(d, &hp) || L.residual) return 0;
@@ -811,7 +846,10 @@ bool conv_h16_pair_ok(const ConvLaunch<bf16_t>& L1in, const ConvLaunch<bf16_t>& 
   static const int mask = [] { const char* e = std::getenv("PRG_H16"); return e ? std::atoi(e) : 7; }();
   if (!mask) return false;
   ConvLaunch<bf16_t> L1 = L1in, L2 = L2in;
-  if (L1.w_mx || L2.w_mx || !L2.w_f16 || !L1.gn_acc || !L2.pro_fold.acc) return false;
+  // mxfp8 handles: a conv whose MX copy would run (the 256-pixel MX kernel takes Cout % 128 == 0; PRG_MX_PURE / mx_pure take every
+  // 3x3 conv) never carries the f16 format — the 64-channel pairs, which the bf16 kernels run in that mode too, do
+  auto mx_takes = [](const ConvLaunch<bf16_t>& L) { return L.w_mx && (L.d.Cout % 128 == 0 || mx_pure_env() || L.mx_pure); };
+  if (mx_takes(L1) || mx_takes(L2) || !L2.w_f16 || !L1.gn_acc || !L2.pro_fold.acc) return false;
   L1.probe = L2.probe = 1;
   L1.out_f16 = 1;
   L2.in_f16 = 1;

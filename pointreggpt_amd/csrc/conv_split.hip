@@ -958,38 +958,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
     }
   }
 
-  float4 ra[AP][2];
-  typedef __attribute__((ext_vector_type(4))) unsigned int rb_t;   // (a native vector: hipcc kept an array of the uint4 STRUCT in scratch — every weight load waited on, stored, reloaded)
-  rb_t rb[NB];
+  // Two register stages, branch-free loads, clamped re-issue past the end (conv.hip's conv_igemm_kernel, round 4): the loads of
+  // iteration it + 2 are in flight while iteration it computes, and hipcc's s_waitcnt vmcnt(N) counts stay exact.
+  typedef __attribute__((ext_vector_type(4))) unsigned int rb_t;   // (native vectors: hipcc kept an array of the uint4 STRUCT in scratch — every weight load waited on, stored, reloaded)
+  typedef __attribute__((ext_vector_type(4))) float ra_t;
+  ra_t ra0[AP][2], ra1[AP][2];
+  rb_t rb0[NB], rb1[NB];
+  unsigned ok0 = 0, ok1 = 0;
   const int niter = d.KH * d.KW * L.split_kchunks;
-  auto gload = [&](int tap, int kc) {
+  auto gload = [&](ra_t(&ra)[AP][2], rb_t(&rb)[NB], unsigned& okm, int tap, int kc) {
+    okm = 0;
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int c = kc * BK + q * 8;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const float* p = nullptr;
+      const float* p = L.src0;
+      bool ok;
       if constexpr (ONE) {
-        if (a_ok[i] && c < Cin) p = (c < d.C0 ? a_p0[i] : a_p1[i]) + kc * BK;
+        ok = a_ok[i] && c < Cin;
+        if (ok) p = (c < d.C0 ? a_p0[i] : a_p1[i]) + kc * BK;
       } else {
         int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl && c < Cin;
+        ok = a_ok[i] && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl && c < Cin;
         if (d.ups) { iy >>= 1; ix >>= 1; }
-        if (ok) {
-          const int64_t pix = (int64_t)a_base[i] + (int64_t)iy * d.Win + ix;
-          p = (c < d.C0) ? L.src0 + pix * d.C0 + c : L.src1 + pix * d.C1 + (c - d.C0);
-        }
+        const int64_t pix = ok ? (int64_t)a_base[i] + (int64_t)iy * d.Win + ix : 0;
+        const float* pp = (c < d.C0) ? L.src0 + pix * d.C0 + c : L.src1 + pix * d.C1 + (c - d.C0);
+        if (ok) p = pp;
       }
-      if (p) {
-        ra[i][0] = reinterpret_cast<const float4*>(p)[0];
-        ra[i][1] = reinterpret_cast<const float4*>(p)[1];
-      } else {
-        ra[i][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ra[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      ra[i][0] = reinterpret_cast<const ra_t*>(p)[0];
+      ra[i][1] = reinterpret_cast<const ra_t*>(p)[1];
+      okm |= (ok ? 1u : 0u) << i;
     }
-    const uint4* wt = reinterpret_cast<const uint4*>(L.w_split + ((size_t)(tap * L.split_kchunks + kc) * d.CoutPad + (size_t)tn * BN) * 64);
+    const rb_t* wt = reinterpret_cast<const rb_t*>(L.w_split + ((size_t)(tap * L.split_kchunks + kc) * d.CoutPad + (size_t)tn * BN) * 64);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = reinterpret_cast<const rb_t*>(wt)[tid + j * 256];
+    for (int j = 0; j < NB; ++j) rb[j] = wt[tid + j * 256];
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -1004,15 +1006,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }
 
-  int tap = 0, kc = 0;
-  gload(0, 0);
-  for (int it = 0; it < niter; ++it) {
+  int tap = 0, kc = 0, nxt = 0;                              // coordinates of the NEXT load to issue (clamped to the last chunk)
+  auto advance = [&]() {
+    const bool more = nxt + 1 < niter;
+    nxt += more ? 1 : 0;
+    const int k2 = kc + 1, wrap = k2 == L.split_kchunks;
+    kc = more ? (wrap ? 0 : k2) : kc;
+    tap = more ? tap + wrap : tap;
+  };
+  gload(ra0, rb0, ok0, tap, kc);
+  advance();
+  gload(ra1, rb1, ok1, tap, kc);
+  advance();
+  auto step = [&](ra_t(&ra)[AP][2], rb_t(&rb)[NB], unsigned& okm, int it) {
     uint4* Ab = As + (it & 1) * BM * 8;
     uint4* Bb = Bs + (it & 1) * BN * 8;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int r = lrow + i * 64, sw = (r >> 1) & 7;
-      const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+      const float z = ((okm >> i) & 1u) ? 1.0f : 0.0f;      // padding, rows past M, channels past Cin (the stand-in load is finite)
+      const float v[8] = {ra[i][0][0] * z, ra[i][0][1] * z, ra[i][0][2] * z, ra[i][0][3] * z,
+                          ra[i][1][0] * z, ra[i][1][1] * z, ra[i][1][2] * z, ra[i][1][3] * z};
       uint4 vh, vl;
       split8(v, vh, vl);
       Ab[r * 8 + (q ^ sw)] = vh;
@@ -1024,8 +1038,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
       *reinterpret_cast<rb_t*>(Bb + n * 8 + (slot ^ ((n >> 1) & 7))) = rb[j];
     }
     __syncthreads();
-    if (++kc == L.split_kchunks) { kc = 0; ++tap; }
-    if (it + 1 < niter) gload(tap, kc);
+    gload(ra, rb, okm, tap, kc);
+    advance();
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const int unit = 2 * st + hi;
@@ -1045,7 +1059,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
       mma3_tiles<TM>(ah, al, wh, wl, acc);
     }
     if ((it & 7) == 7 || it + 1 == niter) flush_acc<TM>(acc, tot);   // 256-term partials
+  };
+  for (int it = 0; it + 1 < niter; it += 2) {
+    step(ra0, rb0, ok0, it);
+    step(ra1, rb1, ok1, it + 1);
   }
+  if (niter & 1) step(ra0, rb0, ok0, niter - 1);
 
   double gs, gq;
   auto row_to_m = [&](int r) -> int64_t {

@@ -946,9 +946,10 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       PRG_HIP(hipMemcpy(u->d_mx_scale, scales.data(), scales.size(), hipMemcpyHostToDevice));
     }
   }
-  if (std::is_same<T, bf16_t>::value && !mx) {
+  if (std::is_same<T, bf16_t>::value) {
     // h16 (conv.h): f16 twins of the ResnetBlocks' second convs (3 x 3, Cin = Cout, 64-channel multiples), standardised like the
-    // bf16 packing; conv2 takes them when the block's h1 tensor is stored as f16
+    // bf16 packing; conv2 takes them when the block's h1 tensor is stored as f16 (mxfp8 handles: the 64-channel pairs only —
+    // conv_h16_pair_ok — the wide convs run on their MX copies)
     Layout& Lm = u->lay;
     std::vector<ResP*> rs;
     for (auto& lv : Lm.downs) { rs.push_back(&lv.r0); rs.push_back(&lv.r1); }
