@@ -160,6 +160,14 @@ int prg_unet_get_tap(prg_unet* h, const char* name, float* out, int64_t out_capa
  * (Cout) float32 HOST or NULL, out (B,Cout,H,W) float32 DEVICE (the bf16 result widened).  Synchronises.           */
 int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                       int dtype, void* stream);
+/* Kernel unit-test hook (round 4): the two convolutions of a ResnetBlock's Block pair (sd:681-697, 731-733) in bf16 mode through
+ * the library's own dispatch:  h = conv3x3(x, w1) + b1, its GroupNorm statistics taken in the epilogue;
+ * y = conv3x3(SiLU(GroupNorm_groups(h) * gamma + beta), w2) + b2 with the norm in conv2's fused prologue.  h16 = 0: h is stored as
+ * bf16; h16 = 1: as f16, prologue in packed f16, f16 MFMA operands in conv2 (PRG_E_INVALID when the shape's kernels do not
+ * implement that).  x (B,Cin,H,W) float32 DEVICE; w1 (C,Cin,3,3), w2 (C,C,3,3), b1, b2, gamma, beta (C) float32 HOST, used as
+ * they are; out (B,C,H,W) float32 DEVICE.  Cin, C multiples of 64.  Synchronises.                                              */
+int prg_debug_block_pair(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2,
+                         const float* b2, float* out, int B, int Cin, int C, int H, int W, int groups, int h16, void* stream);
 /* The same for Downsample's Conv2d(Cin, Cout, 4, stride 2, pad 1) (sd:596-597) in bf16: w (Cout,Cin,4,4),
  * out (B,Cout,H/2,W/2).                                                                                             */
 int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,

@@ -1481,6 +1481,75 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
   return rc;
 }
 
+// The two convolutions of a ResnetBlock's Block pair in bf16 mode, through the library's own dispatch (prg.h).
+int prg_debug_block_pair(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2,
+                         const float* b2, float* out, int B, int Cin, int C, int H, int W, int groups, int h16, void* stream) {
+  PRG_CHECK(x && w1 && b1 && gamma && beta && w2 && b2 && out, "prg_debug_block_pair: null pointer");
+  PRG_CHECK(B > 0 && H > 0 && W > 0 && Cin % 64 == 0 && C % 64 == 0 && groups > 0 && C % groups == 0 && (C / groups) % 8 == 0,
+            "prg_debug_block_pair: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t M = (size_t)B * H * W;
+  std::vector<bf16_t> p1, p2;
+  std::vector<uint16_t> p2h;
+  int cp1 = 0, kc1 = 0, cp2 = 0, kc2 = 0;
+  pack_conv_weight<bf16_t>(w1, C, Cin, 3, 3, p1, &cp1, &kc1);
+  pack_conv_weight<bf16_t>(w2, C, C, 3, 3, p2, &cp2, &kc2);
+  pack_conv_weight_f16(w2, C, C, 3, 3, p2h);
+  std::vector<float> pq(2 * (size_t)C);
+  for (int c = 0; c < C; ++c) { pq[c] = gamma[c]; pq[C + c] = beta[c]; }
+  void *d_x = nullptr, *d_h = nullptr, *d_y = nullptr, *d_w1 = nullptr, *d_w2 = nullptr, *d_w2h = nullptr, *d_b1 = nullptr, *d_b2 = nullptr,
+       *d_pq = nullptr, *d_acc = nullptr, *d_part = nullptr, *d_coef = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_x, d_h, d_y, d_w1, d_w2, d_w2h, d_b1, d_b2, d_pq, d_acc, d_part, d_coef}) if (p) (void)hipFree(p); };
+  const size_t acc_bytes = (size_t)B * groups * 2 * sizeof(long long);
+  if (hipMalloc(&d_x, M * Cin * 2) != hipSuccess || hipMalloc(&d_h, M * C * 2) != hipSuccess || hipMalloc(&d_y, M * C * 2) != hipSuccess ||
+      hipMalloc(&d_w1, p1.size() * 2) != hipSuccess || hipMalloc(&d_w2, p2.size() * 2) != hipSuccess || hipMalloc(&d_w2h, p2h.size() * 2) != hipSuccess ||
+      hipMalloc(&d_b1, C * 4) != hipSuccess || hipMalloc(&d_b2, C * 4) != hipSuccess || hipMalloc(&d_pq, pq.size() * 4) != hipSuccess ||
+      hipMalloc(&d_acc, acc_bytes) != hipSuccess || hipMalloc(&d_part, (size_t)B * kGnMaxSplit * groups * 2 * 4) != hipSuccess ||
+      hipMalloc(&d_coef, (size_t)2 * B * C * 4) != hipSuccess) {
+    cleanup();
+    return fail(PRG_E_NOMEM, "prg_debug_block_pair: hipMalloc failed");
+  }
+  if (hipMemcpy(d_w1, p1.data(), p1.size() * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_w2, p2.data(), p2.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_w2h, p2h.data(), p2h.size() * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_b1, b1, C * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_b2, b2, C * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_pq, pq.data(), pq.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemsetAsync(d_acc, 0, acc_bytes, s) != hipSuccess) {
+    cleanup();
+    return fail(PRG_E_HIP, "prg_debug_block_pair: upload failed");
+  }
+  int rc = launch_nchw_f32_to_nhwc<bf16_t>(x, reinterpret_cast<bf16_t*>(d_x), B, H * W, Cin, s);
+  ConvLaunch<bf16_t> L1{}, L2{};
+  auto desc = [&](ConvLaunch<bf16_t>& L, int cin, int cp, int kc) {
+    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = cin; L.d.C1 = 0; L.d.ups = 0; L.d.KH = 3; L.d.KW = 3; L.d.stride = 1; L.d.pad = 1;
+    L.d.Hout = H; L.d.Wout = W; L.d.Cout = C; L.d.CoutPad = cp; L.d.kchunks = kc;
+    L.gn_groups = groups;
+  };
+  desc(L1, Cin, cp1, kc1);
+  L1.src0 = reinterpret_cast<const bf16_t*>(d_x); L1.w = reinterpret_cast<const bf16_t*>(d_w1); L1.bias = reinterpret_cast<const float*>(d_b1);
+  L1.out = reinterpret_cast<bf16_t*>(d_h);
+  L1.gn_partials = reinterpret_cast<float*>(d_part); L1.gn_acc = reinterpret_cast<long long*>(d_acc);
+  desc(L2, C, cp2, kc2);
+  L2.src0 = reinterpret_cast<const bf16_t*>(d_h); L2.w = reinterpret_cast<const bf16_t*>(d_w2); L2.w_f16 = reinterpret_cast<const uint16_t*>(d_w2h);
+  L2.bias = reinterpret_cast<const float*>(d_b2); L2.out = reinterpret_cast<bf16_t*>(d_y);
+  GnFold f{};
+  f.acc = reinterpret_cast<const long long*>(d_acc); f.P = reinterpret_cast<const float*>(d_pq); f.Q = f.P + C; f.pq_stride = 0;
+  f.G = groups; f.cpg = C / groups; f.inv_n = 1.0f / ((float)(H * W) * (float)f.cpg);
+  L2.pro_fold = f;
+  L2.pro_a = reinterpret_cast<const float*>(d_coef); L2.pro_b = L2.pro_a + (size_t)B * C;
+  if (rc == PRG_OK && h16) {
+    if (!conv_h16_pair_ok(L1, L2)) rc = fail(PRG_E_INVALID, "prg_debug_block_pair: the kernels this shape dispatches to do not implement the f16 format");
+    L1.out_f16 = 1;
+    L2.in_f16 = 1;
+  }
+  int ns = 0, cd = 0, ad = 0;
+  if (rc == PRG_OK) rc = launch_conv<bf16_t>(L1, s, &ns, &cd, &ad);
+  if (rc == PRG_OK && !ad) rc = fail(PRG_E_INVALID, "prg_debug_block_pair: conv1's kernel does not accumulate fixed-point statistics for this shape");
+  if (rc == PRG_OK) rc = launch_conv<bf16_t>(L2, s, nullptr);
+  if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<bf16_t>(reinterpret_cast<const bf16_t*>(d_y), out, B, H * W, C, s);
+  if (hipStreamSynchronize(s) != hipSuccess && rc == PRG_OK) rc = fail(PRG_E_HIP, "prg_debug_block_pair: stream synchronise failed");
+  cleanup();
+  return rc;
+}
+
 int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                       int dtype, void* stream) {
   return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, dtype, 3, 1, stream);

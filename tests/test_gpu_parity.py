@@ -907,6 +907,71 @@ def test_conv3x3_kernels_one_at_a_time(hip, B, Cin, Cout, H, Wd):
     assert bool((err <= tol).all()), float((err - tol).max())
 
 
+# (B, Cin, C, H, W): conv1 / conv2 kernels of the pair
+PAIR_SHAPES = [(4, 64, 64, 64, 64),      # c64 -> c64 (down levels 0-1)
+               (4, 128, 64, 64, 64),     # wave-specialised 8x32x64 (Cin = 128) -> c64 (up level 3, final block)
+               (64, 128, 128, 32, 32),   # 256-pixel kernel on both sides, 8x32 tiles, one channel tile (level 2)
+               (128, 256, 256, 16, 16)]  # ... 16x16 tiles, two channel tiles (256 workgroups): every input pixel transformed twice
+
+
+@pytest.mark.parametrize("B,Cin,C,H,Wd", PAIR_SHAPES)
+def test_block_pair_h16_against_float64(hip, B, Cin, C, H, Wd):
+    """Round 4, `h16`: conv1 -> [GroupNorm + SiLU in conv2's prologue] -> conv2 with the tensor in between stored as
+    f16 (packed-f16 prologue, f16 MFMA operands) and as bf16 (float32 prologue, bf16 operands), each against the float64
+    evaluation of the same chain on the same bf16-rounded inputs and conv1 weights.  The f16 form must be the MORE accurate
+    one (11-bit tensor and operands instead of 8) and stay inside a bf16-output bound."""
+    import ctypes as C_
+    lib = hip.lib.load()
+    g = torch.Generator().manual_seed(Cin * 131 + C + H)
+    x = torch.randn((B, Cin, H, Wd), generator=g) * torch.exp(0.5 * torch.randn((1, Cin, 1, 1), generator=g))
+    w1 = torch.randn((C, Cin, 3, 3), generator=g) / (3.0 * Cin ** 0.5)
+    w2 = torch.randn((C, C, 3, 3), generator=g) / (3.0 * C ** 0.5)
+    b1, b2 = torch.randn((C,), generator=g), torch.randn((C,), generator=g)
+    gamma, beta = 1.0 + 0.3 * torch.randn((C,), generator=g), 0.3 * torch.randn((C,), generator=g)
+    groups = 8
+    # float64 chain: bf16-rounded x and w1 (what both forms read); h, the norm and conv2 exact
+    h = torch.nn.functional.conv2d(x.to(torch.bfloat16).double(), w1.to(torch.bfloat16).double(), b1.double(), padding=1)
+    a = torch.nn.functional.silu(torch.nn.functional.group_norm(h, groups, gamma.double(), beta.double(), eps=1e-5))
+    ref = torch.nn.functional.conv2d(a, w2.double(), b2.double(), padding=1)
+    hp = lambda t: np.ascontiguousarray(t.numpy(), dtype=np.float32)
+    arrs = [hp(t) for t in (w1, b1, gamma, beta, w2, b2)]
+    xd = x.cuda().contiguous()
+    errs = {}
+    for h16 in (0, 1):
+        out = torch.empty((B, C, H, Wd), dtype=torch.float32, device="cuda")
+        hip.lib.check(lib.prg_debug_block_pair(hip.lib.ptr(xd), *[a_.ctypes.data_as(C_.c_void_p) for a_ in arrs], hip.lib.ptr(out),
+                                               B, Cin, C, H, Wd, groups, h16, hip.lib.stream_ptr()), "prg_debug_block_pair")
+        e = (out.cpu().double() - ref).abs()
+        assert bool(torch.isfinite(out).all())
+        errs[h16] = (float(e.max()), float(e.mean()))
+    scale = float(ref.abs().max())
+    print(f"block pair {Cin}->{C} @{H}x{Wd} B={B}: bf16 h max {errs[0][0]:.3e} mean {errs[0][1]:.3e} | f16 h max {errs[1][0]:.3e} mean {errs[1][1]:.3e} "
+          f"(|ref| max {scale:.2f})")
+    assert errs[1][1] <= errs[0][1], errs                       # the f16 form is the more accurate one on average ...
+    assert errs[1][0] <= 2.0 ** -7 * scale and errs[0][0] <= 2.0 ** -6 * scale, (errs, scale)   # ... both inside their rounding budgets
+
+
+def test_block_pair_h16_overflow_is_visible(hip):
+    """An h value beyond the f16 range (65504) must not be clipped silently: the block's output carries NaN / inf."""
+    import ctypes as C_
+    lib = hip.lib.load()
+    B, Cc, H = 4, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B, Cc, H, H), generator=g)
+    x[1, :, 10:14, 20:24] = 1.2e4                                                   # conv1 sums reach 1.4e5 there (f16 max: 65504)
+    w1 = torch.full((Cc, Cc, 3, 3), 0.02)
+    w2 = torch.randn((Cc, Cc, 3, 3), generator=g) / 24.0
+    z, one = torch.zeros(Cc), torch.ones(Cc)
+    hp = lambda t: np.ascontiguousarray(t.numpy(), dtype=np.float32)
+    arrs = [hp(t) for t in (w1, z, one, z, w2, z)]
+    out = torch.empty((B, Cc, H, H), dtype=torch.float32, device="cuda")
+    hip.lib.check(lib.prg_debug_block_pair(hip.lib.ptr(x.cuda().contiguous()), *[a_.ctypes.data_as(C_.c_void_p) for a_ in arrs], hip.lib.ptr(out),
+                                           B, Cc, Cc, H, H, 8, 1, hip.lib.stream_ptr()), "prg_debug_block_pair")
+    o = out.cpu()
+    assert not bool(torch.isfinite(o[1]).all())              # the image with the out-of-range patch
+    assert bool(torch.isfinite(o[0]).all()) and bool(torch.isfinite(o[2:]).all())   # its neighbours in the batch are untouched
+
+
 DOWN_SHAPES = [(64, 64, 64, 64, 64),     # Cout = 64: second channel half of the consumers idle; 8 x 32 tiles, 256 of them
                (32, 64, 128, 64, 64),    # 128 tiles: half the CUs
                (64, 128, 256, 32, 32),   # 16 x 16 tiles, two sub-pixel chunks per source pixel, two channel tiles
