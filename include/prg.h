@@ -168,6 +168,10 @@ int prg_debug_conv3x3(const float* x, const float* w, const float* bias, float* 
  * they are; out (B,C,H,W) float32 DEVICE.  Cin, C multiples of 64.  Synchronises.                                              */
 int prg_debug_block_pair(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2,
                          const float* b2, float* out, int B, int Cin, int C, int H, int W, int groups, int h16, void* stream);
+/* The same for Upsample = nn.Upsample(scale_factor 2, nearest) + Conv2d(Cin, Cout, 3, pad 1) (sd:592-594) in bf16:
+ * out (B,Cout,2H,2W).  Shapes the 256-pixel kernel covers run as four 2 x 2-tap sub-pixel convolutions of the source image.   */
+int prg_debug_upsample_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H,
+                               int W, void* stream);
 /* The same for Downsample's Conv2d(Cin, Cout, 4, stride 2, pad 1) (sd:596-597) in bf16: w (Cout,Cin,4,4),
  * out (B,Cout,H/2,W/2).                                                                                             */
 int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "prg_maskunet_forward": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "prg_debug_conv3x3": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "prg_debug_block_pair": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "prg_debug_upsample_conv3x3": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "prg_debug_conv4x4s2": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "prg_debug_conv": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "prg_unet_set_taps": (C.c_int, [_P, _I]),

@@ -78,6 +78,10 @@ struct ConvLaunch {
   // channel (2 dy + dx) C + c, tap (1 + by, 1 + bx) = W[.][c][2 by + dy][2 bx + dx]); null = not available.  conv_w256.hip
   const T* w_s2d;
   int s2d_kchunks;
+  // Upsample convs (nn.Upsample(x2, nearest) + Conv2d(C, Cout, 3, pad 1), d.ups = 1; bf16): the four pre-summed 2 x 2-tap packings of
+  // the sub-pixel decomposition (conv_w256.hip, MODE 2), [phase 2 dy + dx][tap 2 a + b][32-channel chunk][CoutPad][32]; null = the
+  // nine-tap gather form.  up_equivalent_weights() builds the OIHW tensors.
+  const T* w_up = nullptr;
   // f16x3 mode (handles of dtype PRG_F16X3, T = float; conv_split.hip): the weights split into f16 hi / lo halves,
   // [tap][32-channel chunk][CoutPad][32 hi | 32 lo]; null = the exact-f32 kernels
   const uint16_t* w_split;
@@ -155,6 +159,9 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
 
 // OIHW weights of the equivalent convolution described at ConvLaunch::w_s2d, from Conv2d(Cin, Cout, 4, 2, 1) weights
 void s2d_equivalent_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>& out);
+// The four [Cout][Cin][2][2] tensors (phase-major) of ConvLaunch::w_up from Conv2d(Cin, Cout, 3, 1, 1) weights: for output sub-pixel
+// dy the kernel rows {0 | 1, 2} (dy = 0) or {0, 1 | 2} (dy = 1) fall on the two source rows of its window (summed in float64)
+void up_equivalent_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>& out);
 
 // MX (OCP microscaling) fp8 packing of a conv weight: per (tap, output channel) the input channels are cut into blocks of
 // 32; block scale = 2^(floor(log2 max|w|) - 8) as an E8M0 byte (bias 127), elements = e4m3fn(w / scale), round to

@@ -821,10 +821,12 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
 int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done);  // conv_c64.hip
 int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done);   // conv_w256.hip
 int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s);                       // conv_w256.hip
+int try_launch_conv3x3_up_w256(const ConvLaunch<bf16_t>& L, hipStream_t s);                     // conv_w256.hip
 static inline int try_down(const ConvLaunch<bf16_t>& L, hipStream_t s) { return try_launch_conv4x4s2_w256(L, s); }
 static inline int try_down(const ConvLaunch<float>&, hipStream_t) { return 0; }
 static inline int try_ws(ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done, int* acc_done) {
   int r = try_launch_conv3x3_c64(L, s, n, coef_done, acc_done);   // weights-stationary kernel for the 64 -> 64 convs
+  if (r == 0 && L.d.ups && !L.gn_partials) r = try_launch_conv3x3_up_w256(L, s);   // Upsample convs as four 2 x 2-tap sub-pixel convs
   if (r == 0) r = try_launch_conv3x3_w256(L, s, n, acc_done);     // 256-pixel x 128-channel tiles where the launch fills the chip
   if (r != 0) return r;
   // the wave-specialised kernel reads coefficient tables (hand-counted loads): fold the accumulators into them first when
@@ -923,6 +925,22 @@ int launch_conv(const ConvLaunch<T>& Lin, hipStream_t s, int* gn_nsplit_out, int
   if (d.CoutPad % 128 == 0) return launch_igemm<T, 128, 128>(L, M, s, want_stats, gn_nsplit_out);
   if (M >= 256 * 64) return launch_igemm<T, 256, 64>(L, M, s, want_stats, gn_nsplit_out);
   return launch_igemm<T, 128, 64>(L, M, s, want_stats, gn_nsplit_out);
+}
+
+void up_equivalent_weights(const float* w, int Cout, int Cin, std::vector<float>& out) {
+  out.assign((size_t)4 * Cout * Cin * 4, 0.0f);
+  // tap a of phase dy collects kernel rows ky with source row offset (dy + ky - 1 floor-div 2) - (dy - 1) == a
+  auto slot = [](int dphase, int k) { const int r = dphase + k - 1; return (r >= 0 ? r / 2 : -1) - (dphase - 1); };
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx)
+      for (int o = 0; o < Cout; ++o)
+        for (int c = 0; c < Cin; ++c) {
+          double acc[2][2] = {{0, 0}, {0, 0}};
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) acc[slot(dy, ky)][slot(dx, kx)] += (double)w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx];
+          float* dst = out.data() + ((((size_t)(2 * dy + dx) * Cout + o) * Cin + c) * 4);
+          dst[0] = (float)acc[0][0]; dst[1] = (float)acc[0][1]; dst[2] = (float)acc[1][0]; dst[3] = (float)acc[1][1];
+        }
 }
 
 void s2d_equivalent_weights(const float* w, int Cout, int Cin, std::vector<float>& out) {

@@ -98,19 +98,23 @@ __device__ __forceinline__ void w2_barrier() {
 // Tile schedule of one workgroup (workgroup b runs on XCD b % 8: observed placement, speed only).  With several output
 // channel tiles every XCD is pinned to ONE of them: its CUs stream the same weight slice, which stays in the XCD's L2.
 struct W2Tiles {
-  int tiles_x, tiles_y, first, stride, count, tn;
-  __device__ __forceinline__ void init(int bid, int GR, int tx, int ty, int tiles_n, int nb) {
+  int tiles_x, tiles_y, first, stride, count, tn, psh;
+  // psh = 2 (MODE 2, the Upsample conv as four 2 x 2-tap sub-pixel convolutions): the two low bits of a tile index are the
+  // sub-pixel phase (dy, dx) — the four phases of one source tile run next to each other and share its halo in the L2
+  __device__ __forceinline__ void init(int bid, int GR, int tx, int ty, int tiles_n, int nb, int phase_bits = 0) {
     tiles_x = tx;
     tiles_y = ty;
-    const int npix = tx * ty * nb, per_xcd = GR >> 3, xcd = bid & 7, idx = bid >> 3;
+    psh = phase_bits;
+    const int npix = (tx * ty * nb) << phase_bits, per_xcd = GR >> 3, xcd = bid & 7, idx = bid >> 3;
     tn = xcd % tiles_n;
     const int gx = 8 / tiles_n, member = xcd / tiles_n;
     first = member * per_xcd + idx;
     stride = gx * per_xcd;
     count = first < npix ? (npix - first + stride - 1) / stride : 0;
   }
+  __device__ __forceinline__ int phase(int it) const { return (first + it * stride) & ((1 << psh) - 1); }
   __device__ __forceinline__ void decode(int it, int& b, int& y0, int& x0, int TH, int TW) const {
-    int t = first + it * stride;
+    int t = (first + it * stride) >> psh;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
@@ -122,12 +126,18 @@ struct W2Tiles {
 
 // phase p of a step: LDS row offset of its tap inside the halo, and the tap's index in the packed 3 x 3 weights
 template <int MODE, int HP>
-__device__ constexpr int w2_toff(int p) { return MODE ? (1 + p / 2) * HP + 1 + p % 2 : (p / 3) * HP + p % 3; }
+__device__ constexpr int w2_toff(int p) { return MODE == 1 ? (1 + p / 2) * HP + 1 + p % 2 : MODE == 2 ? (p / 2) * HP + p % 2 : (p / 3) * HP + p % 3; }
 template <int MODE>
-__device__ constexpr int w2_tapid(int p) { return MODE ? (1 + p / 2) * 3 + 1 + p % 2 : p; }
+__device__ constexpr int w2_tapid(int p) { return MODE == 1 ? (1 + p / 2) * 3 + 1 + p % 2 : p; }
 
 // PRO 0: no prologue, 1: coefficient tables, 2: coefficients folded in-kernel (pro_fold), 3: as 2 on an f16 input with f16
 // weights (the h16 format of conv.h: packed-f16 prologue, v_mfma_f32_32x32x16_f16).  L.out_f16: f16 output (run-time flag).
+// MODE 0: 3 x 3 / stride 1; 1: Downsample (4 x 4 / stride 2 as 2 x 2 taps over the space-to-depth view); 2 (round 4): Upsample —
+// nn.Upsample(x2, nearest) + Conv2d(3, pad 1) (sd:592-594) as FOUR 2 x 2-tap convolutions of the SOURCE image, one per output
+// sub-pixel (dy, dx): output row 2y + dy reads upsampled rows 2y + dy - 1 .. + 1 = source rows {y - 1, y, y} (dy = 0) or
+// {y, y, y + 1} (dy = 1), so its three kernel rows collapse onto two source rows with weights (w0, w1 + w2) / (w0 + w1, w2); the
+// same in x.  4 instead of 9 taps per output: 2.25x fewer MACs, and the zero padding of the upsampled image is exactly the zero
+// padding of the source image.  Tiles are 256 SOURCE pixels x one phase; L.w_up holds the four pre-summed 2 x 2 packings.
 template <int TW, int PRO, int MODE>
 __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y,
                                                            const int tiles_n, const int fuse_stats) {
@@ -141,10 +151,10 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
   float* const bias_lds = reinterpret_cast<float*>(smem + 2 * G::AH_BYTES + 3 * G::BW_BYTES);
   const ConvDesc& d = L.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nchunks = MODE ? 4 * d.C0 / kCH : (d.C0 + d.C1) / kCH;
+  const int nchunks = MODE == 1 ? 4 * d.C0 / kCH : (d.C0 + d.C1) / kCH;
   const int nwn = d.Cout >= BN ? 2 : 1;                     // active channel halves (Cout = 64: the second half idles)
   W2Tiles tm;
-  tm.init((int)blockIdx.x, (int)gridDim.x, tiles_x, tiles_y, tiles_n, d.B);
+  tm.init((int)blockIdx.x, (int)gridDim.x, tiles_x, tiles_y, tiles_n, d.B, MODE == 2 ? 2 : 0);
   const int nsteps = tm.count * nchunks;
   if (nsteps == 0) return;
   const int nsteps_pad = (nsteps + UNR - 1) / UNR * UNR;    // the producers' loop body covers UNR steps (clamped reloads past the end)
@@ -162,6 +172,18 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     constexpr int PTB = GROWS * HP * ROWB;                  // LDS bytes between the wave's pixel groups
     const char* xa = smem + (prow * HP + pcol) * ROWB + hi * 16;
     const char* xn = xa + AH;
+    // MODE 2: the 2 x 2 window of phase (dy, dx) starts at halo position (dy, dx): the phase's byte offset rides on xa / xn
+    // (pho_a / pho_n = the offsets they currently carry; step s + 2's tile is tracked by (chunk2, it2))
+    auto pho_of = [&](int tile) { const int ph = tm.phase(tile); return ((ph >> 1) * HP + (ph & 1)) * ROWB; };
+    int pho_a = 0, pho_n = 0, chunk2 = 0, it2 = 0;
+    if constexpr (MODE == 2) {
+      pho_a = pho_of(0);
+      pho_n = nchunks > 1 ? pho_a : pho_of(1);
+      xa += pho_a;
+      xn += pho_n;
+      chunk2 = 2 % nchunks;
+      it2 = 2 / nchunks;
+    }
     const char* const wr = smem + 2 * AH + (wn * 64 + l31) * ROWB + hi * 16;
     if (tid < BN && tid < d.Cout) bias_lds[tid] = L.bias[tm.tn * BN + tid];
     const int gn_per = fuse_stats ? (d.Cout / L.gn_groups) >> 3 : 1;   // 8-channel chunks per GroupNorm group
@@ -246,9 +268,11 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
 #pragma unroll
               for (int pt = 0; pt < 4; ++pt) asm volatile("" ::"v"(acc[ct][pt]));
           } else {
+            const int oph = MODE == 2 ? tm.phase(it) : 0, osc = MODE == 2 ? 2 : 1;   // MODE 2: output pixel (2 y + dy, 2 x + dx)
             char* const obase = reinterpret_cast<char*>(L.out) +
-                                ((((size_t)tb * d.Hout + ty0 + prow) * d.Wout + tx0 + pcol) * d.Cout + tm.tn * BN + wn * 64 + 8 * hi) * 2;
-            const size_t optb = (size_t)GROWS * d.Wout * d.Cout * 2;   // bytes between the wave's pixel groups
+                                ((((size_t)tb * d.Hout + osc * (ty0 + prow) + (oph >> 1)) * d.Wout + osc * (tx0 + pcol) + (oph & 1)) * d.Cout +
+                                 tm.tn * BN + wn * 64 + 8 * hi) * 2;
+            const size_t optb = (size_t)GROWS * osc * d.Wout * d.Cout * 2;   // bytes between the wave's pixel groups
             float V[16];                                     // [sum | sum of squares][ct][q]
             const bool o16 = L.out_f16 != 0;                  // (wave-uniform; MODE 1 = Downsample never stores f16)
 #pragma unroll
@@ -326,6 +350,13 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
         w2_barrier<false>();   // every LDS read of this phase has been consumed by an MFMA above
       }
       { const char* t = xa; xa = xn; xn = t; }
+      if constexpr (MODE == 2) {                             // xn (the buffer just left) serves step s + 2 next: its tile's phase
+        const int t = pho_a; pho_a = pho_n; pho_n = t;
+        const int want = pho_of(it2);
+        xn += want - pho_n;
+        pho_n = want;
+        if (++chunk2 == nchunks) { chunk2 = 0; ++it2; }
+      }
       if (++chunk == nchunks) {
         chunk = 0;
         ++it;
@@ -352,7 +383,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     const int ptid = tid - 256, slot = ptid & 7, row = ptid >> 3;   // 16-byte unit of a 128-byte row; rows row + 32 k
     char* const Ah0 = smem + row * ROWB + slot * 16;
     char* const Bw0 = smem + 2 * AH + row * ROWB + slot * 16;
-    const int Hl = d.Hout, Wl = d.Wout;
+    const int Hl = MODE == 2 ? d.Hin : d.Hout, Wl = MODE == 2 ? d.Win : d.Wout;   // (MODE 2 tiles the SOURCE image)
     // tile-independent part of every halo unit's address and validity
     unsigned hpix[KU], hedge[KU];
 #pragma unroll
@@ -365,12 +396,12 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
       hedge[k] = (hy == 0 ? 1u : 0u) | (hy == TH + 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == TW + 1 ? 8u : 0u) |
                  (hp >= G::HALO ? 16u : 0u) | (hy == 1 ? 32u : 0u) | (hx == 1 ? 64u : 0u);
     }
-    const bf16_t* const wbase = MODE ? L.w_s2d : PRO == 3 ? reinterpret_cast<const bf16_t*>(L.w_f16) : L.w;
-    const int wkch = MODE ? L.s2d_kchunks : d.kchunks;
+    const bf16_t* const wbase = MODE == 1 ? L.w_s2d : MODE == 2 ? L.w_up : PRO == 3 ? reinterpret_cast<const bf16_t*>(L.w_f16) : L.w;
+    const int wkch = MODE == 1 ? L.s2d_kchunks : d.kchunks;
     // this thread's first unit of a weight tile inside a tap's [2][CoutPad][32] slab; rows row + 32 j are 2048 bytes apart
     const unsigned w_voff = (unsigned)((((slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8) * 2);
     const int wj_mask = nwn == 2 ? 3 : 1;                    // Cout = 64: only 64 weight rows exist (the upper ones are re-read)
-    struct StepInfo { int chunk, it, b, y0, x0; };
+    struct StepInfo { int chunk, it, b, y0, x0, ph; };
     int gC = 0;
     auto advance = [&](StepInfo& si) {                       // past the last step it stays there: harmless reloads
       if (gC + 1 < nsteps) {
@@ -379,6 +410,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
           si.chunk = 0;
           ++si.it;
           tm.decode(si.it, si.b, si.y0, si.x0, TH, TW);
+          si.ph = tm.phase(si.it);
         }
       }
     };
@@ -386,6 +418,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     sA.chunk = 0;
     sA.it = 0;
     tm.decode(0, sA.b, sA.y0, sA.x0, TH, TW);
+    sA.ph = tm.phase(0);
     StepInfo sB = sA;
     advance(sB);
     StepInfo sC = sB;
@@ -449,7 +482,8 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
         const int cc = first ? c : c - d.C0;
         ld_cs2 = (unsigned)(cs * 2);
         ld_tedge = (si.y0 == 0 ? 1u : 0u) | (si.y0 + TH == Hl ? 2u : 0u) | (si.x0 == 0 ? 4u : 0u) | (si.x0 + TW == Wl ? 8u : 0u) | 16u;
-        const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> d.ups)) * d.Win + (si.x0 >> d.ups) - (d.Win + 1);
+        const int sh = MODE == 2 ? 0 : d.ups;                 // (MODE 2: tile origins are source coordinates already)
+        const int64_t horg = ((int64_t)si.b * d.Hin + (si.y0 >> sh)) * d.Win + (si.x0 >> sh) - (d.Win + 1);
         ld_base = reinterpret_cast<const char*>(src) + (horg * cs + cc) * 2;
       }
       ld_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ld_base), 0, 0x7ffffff0, 0x00020000);   // (base may lie before the tensor: only in-image offsets are ever in range AND valid)
@@ -505,9 +539,10 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
       }
       *reinterpret_cast<w2_u32x4*>(Ah0 + bufoff + k * RPP * ROWB) = v;
     };
-    // weight tile of phase `ph` (its tap in the packed 3 x 3 layout) and 64-channel chunk
-    auto w_tile = [&](int ph, int chunk) -> const char* {
-      return reinterpret_cast<const char*>(wbase) + ((size_t)(w2_tapid<MODE>(ph) * wkch + 2 * chunk) * d.CoutPad + tm.tn * BN) * 64 + w_voff;
+    // weight tile of phase `ph` (its tap in the packed 3 x 3 layout) and 64-channel chunk; MODE 2: of sub-pixel `sub`'s 2 x 2 packing
+    auto w_tile = [&](int ph, int chunk, int sub) -> const char* {
+      const int tap = MODE == 2 ? sub * 4 + ph : w2_tapid<MODE>(ph);
+      return reinterpret_cast<const char*>(wbase) + ((size_t)(tap * wkch + 2 * chunk) * d.CoutPad + tm.tn * BN) * 64 + w_voff;
     };
     auto w_issue = [&](int set, const char* p) {
 #pragma unroll
@@ -519,6 +554,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     };
     // global weight tile t (t < 3 NPH) belongs to step t / NPH of (sA, sB, sC)
     auto chunk_of = [&](int t) { return t < NPH ? sA.chunk : t < 2 * NPH ? sB.chunk : sC.chunk; };
+    auto sub_of = [&](int t) { return MODE == 2 ? (t < NPH ? sA.ph : t < 2 * NPH ? sB.ph : sC.ph) : 0; };
 
     // ---- prologue: halo 0 and weight tiles 0, 1 into LDS; halo 1 and tiles 2, 3, 4 into registers
     issue_setup(sA);
@@ -527,8 +563,8 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
 #pragma unroll
     for (int k = 0; k < KU; ++k) issue_unit(k);
     hvalid = hvalid_nxt;
-    w_issue(0, w_tile(0, chunk_of(0)));
-    w_issue(1, w_tile(1, chunk_of(1)));
+    w_issue(0, w_tile(0, chunk_of(0), sub_of(0)));
+    w_issue(1, w_tile(1, chunk_of(1), sub_of(1)));
 #pragma unroll
     for (int k = 0; k < KU; ++k) write_unit(k, 0);
     w_write(0, 0);
@@ -541,9 +577,9 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
 #pragma unroll
     for (int j = 0; j < 4; ++j) cf[j] = nf[j];
     fold_inplace(cf);
-    w_issue(2, w_tile(2 % NPH, chunk_of(2)));
-    w_issue(0, w_tile(3 % NPH, chunk_of(3)));
-    w_issue(1, w_tile(4 % NPH, chunk_of(4)));
+    w_issue(2, w_tile(2 % NPH, chunk_of(2), sub_of(2)));
+    w_issue(0, w_tile(3 % NPH, chunk_of(3), sub_of(3)));
+    w_issue(1, w_tile(4 % NPH, chunk_of(4), sub_of(4)));
     issue_setup(sC);
     w2_barrier<true>();
 
@@ -561,7 +597,7 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
 #pragma unroll
         for (int k = u0; k < u1; ++k) write_unit(k, bufoff);
         if (p == 0) issue_coeffs(nf);                        // coefficients of halo g + 2
-        w_issue(set, w_tile((p + 5) % NPH, chunk_of(p + 5)));   // weight tile NPH g + p + 5: this step's or a later one's chunk
+        w_issue(set, w_tile((p + 5) % NPH, chunk_of(p + 5), sub_of(p + 5)));   // weight tile NPH g + p + 5: this step's or a later one's chunk
 #pragma unroll
         for (int k = u0; k < u1; ++k) issue_unit(k);
         if (p == NPH - 1) {                                  // step bookkeeping (wave-uniform) in the phase without halo work
@@ -1107,6 +1143,54 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
     else if (pro == 1) conv3x3_w256_kernel<16, 1, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
     else conv3x3_w256_kernel<16, 0, 0><<<dim3(grid), 512, lds, s>>>(Lk, tiles_x, tiles_y, tiles_n, fuse);
   }
+  PRG_LAUNCH_CHECK();
+  return 1;
+}
+
+// Upsample (nearest x2) + 3x3 conv as four 2 x 2-tap sub-pixel convolutions of the source image (MODE 2).  Returns 1 / 0 / negative.
+int try_launch_conv3x3_up_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
+  static const int enabled = [] {
+    const char* e = std::getenv("PRG_UP2X2");
+    return e ? std::atoi(e) : 1;
+  }();
+  if (!enabled || !L.w_up) return 0;
+  const ConvDesc& d = L.d;
+  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.ups == 1 && d.C1 == 0)) return 0;
+  if (d.C0 % kCH || d.C0 == 0 || (d.Cout != 64 && d.Cout % BN) || d.CoutPad != d.Cout) return 0;
+  if (L.residual || !L.bias || L.pro_a || L.pro_fold.acc || L.gn_partials || L.out_f16 || L.in_f16) return 0;
+  if (d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win) return 0;
+  const int tiles_n = d.Cout == 64 ? 1 : d.Cout / BN;
+  if (tiles_n != 1 && tiles_n != 2 && tiles_n != 4 && tiles_n != 8) return 0;
+  const int H = d.Hin, W = d.Win;                            // tiles of 256 SOURCE pixels, four phases each
+  int tw = 0;
+  if (W % 32 == 0 && H % 8 == 0) tw = 32;
+  else if (W % 16 == 0 && H % 16 == 0) tw = 16;
+  else return 0;
+  if ((size_t)d.B * d.Hin * d.Win * d.C0 * 2 >= ((size_t)1 << 31)) return 0;   // (32-bit halo offsets, as the other modes)
+  const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
+  const long total = (long)tiles_x * tiles_y * tiles_n * d.B * 4;
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    num_cus = p.multiProcessorCount;
+  }
+  const int grid = num_cus & ~7;
+  static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
+  if (grid < 8 || total < (min_fill > 0 ? min_fill : grid / 2)) return 0;
+  const void* fn = tw == 32 ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 2>)
+                            : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 2>);
+  const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
+  static std::atomic<bool> attr_done[2];
+  if (!attr_done[tw == 32]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 upsample): ") + hipGetErrorString(e));
+    attr_done[tw == 32] = true;
+  }
+  if (L.probe) return 1;
+  if (tw == 32) conv3x3_w256_kernel<32, 0, 2><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
+  else conv3x3_w256_kernel<16, 0, 2><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
   PRG_LAUNCH_CHECK();
   return 1;
 }

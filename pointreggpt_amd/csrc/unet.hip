@@ -100,6 +100,7 @@ struct ConvP {
   int64_t sp_off = -1;     // f16x3 mode: element offset of the hi / lo f16 split packing (ConvLaunch::w_split)
   int sp_kchunks = 0;
   int64_t h16_off = -1;    // bf16 mode, second conv of a ResnetBlock: element offset of the f16 twin of the packing (ConvLaunch::w_f16)
+  int64_t up_off = -1;     // bf16 mode, Upsample convs: element offset of the four pre-summed 2 x 2-tap packings (ConvLaunch::w_up)
 };
 struct ResP {
   int cin = 0, cout = 0;
@@ -355,6 +356,7 @@ struct UnetImpl : prg_unet {
     L.w_mx_scale = (d_mx_scale && p.mx_soff >= 0) ? d_mx_scale + p.mx_soff : nullptr;
     L.mx_pure = 0;
     L.w_s2d = (p.s2d_off >= 0 && stride == 2 && pad == 1) ? reinterpret_cast<const T*>(d_packed) + p.s2d_off : nullptr;
+    L.w_up = (p.up_off >= 0 && ups && stride == 1 && pad == 1) ? reinterpret_cast<const T*>(d_packed) + p.up_off : nullptr;
     L.s2d_kchunks = p.s2d_kchunks;
     L.w_split = (d_split && p.sp_off >= 0) ? d_split + p.sp_off : nullptr;
     L.split_kchunks = p.sp_kchunks;
@@ -875,6 +877,26 @@ static void pack_all(Layout& L, const float* flat, std::vector<T>& packed) {
       packed.resize(off + one.size());
       std::memcpy(packed.data() + off, one.data(), one.size() * sizeof(T));
       p->s2d_off = (int64_t)off;
+    }
+  }
+  if (std::is_same<T, bf16_t>::value) {
+    // Upsample convs (up levels whose resample is nearest x2 + 3 x 3): third packing, the sub-pixel decomposition (conv_w256.hip MODE 2)
+    for (auto& lv : L.ups) {
+      ConvP* p = &lv.resample;
+      if (!lv.strided || !(p->KH == 3 && p->KW == 3 && p->Cin % 64 == 0 && (p->Cout == 64 || p->Cout % 128 == 0))) continue;
+      const float* w = flat + p->w_flat;
+      if (p->ws) { standardize(w, p->Cout, p->Cin * 9, tmp); w = tmp.data(); }
+      std::vector<float> eq;
+      up_equivalent_weights(w, p->Cout, p->Cin, eq);
+      size_t off = (packed.size() + 127) / 128 * 128;
+      p->up_off = (int64_t)off;
+      for (int ph = 0; ph < 4; ++ph) {
+        int cp = 0, kc = 0;
+        pack_conv_weight<T>(eq.data() + (size_t)ph * p->Cout * p->Cin * 4, p->Cout, p->Cin, 2, 2, one, &cp, &kc);
+        packed.resize(off + one.size());
+        std::memcpy(packed.data() + off, one.data(), one.size() * sizeof(T));
+        off += one.size();
+      }
     }
   }
 }
@@ -1416,18 +1438,29 @@ static int debug_conv_f32(const float* x, const float* w, const float* bias, flo
 }
 
 static int debug_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
-                      int dtype, int K, int stride, void* stream) {
+                      int dtype, int K, int stride, void* stream, int ups = 0) {
   PRG_CHECK(x && w && out, "prg_debug_conv3x3: null pointer");
   PRG_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0, "prg_debug_conv3x3: bad shape");
   PRG_CHECK(dtype == PRG_BF16 || dtype == PRG_MXFP8 || dtype == PRG_F32 || dtype == PRG_F16X3, "prg_debug_conv3x3: bad dtype");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == PRG_F32 || dtype == PRG_F16X3) return debug_conv_f32(x, w, bias, out, B, Cin, Cout, H, W, dtype, K, stride, K == 1 ? 0 : 1, s);
   const size_t M = (size_t)B * H * W;
-  const int Ho = H / stride, Wo = W / stride;
+  const int Ho = ups ? 2 * H : H / stride, Wo = ups ? 2 * W : W / stride;
   const size_t Mo = (size_t)B * Ho * Wo;
   std::vector<bf16_t> packed;
   int cp = 0, kc = 0;
   pack_conv_weight<bf16_t>(w, Cout, Cin, K, K, packed, &cp, &kc);
+  std::vector<bf16_t> packed_up;
+  if (ups && Cin % 64 == 0 && (Cout == 64 || Cout % 128 == 0)) {
+    std::vector<float> eq;
+    std::vector<bf16_t> one;
+    up_equivalent_weights(w, Cout, Cin, eq);
+    for (int ph = 0; ph < 4; ++ph) {
+      int cp2 = 0, kc2 = 0;
+      pack_conv_weight<bf16_t>(eq.data() + (size_t)ph * Cout * Cin * 4, Cout, Cin, 2, 2, one, &cp2, &kc2);
+      packed_up.insert(packed_up.end(), one.begin(), one.end());
+    }
+  }
   std::vector<bf16_t> packed_s2d;
   int kc_s2d = 0;
   if (K == 4 && Cin % 64 == 0 && Cout % 64 == 0) {
@@ -1443,9 +1476,11 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
     pack_conv_weight_mxfp8(w, Cout, Cin, 3, 3, mxd, mxs, &cp2, &kc2);
   }
   std::vector<float> zb(Cout, 0.0f);
-  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_mxd = nullptr, *d_mxs = nullptr, *d_w2 = nullptr;
-  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_mxd, d_mxs, d_w2}) if (p) (void)hipFree(p); };
+  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_mxd = nullptr, *d_mxs = nullptr, *d_w2 = nullptr, *d_wu = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_mxd, d_mxs, d_w2, d_wu}) if (p) (void)hipFree(p); };
   if (hipMalloc(&d_in, M * Cin * 2) != hipSuccess || hipMalloc(&d_out, Mo * Cout * 2) != hipSuccess ||
+      (!packed_up.empty() && (hipMalloc(&d_wu, packed_up.size() * 2) != hipSuccess ||
+                              hipMemcpy(d_wu, packed_up.data(), packed_up.size() * 2, hipMemcpyHostToDevice) != hipSuccess)) ||
       (!packed_s2d.empty() && hipMalloc(&d_w2, packed_s2d.size() * 2) != hipSuccess) ||
       hipMalloc(&d_w, packed.size() * 2) != hipSuccess || hipMalloc(&d_b, Cout * 4) != hipSuccess ||
       (dtype == PRG_MXFP8 && (hipMalloc(&d_mxd, mxd.size()) != hipSuccess || hipMalloc(&d_mxs, mxs.size()) != hipSuccess))) {
@@ -1465,11 +1500,12 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
   int rc = launch_nchw_f32_to_nhwc<bf16_t>(x, reinterpret_cast<bf16_t*>(d_in), B, H * W, Cin, s);
   if (rc == PRG_OK) {
     ConvLaunch<bf16_t> L{};
-    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = 0; L.d.KH = K; L.d.KW = K; L.d.stride = stride; L.d.pad = 1;
+    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = ups; L.d.KH = K; L.d.KW = K; L.d.stride = stride; L.d.pad = 1;
     L.d.Hout = Ho; L.d.Wout = Wo; L.d.Cout = Cout; L.d.CoutPad = cp; L.d.kchunks = kc;
     L.src0 = reinterpret_cast<const bf16_t*>(d_in); L.w = reinterpret_cast<const bf16_t*>(d_w);
     L.bias = reinterpret_cast<const float*>(d_b); L.out = reinterpret_cast<bf16_t*>(d_out);
     L.gn_groups = 8;
+    L.w_up = reinterpret_cast<const bf16_t*>(d_wu);
     L.w_s2d = reinterpret_cast<const bf16_t*>(d_w2); L.s2d_kchunks = kc_s2d;
     L.w_mx = reinterpret_cast<const uint8_t*>(d_mxd); L.w_mx_scale = reinterpret_cast<const uint8_t*>(d_mxs);
     L.mx_pure = 1;
@@ -1561,6 +1597,11 @@ int prg_debug_conv(const float* x, const float* w, const float* bias, float* out
   PRG_CHECK(dtype == PRG_F32 || dtype == PRG_F16X3 || K != 1, "prg_debug_conv: 1x1 convs only in the float32-storage modes");
   PRG_CHECK(stride == 1 || (H % 2 == 0 && W % 2 == 0), "prg_debug_conv: odd image size");
   return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, dtype, K, stride, stream);
+}
+
+int prg_debug_upsample_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                               void* stream) {
+  return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, PRG_BF16, 3, 1, stream, 1);
 }
 
 int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,

@@ -304,7 +304,10 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
                 "gn_acc_w256_all": {"PRG_W256_MIN_TILES": "1", "PRG_GN_ACC": "1"},
                 # round 4: h1 (the tensor between a ResnetBlock's two convs) as bf16 with the float32 prologue instead of f16 with
                 # the packed-f16 prologue and f16 MFMA operands in conv2 (conv.h, "h16")
-                "no_h16": {"PRG_H16": "0"}}
+                "no_h16": {"PRG_H16": "0"},
+                # Upsample convs in the nine-tap gather form instead of the four 2 x 2-tap sub-pixel convolutions (conv_w256.hip MODE 2);
+                # and the sub-pixel form wherever the shape allows (at these batch sizes the default keeps the gather form)
+                "no_up2x2": {"PRG_UP2X2": "0"}, "up2x2_all": {"PRG_W256_MIN_TILES": "1", "PRG_UP2X2": "1"}}
     for name, env in variants.items():
         out = str(tmp_path / f"{name}.npz")
         e = dict(os.environ, **env)
@@ -313,7 +316,7 @@ def test_bf16_fast_paths_match_generic_kernels(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs[name] = np.load(out)
     for name in ("no_ws", "no_fused_attn", "no_kshift", "no_c64", "gn_fold", "c64_contiguous", "w256_all", "no_w256", "no_res_epilogue", "no_head_fuse",
-                 "no_gn_acc", "gn_acc_w256_all", "la_psum", "la_ssum", "no_h16"):
+                 "no_gn_acc", "gn_acc_w256_all", "la_psum", "la_ssum", "no_h16", "no_up2x2", "up2x2_all"):
         for k in ("y64", "y128", "y40", "y96"):
             d = np.abs(outs["fast"][k].astype(np.float64) - outs[name][k].astype(np.float64))
             assert np.isfinite(outs[name][k]).all()
@@ -905,6 +908,40 @@ def test_conv3x3_kernels_one_at_a_time(hip, B, Cin, Cout, H, Wd):
     err = (got.double() - ref).abs()
     tol = 2.0 ** -8 * ref.abs() + 1e-4 * float(ref.abs().max())
     assert bool((err <= tol).all()), float((err - tol).max())
+
+
+UP_SHAPES = [(16, 512, 256, 16, 16),   # 16 x 16 source tiles, two output-channel tiles (up level 0 -> 1)
+             (8, 256, 128, 32, 32),    # 8 x 32 source tiles (up level 1 -> 2)
+             (8, 128, 64, 64, 64),     # Cout = 64: the second channel half of the consumers idles (up level 2 -> 3)
+             (16, 64, 128, 16, 32),    # one 64-channel chunk per phase, 16 x 16 tiles on a non-square image
+             (1, 128, 64, 16, 16)]     # too small for it: the nine-tap gather form of the older kernels
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,Wd", UP_SHAPES)
+def test_upsample_conv_subpixel_form(hip, B, Cin, Cout, H, Wd):
+    """Upsample = nn.Upsample(x2, nearest) + Conv2d(C, Cout, 3, pad 1) (sd:592-594) through the dispatch: the 256-pixel
+    kernel's MODE 2 (four 2 x 2-tap sub-pixel convolutions of the source image with pre-summed weights: 4 / 9 of the MACs)
+    against a float64 convolution of the nearest-upsampled bf16-rounded input with the UNROUNDED weights.  What remains: bf16
+    rounding of the (pre-summed) weights and of the output."""
+    import ctypes as C
+    lib = hip.lib.load()
+    g = torch.Generator().manual_seed(Cin * 53 + Cout + H)
+    x = torch.randn((B, Cin, H, Wd), generator=g) * torch.exp(0.5 * torch.randn((1, Cin, 1, 1), generator=g))
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3.0 * Cin ** 0.5)
+    bias = torch.randn((Cout,), generator=g)
+    out = torch.empty((B, Cout, 2 * H, 2 * Wd), dtype=torch.float32, device="cuda")
+    wh, bh = np.ascontiguousarray(w.numpy(), dtype=np.float32), np.ascontiguousarray(bias.numpy(), dtype=np.float32)
+    hip.lib.check(lib.prg_debug_upsample_conv3x3(hip.lib.ptr(x.cuda().contiguous()), wh.ctypes.data_as(C.c_void_p), bh.ctypes.data_as(C.c_void_p),
+                                                 hip.lib.ptr(out), B, Cin, Cout, H, Wd, hip.lib.stream_ptr()), "prg_debug_upsample_conv3x3")
+    xu = torch.nn.functional.interpolate(x.to(torch.bfloat16).double(), scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xu, w.double(), bias.double(), padding=1)
+    err = (out.cpu().double() - ref).abs()
+    scale = float(ref.abs().max())
+    print(f"upsample conv {Cin}->{Cout} @{H}x{Wd} B={B}: max {float(err.max()):.3e} mean {float(err.mean()):.3e} (|ref| max {scale:.2f})")
+    # bf16 output rounding (2^-9 relative) + bf16 weight rounding summed over K = 9 Cin terms (random signs: ~2^-9 |ref| rms)
+    tol = 2.0 ** -7 * ref.abs() + 2.0 ** -8 * scale
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert float(err.mean()) <= 2.0 ** -9 * scale
 
 
 # (B, Cin, C, H, W): conv1 / conv2 kernels of the pair
