@@ -31,7 +31,8 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mxfp8": 5000.0, "f16x3": 250
 CONV_CLASS = ("MFMA convolutions: conv3x3_w256_kernel (256-pixel x 128-channel tiles, also Downsample) + conv3x3_c64_kernel "
               "(64 -> 64, weights-stationary) + conv3x3_ws_kernel (128-pixel wave-specialised tiles) + conv_igemm_kernel (1x1); "
               "the second conv of every ResnetBlock reads an f16 tensor through a packed-f16 GroupNorm+SiLU prologue and contracts "
-              "f16 operands (v_mfma_f32_32x32x16_f16, the bf16 instruction's rate; 'h16', DESIGN 4.7)")
+              "f16 operands (v_mfma_f32_32x32x16_f16, the bf16 instruction's rate; 'h16', DESIGN 4.7); Upsample convs as four 2x2-tap "
+              "sub-pixel convolutions (4/9 of the MACs, DESIGN 4.8)")
 
 
 def conv_sources_hash():
@@ -714,6 +715,11 @@ def main():
             "peak_measured_random_operands": 1670.0 if a.dtype == "bf16" else None,   # tools/micro/mfma_power.hip, power-limited
             "launches": pr["conv_launches"], "avg_launch_us": pr["conv_ms"] * 1e3 / max(1, pr["conv_launches"]),
             "flop_per_launch": pr["conv_flops"] / max(1, pr["conv_launches"]),
+            # `achieved` / `frac` are ALGORITHMIC (the reference operator's 2 * MAC count); the three Upsample convs
+            # run as four 2 x 2-tap sub-pixel convolutions (4 / 9 of their MACs): what the matrix pipe actually executed
+            "executed_achieved": pr.get("conv_flops_executed", pr["conv_flops"]) / (pr["conv_ms"] * 1e-3) / 1e12,
+            "executed_frac": pr.get("conv_flops_executed", pr["conv_flops"]) / (pr["conv_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype],
+            "executed_over_algorithmic_flops": pr.get("conv_flops_executed", pr["conv_flops"]) / max(1.0, pr["conv_flops"]),
             "share_of_step_time": pr["conv_ms"] / pr["total_ms"],
             "measured": f"HIP events around every conv launch, {nprof} transitions, batch {B}",
         }

@@ -236,6 +236,9 @@ int prg_sampler_get_profile(prg_sampler* h, double* conv_ms, int64_t* conv_launc
 /* Algorithmic bytes of the same launches (each input and output element once, plus the weights): what the PMC-measured
  * HBM traffic of bench.py's `roofline.traffic` is compared with. */
 int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes);
+/* 2 * MAC count the same launches EXECUTED: equal to conv_flops except for Upsample convs that ran as four 2 x 2-tap sub-pixel
+ * convolutions (4 / 9 of the algorithmic count, which stays the reference operator's). */
+int prg_sampler_get_profile_executed(prg_sampler* h, double* conv_flops_executed);
 /* The same for the per-transition update kernel (x0 / DDNM replace / posterior / noise: HBM-bound, 20 B per pixel). */
 int prg_sampler_get_profile_step(prg_sampler* h, double* step_ms, int64_t* step_launches);
 

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "prg_sampler_get_profile": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]),
     "prg_sampler_get_profile_bytes": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "prg_sampler_get_profile_executed": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "prg_sampler_get_profile_step": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
     "prg_host_crop_aabb": (C.c_int, [_P, _L, _P, _P, _P, C.POINTER(_L)]),
     "prg_host_voxel_down_sample": (C.c_int, [_P, _L, C.c_double, _P, C.POINTER(_L)]),

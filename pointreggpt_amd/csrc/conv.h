@@ -182,6 +182,10 @@ int launch_conv(const ConvLaunch<T>& L, hipStream_t s, int* gn_nsplit_out, int* 
 template <typename T>
 bool conv_supports_prologue(const ConvDesc& d);
 
+// executed / algorithmic MAC ratio of the calling thread's last launch_conv: 1, or 4 / 9 when an Upsample conv ran as four
+// 2 x 2-tap sub-pixel convolutions (conv_w256.hip MODE 2) — conv_flops() below is the ALGORITHMIC count (the reference's op)
+double conv_last_exec_scale();
+
 inline double conv_flops(const ConvDesc& d) {
   return 2.0 * (double)d.B * d.Hout * d.Wout * d.Cout * (double)(d.C0 + d.C1) * d.KH * d.KW;
 }

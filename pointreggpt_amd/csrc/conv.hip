@@ -775,6 +775,10 @@ static int launch_mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats,
 }
 // MX-fp8 operands: 1 = launched, 0 = shape not covered (bf16 kernels run instead)
 int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done);   // conv_w256.hip
+// executed / algorithmic MAC ratio of this thread's last launch_conv (1 except for the sub-pixel Upsample form: 4 / 9)
+static thread_local double g_last_exec_scale = 1.0;
+double conv_last_exec_scale() { return g_last_exec_scale; }
+
 // Consumers without the in-kernel GroupNorm fold (common.h, GnFold): fill the pro_a / pro_b tables from the accumulators
 // with one small launch, then run on the tables as before.
 int materialize_prologue(ConvLaunch<bf16_t>& L, hipStream_t s) {
@@ -826,7 +830,10 @@ static inline int try_down(const ConvLaunch<bf16_t>& L, hipStream_t s) { return 
 static inline int try_down(const ConvLaunch<float>&, hipStream_t) { return 0; }
 static inline int try_ws(ConvLaunch<bf16_t>& L, hipStream_t s, int* n, int* coef_done, int* acc_done) {
   int r = try_launch_conv3x3_c64(L, s, n, coef_done, acc_done);   // weights-stationary kernel for the 64 -> 64 convs
-  if (r == 0 && L.d.ups && !L.gn_partials) r = try_launch_conv3x3_up_w256(L, s);   // Upsample convs as four 2 x 2-tap sub-pixel convs
+  if (r == 0 && L.d.ups && !L.gn_partials) {
+    r = try_launch_conv3x3_up_w256(L, s);                    // Upsample convs as four 2 x 2-tap sub-pixel convs
+    if (r == 1) g_last_exec_scale = 4.0 / 9.0;               // (what the profile reports as EXECUTED work)
+  }
   if (r == 0) r = try_launch_conv3x3_w256(L, s, n, acc_done);     // 256-pixel x 128-channel tiles where the launch fills the chip
   if (r != 0) return r;
   // the wave-specialised kernel reads coefficient tables (hand-counted loads): fold the accumulators into them first when
@@ -874,6 +881,7 @@ bool conv_h16_pair_ok(const ConvLaunch<bf16_t>& L1in, const ConvLaunch<bf16_t>& 
 
 template <typename T>
 int launch_conv(const ConvLaunch<T>& Lin, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
+  g_last_exec_scale = 1.0;
   if (coef_done) *coef_done = 0;
   if (acc_done) *acc_done = 0;
   ConvLaunch<T> L = Lin;          // (materialize_prologue clears pro_fold once the coefficient tables are filled)

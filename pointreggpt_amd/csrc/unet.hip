@@ -77,6 +77,7 @@ struct ProfileSink {  // per-launch conv timing (bench roofline)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
   size_t used = 0;
   double conv_ms = 0, conv_flops = 0, conv_bytes = 0;   // conv_bytes: algorithmic input + output + weight bytes
+  double conv_flops_exec = 0;                           // 2 * MACs the kernels executed (sub-pixel Upsample convs: 4 / 9 of the algorithmic count)
   int64_t launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> step_pool;   // the per-transition update kernel (HBM-bound)
   size_t step_used = 0;
@@ -392,6 +393,7 @@ struct UnetImpl : prg_unet {
       int rc = launch_conv<T>(L, s, o.gn_nsplit, o.coef_done, o.acc_done);
       PRG_HIP(hipEventRecord(ev.second, s));
       prof->conv_flops += conv_flops(L.d);
+      prof->conv_flops_exec += conv_flops(L.d) * conv_last_exec_scale();
       prof->conv_bytes += ((double)L.d.B * L.d.Hin * L.d.Win * (L.d.C0 + L.d.C1) + (double)L.d.B * L.d.Hout * L.d.Wout * L.d.Cout +
                            (double)L.d.Cout * (L.d.C0 + L.d.C1) * L.d.KH * L.d.KW) * sizeof(T);
       prof->launches += 1;
@@ -1687,6 +1689,12 @@ int prg_sampler_set_profile(prg_sampler* h, int enable) {
   return PRG_OK;
 }
 
+int prg_sampler_get_profile_executed(prg_sampler* h, double* conv_flops_executed) {
+  PRG_CHECK(h && conv_flops_executed, "prg_sampler_get_profile_executed: null argument");
+  *conv_flops_executed = h->prof.conv_flops_exec;
+  return PRG_OK;
+}
+
 int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes) {
   PRG_CHECK(h && conv_bytes, "prg_sampler_get_profile_bytes: null argument");
   *conv_bytes = h->prof.conv_bytes;
@@ -1750,7 +1758,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
 
   const bool profiling = h->prof.on;
   u->prof = profiling ? &h->prof : nullptr;
-  h->prof.conv_ms = 0; h->prof.conv_flops = 0; h->prof.conv_bytes = 0; h->prof.launches = 0; h->prof.used = 0;
+  h->prof.conv_ms = 0; h->prof.conv_flops = 0; h->prof.conv_flops_exec = 0; h->prof.conv_bytes = 0; h->prof.launches = 0; h->prof.used = 0;
   h->prof.step_ms = 0; h->prof.step_launches = 0; h->prof.step_used = 0;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   if (profiling) {

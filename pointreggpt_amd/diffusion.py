@@ -191,5 +191,7 @@ class GaussianDiffusion:
         _lib.check(lib.prg_sampler_get_profile_bytes(h, C.byref(by)))
         sms, sn = C.c_double(), C.c_int64()
         _lib.check(lib.prg_sampler_get_profile_step(h, C.byref(sms), C.byref(sn)))
-        return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value, "conv_bytes": by.value,
+        ex = C.c_double()
+        _lib.check(lib.prg_sampler_get_profile_executed(h, C.byref(ex)))
+        return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value, "conv_bytes": by.value, "conv_flops_executed": ex.value,
                 "total_ms": tot.value, "step_ms": sms.value, "step_launches": sn.value}
