@@ -152,9 +152,12 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
   const ConvDesc& d = L.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nchunks = MODE == 1 ? 4 * d.C0 / kCH : (d.C0 + d.C1) / kCH;
-  const int nwn = d.Cout >= BN ? 2 : 1;                     // active channel halves (Cout = 64: the second half idles)
+  // MODE 2 with Cout = 64 ("dual"): the two channel halves of the consumers take the two x-phases (dy, 0) / (dy, 1) of the SAME
+  // source tile — 2 x 64 virtual output channels on one halo — instead of one half idling; a tile index then carries dy only
+  const bool dual = MODE == 2 && d.Cout == 64;
+  const int nwn = (d.Cout >= BN || dual) ? 2 : 1;           // active channel halves (Cout = 64: the second half idles)
   W2Tiles tm;
-  tm.init((int)blockIdx.x, (int)gridDim.x, tiles_x, tiles_y, tiles_n, d.B, MODE == 2 ? 2 : 0);
+  tm.init((int)blockIdx.x, (int)gridDim.x, tiles_x, tiles_y, tiles_n, d.B, MODE == 2 ? (dual ? 1 : 2) : 0);
   const int nsteps = tm.count * nchunks;
   if (nsteps == 0) return;
   const int nsteps_pad = (nsteps + UNR - 1) / UNR * UNR;    // the producers' loop body covers UNR steps (clamped reloads past the end)
@@ -174,7 +177,10 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     const char* xn = xa + AH;
     // MODE 2: the 2 x 2 window of phase (dy, dx) starts at halo position (dy, dx): the phase's byte offset rides on xa / xn
     // (pho_a / pho_n = the offsets they currently carry; step s + 2's tile is tracked by (chunk2, it2))
-    auto pho_of = [&](int tile) { const int ph = tm.phase(tile); return ((ph >> 1) * HP + (ph & 1)) * ROWB; };
+    auto pho_of = [&](int tile) {
+      const int ph = tm.phase(tile);
+      return dual ? (ph * HP + wn) * ROWB : ((ph >> 1) * HP + (ph & 1)) * ROWB;
+    };
     int pho_a = 0, pho_n = 0, chunk2 = 0, it2 = 0;
     if constexpr (MODE == 2) {
       pho_a = pho_of(0);
@@ -185,7 +191,8 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
       it2 = 2 / nchunks;
     }
     const char* const wr = smem + 2 * AH + (wn * 64 + l31) * ROWB + hi * 16;
-    if (tid < BN && tid < d.Cout) bias_lds[tid] = L.bias[tm.tn * BN + tid];
+    if (dual) { if (tid < BN) bias_lds[tid] = L.bias[tid & 63]; }
+    else if (tid < BN && tid < d.Cout) bias_lds[tid] = L.bias[tm.tn * BN + tid];
     const int gn_per = fuse_stats ? (d.Cout / L.gn_groups) >> 3 : 1;   // 8-channel chunks per GroupNorm group
     const int gn_per_sh = 31 - __builtin_clz(gn_per);
     if (wn >= nwn) {                                         // idle channel half: only the barriers
@@ -269,9 +276,9 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
               for (int pt = 0; pt < 4; ++pt) asm volatile("" ::"v"(acc[ct][pt]));
           } else {
             const int oph = MODE == 2 ? tm.phase(it) : 0, osc = MODE == 2 ? 2 : 1;   // MODE 2: output pixel (2 y + dy, 2 x + dx)
+            const int ody = dual ? oph : oph >> 1, odx = dual ? wn : oph & 1, och = dual ? 0 : tm.tn * BN + wn * 64;
             char* const obase = reinterpret_cast<char*>(L.out) +
-                                ((((size_t)tb * d.Hout + osc * (ty0 + prow) + (oph >> 1)) * d.Wout + osc * (tx0 + pcol) + (oph & 1)) * d.Cout +
-                                 tm.tn * BN + wn * 64 + 8 * hi) * 2;
+                                ((((size_t)tb * d.Hout + osc * (ty0 + prow) + ody) * d.Wout + osc * (tx0 + pcol) + odx) * d.Cout + och + 8 * hi) * 2;
             const size_t optb = (size_t)GROWS * osc * d.Wout * d.Cout * 2;   // bytes between the wave's pixel groups
             float V[16];                                     // [sum | sum of squares][ct][q]
             const bool o16 = L.out_f16 != 0;                  // (wave-uniform; MODE 1 = Downsample never stores f16)
@@ -400,7 +407,8 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     const int wkch = MODE == 1 ? L.s2d_kchunks : d.kchunks;
     // this thread's first unit of a weight tile inside a tap's [2][CoutPad][32] slab; rows row + 32 j are 2048 bytes apart
     const unsigned w_voff = (unsigned)((((slot >> 2) * d.CoutPad + row) * 32 + (slot & 3) * 8) * 2);
-    const int wj_mask = nwn == 2 ? 3 : 1;                    // Cout = 64: only 64 weight rows exist (the upper ones are re-read)
+    const int wj_mask = (nwn == 2 && !dual) ? 3 : 1;         // Cout = 64: only 64 weight rows exist (the upper ones are re-read)
+    const size_t wsub = (size_t)4 * wkch * d.CoutPad * 64;   // dual: bytes between the packings of two phases (rows 64-127 = phase dx = 1)
     struct StepInfo { int chunk, it, b, y0, x0, ph; };
     int gC = 0;
     auto advance = [&](StepInfo& si) {                       // past the last step it stays there: harmless reloads
@@ -541,12 +549,13 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
     };
     // weight tile of phase `ph` (its tap in the packed 3 x 3 layout) and 64-channel chunk; MODE 2: of sub-pixel `sub`'s 2 x 2 packing
     auto w_tile = [&](int ph, int chunk, int sub) -> const char* {
-      const int tap = MODE == 2 ? sub * 4 + ph : w2_tapid<MODE>(ph);
+      const int tap = MODE == 2 ? (dual ? 2 * sub : sub) * 4 + ph : w2_tapid<MODE>(ph);
       return reinterpret_cast<const char*>(wbase) + ((size_t)(tap * wkch + 2 * chunk) * d.CoutPad + tm.tn * BN) * 64 + w_voff;
     };
     auto w_issue = [&](int set, const char* p) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wset[set][j] = *reinterpret_cast<const w2_u32x4*>(p + ((PRG_W256_EXP & 8) ? 0 : (j & wj_mask) * 2048));
+      for (int j = 0; j < 4; ++j)
+        wset[set][j] = *reinterpret_cast<const w2_u32x4*>(p + ((PRG_W256_EXP & 8) ? 0 : (j & wj_mask) * 2048) + ((dual && j >= 2) ? wsub : (size_t)0));
     };
     auto w_write = [&](int set, int ring) {
 #pragma unroll
@@ -1168,7 +1177,7 @@ int try_launch_conv3x3_up_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
   else return 0;
   if ((size_t)d.B * d.Hin * d.Win * d.C0 * 2 >= ((size_t)1 << 31)) return 0;   // (32-bit halo offsets, as the other modes)
   const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
-  const long total = (long)tiles_x * tiles_y * tiles_n * d.B * 4;
+  const long total = (long)tiles_x * tiles_y * tiles_n * d.B * (d.Cout == 64 ? 2 : 4);   // (Cout = 64: two x-phases per tile)
   static int num_cus = 0;
   if (!num_cus) {
     int dev = 0;
