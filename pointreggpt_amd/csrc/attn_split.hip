@@ -132,7 +132,7 @@ __device__ inline void load_wfrags(h8 (&w)[COLS / 16], const uint16_t* mat, int 
 // la_ctx: per slab (column maxima of k, sums of p = exp2(k - max), p^T v)
 // =====================================================================================================
 template <int C>
-__global__ __launch_bounds__(256, 2) void la_ctx_split_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wqkv_h,
+__global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_ctx_split_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wqkv_h,
                                                               const uint16_t* __restrict__ wqkv_l, float* __restrict__ ctxp,
                                                               float* __restrict__ sump, float* __restrict__ maxp, int N, int nslab) {
   using G = SG<C>;
@@ -453,7 +453,10 @@ int launch_c(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, con
 
 }  // namespace
 
-bool linattn_split_supported(int C, int N) { return C == 64 && N % kTP == 0 && N >= kTP; }
+bool linattn_split_supported(int C, int N) {
+  static const int c128 = [] { const char* e = std::getenv("PRG_SPLIT_ATTN_C128"); return e ? std::atoi(e) : 1; }();
+  return (C == 64 || (C == 128 && c128)) && N % kTP == 0 && N >= kTP;
+}
 
 size_t linattn_split_ws_floats(int B, int N) {
   const int ntiles = N / kTP, nslab = ceil_div(ntiles, sp_tpb(ntiles));
@@ -466,6 +469,7 @@ int launch_linear_attention_split(const float* x, const uint16_t* wqkv_h, const 
                                   const uint16_t* wout_l, const float* bias, const float* out_g, float* out, float* ws, int B, int N,
                                   int C, hipStream_t s) {
   PRG_CHECK(linattn_split_supported(C, N) && x && out && ws, "linear attention (f16x3): unsupported shape");
+  if (C == 128) return launch_c<128>(x, wqkv_h, wqkv_l, wout_h, wout_l, bias, out_g, out, ws, B, N, s);
   return launch_c<64>(x, wqkv_h, wqkv_l, wout_h, wout_l, bias, out_g, out, ws, B, N, s);
 }
 

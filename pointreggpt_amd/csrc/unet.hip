@@ -1023,7 +1023,7 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       std::memcpy(&l, &b, 2);
     };
     auto add_attn = [&](AttnP& a) {
-      if (!sa_on || !a.linear || a.C != 64) return;      // (linattn_split_supported: C = 64; the token count is checked per call)
+      if (!sa_on || !a.linear || (a.C != 64 && a.C != 128)) return;   // (linattn_split_supported: C = 64 / 128; the token count is checked per call)
       aw.resize((aw.size() + 63) / 64 * 64);
       a.sp_qkv = (int64_t)aw.size();
       const size_t nq = (size_t)3 * kHidden * a.C;
