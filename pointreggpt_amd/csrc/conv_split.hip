@@ -1174,7 +1174,10 @@ static int launch_split_igemm(const ConvLaunch<float>& L, int M, hipStream_t s, 
 int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsplit_out) {
   if (!L.w_split) return 0;
   const ConvDesc& d = L.d;
-  if (d.Cout % 8 || d.C0 % 8 || d.C1 % 8 || L.res_a || L.res_fold.acc || L.pro_fold.acc) return 0;
+  if (d.Cout % 8 || d.C0 % 8 || d.C1 % 8 || L.res_fold.acc || L.pro_fold.acc) return 0;
+  // the activated residual (ConvLaunch::res_a: the ResnetBlock tail in a 1x1 res_conv's epilogue) is the shared transposing
+  // epilogue's feature: the gather kernel below has it, the 3x3 kernels do not
+  if (L.res_a && !(d.KH == 1 && d.KW == 1)) return 0;
   const int64_t M64 = (int64_t)d.B * d.Hout * d.Wout;
   if ((int64_t)d.B * d.Hin * d.Win >= ((int64_t)1 << 31) || M64 >= ((int64_t)1 << 31)) return 0;
   const int M = (int)M64;

@@ -523,7 +523,10 @@ struct UnetImpl : prg_unet {
       fused_tail = r.has_res && r.fw_res >= 0 && d_attn && resblock_tail_fused_supported(C0, C1, r.cout);
     // bf16: a res_conv the fused tail kernel does not cover (up levels 0-1: 768 -> 512, 384 -> 256) takes the tail into ITS
     // epilogue instead: out = Wres . cat[s0, s1] + b + SiLU(GroupNorm(h)), one launch, `res` never materialised either
-    const bool epi_tail = std::is_same<T, bf16_t>::value && r.has_res && !fused_tail && r.cout % 8 == 0 && res_epilogue_enabled();
+    // (f16x3 too, round 4: the split-operand 1x1 kernel shares the transposing epilogue — `res` is not written and re-read, the
+    //  GroupNorm + SiLU + skip pass of these blocks is gone; the exact-f32 parity mode keeps its separate passes)
+    const bool epi_tail = (std::is_same<T, bf16_t>::value || (std::is_same<T, float>::value && d_split != nullptr)) && r.has_res && !fused_tail &&
+                          r.cout % 8 == 0 && res_epilogue_enabled();
     if (fused_tail || epi_tail) {
       // res_conv folded into the tail pass below: `res` is never materialised
     } else if (r.has_res) {
