@@ -86,6 +86,9 @@ struct ConvLaunch {
   // [tap][32-channel chunk][CoutPad][32 hi | 32 lo]; null = the exact-f32 kernels
   const uint16_t* w_split;
   int split_kchunks;
+  // f16x3, Upsample convs: the four sub-pixel 2 x 2-tap packings (up_equivalent_weights) in the split layout, phase-major:
+  // [phase][tap 4][32-channel chunk][CoutPad][32 hi | 32 lo]; null = the nine-tap gather form
+  const uint16_t* w_up_split = nullptr;
   // h16 (bf16 mode, round 4): the tensor between the two convs of a ResnetBlock only ever feeds conv2's fused GroupNorm + SiLU
   // prologue, so it is stored as IEEE f16 instead of bf16 — the prologue then runs in PACKED f16 (v_pk_fma_f16, v_exp_f16,
   // v_rcp_f16: two channels per instruction, no unpack / repack) and conv2 contracts f16 operands

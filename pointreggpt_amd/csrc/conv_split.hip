@@ -580,10 +580,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // fetch tile t + 1's first fragments before barrier(t + 1)), tile t - 1's slot is free.  The epilogue is wave-local (each
 // consumer transposes its own tile through a private LDS stage; GroupNorm partial sums per (tile, pixel half) slab): no
 // workgroup barrier after the one that ends the main loop.
-template <int NS>
+// UP (round 4, second half): Upsample = nearest x2 + 3 x 3 conv as four 2 x 2-tap sub-pixel convolutions of the SOURCE image
+// (conv_w256.hip MODE 2 / DESIGN 4.8 for the algebra): a tile is 128 source pixels x one phase (dy, dx) = the two low bits of the
+// tile index, NT = 4 taps per chunk from the phase's own split packing (L.w_up_split), the phase's window starts at halo position
+// (dy, dx), the epilogue stores to (2 y + dy, 2 x + dx).  With four taps per chunk a halo pass would have ONE tap between its
+// load and its conversion, so the halo producers run two chunks ahead (two register sets).
+template <int NS, bool UP>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaunch<float> L, const int tiles_x, const int tiles_y,
                                                                   const int tiles_n, const int fuse_stats) {
   constexpr int TH = 8, TW = 16, BN = 128, CH = 32;
+  constexpr int NT = UP ? 4 : 9;                         // taps per channel chunk
   constexpr int HP = TW + 2, HALO = (TH + 2) * HP, PITCH = 144;
   constexpr int RSTRIDE = (HP * PITCH + 255) / 256 * 256, HBYTES = (TH + 2) * RSTRIDE;   // (row stride 0 mod 16 slots: see above)
   constexpr int NHP = (HALO * 4 + 127) / 128;            // halo staging passes of the 128 halo-producer threads (6)
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
   char* const Bs = smem + 2 * HBYTES;                    // [NS][128][128 B], units XOR-swizzled by (row >> 1) & 7
 
   const ConvDesc& d = L.d;
-  const int nblk = tiles_x * tiles_y * tiles_n * d.B;
+  const int nblk = tiles_x * tiles_y * tiles_n * d.B * (UP ? 4 : 1);
   int tn, lin;
   if (tiles_n > 1 && 8 % tiles_n == 0 && nblk % 8 == 0) {  // every XCD pinned to one output-channel tile (its weight slice stays in L2)
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = 8 / tiles_n;
@@ -606,14 +612,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     tn = lin % tiles_n;
     lin /= tiles_n;
   }
+  const int ph = UP ? lin & 3 : 0;                       // sub-pixel phase 2 dy + dx
+  if (UP) lin >>= 2;
   const int tx = lin % tiles_x; lin /= tiles_x;
   const int ty = lin % tiles_y;
   const int b = lin / tiles_y;
   const int y0 = ty * TH, x0 = tx * TW;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nchunks = (d.C0 + d.C1) / CH, niter = nchunks * 9;
+  const int nchunks = (d.C0 + d.C1) / CH, niter = nchunks * NT;
   const size_t wstep = (size_t)d.CoutPad * 128;
-  const char* wtile = reinterpret_cast<const char*>(L.w_split + (size_t)tn * BN * 64);
+  const char* wtile = UP ? reinterpret_cast<const char*>(L.w_up_split + (size_t)ph * 4 * L.split_kchunks * d.CoutPad * 64 + (size_t)tn * BN * 64)
+                         : reinterpret_cast<const char*>(L.w_split + (size_t)tn * BN * 64);
+  const int Hs = UP ? d.Hin : d.Hout, Ws = UP ? d.Win : d.Wout;   // the image the tiles cover (UP: the source)
 
   if (wave >= 6) {
     // ------------------------------------------------ weight producers ------------------------------------------------
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       wsrc[r] = n * 128 + (((lane & 7) ^ ((n >> 1) & 7)) << 4);
     }
     auto gload_b = [&](int it) {
-      const int c = it / 9, tap = it - 9 * c;
+      const int c = it / NT, tap = it - NT * c;
       const char* p = wtile + (size_t)(tap * L.split_kchunks + c) * wstep;
       char* dst = Bs + ((it & (NS - 1)) * BN + pw * WPW * 8) * 128;
 #pragma unroll
@@ -660,13 +670,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       if (hp < HALO) {
         const int hy = hp / HP, hx = hp - hy * HP;
         int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        if ((unsigned)y < (unsigned)d.Hout && (unsigned)x < (unsigned)d.Wout) {
-          if (d.ups) { y >>= 1; x >>= 1; }
+        if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) {
+          if (!UP && d.ups) { y >>= 1; x >>= 1; }
           hsrc[k] = (b * d.Hin + y) * d.Win + x;
         }
       }
     }
-    float4 g0[NHP], g1[NHP];
+    float4 gA0[NHP], gA1[NHP], gB0[NHP], gB1[NHP];        // (UP: two chunks in flight; otherwise only set A)
+    auto load_chunk_set = [&](int chunk, float4 (&g0)[NHP], float4 (&g1)[NHP]) {
+      const int c = chunk * CH + q * 8;
+      const bool first = c < d.C0;
+      const float* base = first ? L.src0 : L.src1;
+      const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+#pragma unroll
+      for (int k = 0; k < NHP; ++k) {
+        const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
+        g0[k] = p[0];
+        g1[k] = p[1];
+      }
+    };
+    float4 (&g0)[NHP] = gA0;
+    float4 (&g1)[NHP] = gA1;
     auto load_chunk = [&](int chunk) {
       const int c = chunk * CH + q * 8;
       const bool first = c < d.C0;
@@ -689,11 +713,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
         pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
       }
     };
-    auto write_pass = [&](int buf, auto K) {
+    auto write_pass_set = [&](int buf, auto K, const float4 (&h0)[NHP], const float4 (&h1)[NHP]) {
       constexpr int k = decltype(K)::value;
       const int hp = prow + k * 32;
       if (hp < HALO) {
-        float v[8] = {g0[k].x, g0[k].y, g0[k].z, g0[k].w, g1[k].x, g1[k].y, g1[k].z, g1[k].w};
+        float v[8] = {h0[k].x, h0[k].y, h0[k].z, h0[k].w, h1[k].x, h1[k].y, h1[k].z, h1[k].w};
         if (L.pro_a) {
 #pragma unroll
           for (int u = 0; u < 8; ++u) v[u] = silu_fast(fmaf(v[u], pa[u], pb[u]));
@@ -709,6 +733,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
         *reinterpret_cast<uint4*>(p + 64) = vl;
       }
     };
+    auto write_pass = [&](int buf, auto K) { write_pass_set(buf, K, gA0, gA1); };
+    if constexpr (UP) {
+      // Upsample convs have no fused prologue (pro_a is null: checked by the launcher).  Chunk c + 2 is loaded at tap 0 of chunk c
+      // into the register set of its parity, chunk c + 1 (loaded four taps earlier) is converted and written at taps 0-2, two
+      // passes each; tap 3: nothing (the consumers fetch the next chunk's first fragments during it).
+      load_chunk_set(0, gA0, gA1);
+      if (nchunks > 1) load_chunk_set(1, gB0, gB1);
+      write_pass_set(0, IC<0>(), gA0, gA1); write_pass_set(0, IC<1>(), gA0, gA1); write_pass_set(0, IC<2>(), gA0, gA1);
+      write_pass_set(0, IC<3>(), gA0, gA1); write_pass_set(0, IC<4>(), gA0, gA1); write_pass_set(0, IC<5>(), gA0, gA1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      auto chunk_taps = [&](int c, float4 (&n0)[NHP], float4 (&n1)[NHP], float4 (&f0)[NHP], float4 (&f1)[NHP]) {
+        // n = the set holding chunk c + 1 (to be written now), f = the set chunk c held (free: reloaded with chunk c + 2)
+        const bool more = c + 1 < nchunks;
+        const int nb = (c + 1) & 1;
+        if (c + 2 < nchunks) load_chunk_set(c + 2, f0, f1);
+        if (more) { write_pass_set(nb, IC<0>(), n0, n1); write_pass_set(nb, IC<1>(), n0, n1); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // -> barrier(4 c + 1)
+        if (more) { write_pass_set(nb, IC<2>(), n0, n1); write_pass_set(nb, IC<3>(), n0, n1); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // -> barrier(4 c + 2)
+        if (more) { write_pass_set(nb, IC<4>(), n0, n1); write_pass_set(nb, IC<5>(), n0, n1); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // -> barrier(4 c + 3)
+        asm volatile("s_barrier" ::: "memory");                                   // -> barrier(4 c + 4)
+      };
+      for (int c = 0; c < nchunks; c += 2) {
+        chunk_taps(c, gB0, gB1, gA0, gA1);
+        if (c + 1 < nchunks) chunk_taps(c + 1, gA0, gA1, gB0, gB1);
+      }
+      return;
+    }
     pro_load(0);
     load_chunk(0);
     write_pass(0, IC<0>()); write_pass(0, IC<1>()); write_pass(0, IC<2>());
@@ -763,10 +816,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }
   f16x8 fa[2][4], fw[2][4];                              // [k16 step][A: (hi, lo) x row tile | W: (hi, lo) x column tile]
+  const int pho = UP ? (ph >> 1) * RSTRIDE + (ph & 1) * PITCH : 0;   // UP: the phase's 2 x 2 window starts at halo position (dy, dx)
   auto reads = [&](auto ST, auto TAP, int cb, int slot) {
     constexpr int st = decltype(ST)::value, T = decltype(TAP)::value;
-    constexpr int toff = (T / 3) * RSTRIDE + (T % 3) * PITCH;
-    const char* A = Ah + cb * HBYTES + toff + st * 32;
+    constexpr int toff = UP ? (T / 2) * RSTRIDE + (T % 2) * PITCH : (T / 3) * RSTRIDE + (T % 3) * PITCH;
+    const char* A = Ah + cb * HBYTES + toff + st * 32 + pho;
     const char* Bb = Bs + slot * (BN * 128);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -800,7 +854,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 #endif
   auto body = [&](auto TAP, int c) {
     constexpr int T = decltype(TAP)::value;
-    const int it = c * 9 + T;
+    const int it = c * NT + T;
     const bool more = c + 1 < nchunks;
     // barrier #it (tap 0 runs straight after the prologue's barrier #0): weight tiles it, it + 1 are in LDS, tile it - 1's slot
     // is free for the producers, this chunk's halo is complete.  No wait: a consumer's outstanding fragment loads read only
@@ -817,11 +871,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     __builtin_amdgcn_sched_barrier(0);
     mfmas(IC<0>());
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (T < 8) reads(IC<0>(), IC<T + 1>(), c & 1, (it + 1) & (NS - 1));
+    if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), c & 1, (it + 1) & (NS - 1));
     else if (more) reads(IC<0>(), IC<0>(), (c + 1) & 1, (it + 1) & (NS - 1));
     __builtin_amdgcn_sched_barrier(0);
     mfmas(IC<1>());
-    if constexpr (T == 8) {
+    if constexpr (T == NT - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -839,8 +893,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 #endif
   reads(IC<0>(), IC<0>(), 0, 0);
   for (int c = 0; c < nchunks; ++c) {
-    body(IC<0>(), c); body(IC<1>(), c); body(IC<2>(), c); body(IC<3>(), c); body(IC<4>(), c);
-    body(IC<5>(), c); body(IC<6>(), c); body(IC<7>(), c); body(IC<8>(), c);
+    body(IC<0>(), c); body(IC<1>(), c); body(IC<2>(), c); body(IC<3>(), c);
+    if constexpr (!UP) {
+      body(IC<4>(), c); body(IC<5>(), c); body(IC<6>(), c); body(IC<7>(), c); body(IC<8>(), c);
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier(niter): every consumer is done with the LDS images
 #if PRG_SPLIT_EXP == 6
@@ -862,7 +918,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int p = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-          const size_t m = ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+          const size_t m = UP ? ((size_t)b * d.Hout + 2 * (y0 + p / TW) + (ph >> 1)) * d.Wout + 2 * (x0 + p % TW) + (ph & 1)
+                              : ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
           const float v = tot[i][j][e] + bv;
           L.out[m * d.Cout + ch] = v;
           s1 += v;
@@ -1120,6 +1177,22 @@ static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse
   return PRG_OK;
 }
 
+// Upsample conv as four 2 x 2-tap sub-pixel convolutions of the source image (the UP form of the wave-specialised kernel)
+static int launch_split_ws_up(const ConvLaunch<float>& L, hipStream_t s) {
+  constexpr int NS = 4, HB = 10 * ((18 * 144 + 255) / 256 * 256);
+  const ConvDesc& d = L.d;
+  const int tiles_x = d.Win / 16, tiles_y = d.Hin / 8, tiles_n = d.Cout / 128;
+  const size_t lds = (size_t)2 * HB + NS * 128 * 128;
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done.load(std::memory_order_acquire)) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_done.store(true, std::memory_order_release);
+  }
+  conv3x3_split_ws_kernel<NS, true><<<dim3(tiles_x * tiles_y * tiles_n * d.B * 4), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
 static int launch_split_ws(const ConvLaunch<float>& L, hipStream_t s, int fuse_stats, int* nsplit) {
   constexpr int NS = 4, HB = 10 * ((18 * 144 + 255) / 256 * 256);
   const ConvDesc& d = L.d;
@@ -1128,10 +1201,10 @@ static int launch_split_ws(const ConvLaunch<float>& L, hipStream_t s, int fuse_s
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * 2 : 0;
   static std::atomic<bool> attr_done{false};
   if (!attr_done.load(std::memory_order_acquire)) {
-    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_done.store(true, std::memory_order_release);
   }
-  conv3x3_split_ws_kernel<NS><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
+  conv3x3_split_ws_kernel<NS, false><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
   PRG_LAUNCH_CHECK();
 #if PRG_SPLIT_EXP == 6
   {
@@ -1192,6 +1265,15 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
     };
     // Cout % 128 == 0: the wave-specialised kernel (128-pixel x 128-channel tiles, one workgroup per CU); PRG_SPLIT_WS=0: never
     static const int ws_on = [] { const char* e = std::getenv("PRG_SPLIT_WS"); return e ? std::atoi(e) : 1; }();
+    // OFF by default: 2 % of an f16x3 evaluation (0.3 ms), and the same accuracy per evaluation — but every change of the rounding
+    // pattern re-draws the long chains' distance from the reference, and this one moves the 250-step DDIM chain G20 from 5.9e-5 m
+    // to 1.03e-4 m (mean error 3.2e-6 -> 3.4e-6 m): the mode's claim is the literal 1e-4 m on that chain, so the nine-tap form stays
+    static const int up_on = [] { const char* e = std::getenv("PRG_SPLIT_UP2X2"); return e ? std::atoi(e) : 0; }();
+    if (ws_on && up_on && d.ups && L.w_up_split && d.C1 == 0 && d.Cout % 128 == 0 && d.Win % 16 == 0 && d.Hin % 8 == 0 && d.Hout == 2 * d.Hin &&
+        d.Wout == 2 * d.Win && !L.residual && !L.pro_a && !want_stats) {
+      rc = launch_split_ws_up(L, s);
+      return rc ? rc : 1;
+    }
     if (ws_on && d.Cout % 128 == 0 && W % 16 == 0 && H % 8 == 0 && !L.residual) {
       const int tiles = (W / 16) * (H / 8) * 2;
       const int f = want_stats && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 && tiles <= kGnMaxSplit;

@@ -102,6 +102,7 @@ struct ConvP {
   int sp_kchunks = 0;
   int64_t h16_off = -1;    // bf16 mode, second conv of a ResnetBlock: element offset of the f16 twin of the packing (ConvLaunch::w_f16)
   int64_t up_off = -1;     // bf16 mode, Upsample convs: element offset of the four pre-summed 2 x 2-tap packings (ConvLaunch::w_up)
+  int64_t up_sp_off = -1;  // f16x3 mode: the same in the split layout (ConvLaunch::w_up_split)
 };
 struct ResP {
   int cin = 0, cout = 0;
@@ -360,6 +361,7 @@ struct UnetImpl : prg_unet {
     L.w_up = (p.up_off >= 0 && ups && stride == 1 && pad == 1) ? reinterpret_cast<const T*>(d_packed) + p.up_off : nullptr;
     L.s2d_kchunks = p.s2d_kchunks;
     L.w_split = (d_split && p.sp_off >= 0) ? d_split + p.sp_off : nullptr;
+    L.w_up_split = (d_split && p.up_sp_off >= 0 && ups && stride == 1 && pad == 1) ? d_split + p.up_sp_off : nullptr;
     L.split_kchunks = p.sp_kchunks;
     L.gn = o.gn ? *o.gn : GnApply{};
     L.gn_coef_a = o.gn ? o.coef_a : nullptr; L.gn_coef_b = o.gn ? o.coef_b : nullptr;
@@ -1013,6 +1015,23 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
       p->sp_off = (int64_t)((data.size() + 127) / 128 * 128);
       data.resize((size_t)p->sp_off + one.size());
       std::memcpy(data.data() + p->sp_off, one.data(), one.size() * sizeof(uint16_t));
+    }
+    // Upsample convs: the sub-pixel decomposition's four 2 x 2-tap packings (conv_split.hip, UP form of the wave-specialised kernel)
+    for (auto& lv : u->lay.ups) {
+      ConvP* p = &lv.resample;
+      if (!lv.strided || !(p->KH == 3 && p->KW == 3 && p->Cin % 32 == 0 && p->Cout % 128 == 0)) continue;
+      const float* w = weights + p->w_flat;
+      std::vector<float> eq;
+      up_equivalent_weights(w, p->Cout, p->Cin, eq);
+      p->up_sp_off = (int64_t)((data.size() + 127) / 128 * 128);
+      size_t off = (size_t)p->up_sp_off;
+      for (int ph = 0; ph < 4; ++ph) {
+        int cp = 0, kc = 0;
+        pack_conv_weight_split(eq.data() + (size_t)ph * p->Cout * p->Cin * 4, p->Cout, p->Cin, 2, 2, one, &cp, &kc);
+        data.resize(off + one.size());
+        std::memcpy(data.data() + off, one.data(), one.size() * sizeof(uint16_t));
+        off += one.size();
+      }
     }
     if (hipMalloc(&u->d_split, data.size() * sizeof(uint16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split weights)");
     PRG_HIP(hipMemcpy(u->d_split, data.data(), data.size() * sizeof(uint16_t), hipMemcpyHostToDevice));

@@ -94,6 +94,42 @@ def test_unet_dim64_full_size_taps_f16x3(hip, golden, fixture, wseed, B):
     net.close()
 
 
+_UP_SCRIPT = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from pointreggpt_amd import weights as W
+from pointreggpt_amd.unet import Unet
+g = np.load({gold!r})
+net = Unet(64, dtype="f16x3").load_state_dict(W.synth_state_dict(W.unet_config(64), 13))
+y = net(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda(), torch.from_numpy(g["pc"]).cuda())
+np.savez({out!r}, y=y.cpu().numpy())
+"""
+
+
+def test_f16x3_subpixel_upsample_option(tmp_path):
+    """PRG_SPLIT_UP2X2=1 (off by default): the two wide Upsample convs of the f16x3 mode as four 2 x 2-tap sub-pixel
+    convolutions (UP form of the wave-specialised split kernel, pre-summed split weights).  One dim-64 evaluation at 128 x 128
+    against the reference with the option on and off: both inside the mode's per-evaluation bound, and within 1e-5 of each other."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden", "G13_unet_dim64_128.npz")
+    ref = np.load(gold)["y"].astype(np.float64)
+    ys = {}
+    for name, env in {"nine_tap": {}, "subpixel": {"PRG_SPLIT_UP2X2": "1"}}.items():
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", _UP_SCRIPT.format(root=root, gold=gold, out=out)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ys[name] = np.load(out)["y"].astype(np.float64)
+        e = float(np.abs(ys[name] - ref).max())
+        print(f"f16x3 {name}: max err vs reference {e:.3e}")
+        assert e <= 2e-5
+    d = float(np.abs(ys["nine_tap"] - ys["subpixel"]).max())
+    print(f"nine-tap vs sub-pixel form: {d:.3e}")
+    assert 0.0 < d <= 1e-5                                   # (> 0: the option really took the other kernel)
+
+
 @pytest.mark.parametrize("dim", [8, 16])
 def test_unet_small_f16x3(hip, golden, dim):
     """dim 8 / 16 networks (ragged 32-channel chunks, Cout below a tile): every conv on the gather kernel."""
