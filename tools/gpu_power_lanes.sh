@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 for n in 1 2; do
   ( for i in $(seq 1 90); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Package Power|sclk" | tr '\n' ' '; echo; sleep 0.5; done ) > gpurun_out/r3_power_trace_$n.txt &
   SAMP=$!
-  python bench.py --steps 6 --warmup 2 --streams $n --no-cpu-baseline --no-e2e-files --no-drift --no-configs4 --no-roofline > gpurun_out/r3_power_bench_$n.json 2>/dev/null
+  python bench.py --steps 6 --warmup 2 --streams $n --no-cpu-baseline --no-e2e-files --no-drift --no-configs4 --no-roofline --no-parity-mode > gpurun_out/r3_power_bench_$n.json 2>/dev/null
   kill $SAMP 2>/dev/null; wait $SAMP 2>/dev/null
 done
 python - <<'PY'
