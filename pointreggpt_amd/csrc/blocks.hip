@@ -442,8 +442,11 @@ int launch_affine_silu_fold(const bf16_t* x, const GnFold& f, const bf16_t* resi
   PRG_CHECK(f.acc && f.P && f.Q && C % 8 == 0 && C <= 1024 && f.G * f.cpg == C, "affine_silu_fold: bad arguments");
   const int nvc = C / 8;
   const int64_t per_img = (int64_t)HW * nvc;
-  // ~4096 vectors (64 KB in, 64 KB out) per block, at least one block per image, at most 16384 blocks in all
-  int64_t bpi = (per_img + 4095) / 4096;
+  // ~4096 vectors (64 KB in, 64 KB out) per block, at least one block per image, at most 16384 blocks in all; small tensors (the
+  // 32x32 and 16x16 levels at B = 64: 128-256 blocks of four serial iterations, 13 us for 25-50 MB) take 1024-vector blocks: one
+  // iteration per thread, 512-1024 blocks
+  const int64_t vpb = per_img * B < ((int64_t)2 << 20) ? 1024 : 4096;
+  int64_t bpi = (per_img + vpb - 1) / vpb;
   if (bpi * B > 16384) bpi = 16384 / B > 0 ? 16384 / B : 1;
   if (bpi < 1) bpi = 1;
   affine_silu_fold_kernel<<<dim3((int)bpi, B), 256, 0, s>>>(x, f, residual, out, per_img, nvc, C);
