@@ -7,7 +7,7 @@ writes ./<dataset_name>/data/scene-XXXXXX/{sample-000000.cloud.ply, sample-00000
 sample-*.pose.txt, *.png}.  The hot path runs on the MI355X HIP library.  Additive flags (defaults = the reference's
 hard-coded literals, generate_dataset.py:32-55):
   --image_size 256  --timesteps 1000  --sampling_timesteps 250  --batch_size 4  --dim 64
-  --dtype fp32|f16x3|bf16|mxfp8   f16x3 = float32 storage, split-f16 MFMA contractions: the parity tolerance at 3x the speed; fp32 (default: the reference runs with amp=False, generate_dataset.py:54) is the parity mode;
+  --dtype fp32|f16x3|bf16|mxfp8   f16x3 = float32 storage, split-f16 MFMA contractions: inside 1e-4 m of the reference on the committed reference chains (measured per chain, not guaranteed) at ~4x fp32's speed; fp32 (default: the reference runs with amp=False, generate_dataset.py:54) is the parity mode;
                             bf16 = BASELINE configs[1-3] throughput mode; mxfp8 = configs[4] (3x3 convs on block-scaled fp8 MFMA)
   --data_root /path/to/3DMatch-RGBD/train
   --streams 2         lanes per GPU: batches are dealt round-robin to N host threads / HIP streams with their own network
@@ -38,7 +38,10 @@ def main():
     p.add_argument("--batch_size", default=4, type=int)
     p.add_argument("--dim", default=64, type=int)
     p.add_argument("--dtype", default="fp32", choices=["fp32", "f16x3", "bf16", "mxfp8"],
-                   help="arithmetic of the two U-Nets: fp32 = parity mode (the reference's amp=False), bf16 / mxfp8 = throughput modes")
+                   help="arithmetic of the two U-Nets: fp32 = parity mode (the reference's amp=False; the only mode LABELLED parity); "
+                        "f16x3 = float32 storage, split-f16 MFMA contractions: within 1e-4 m point-XYZ of the reference on every "
+                        "calibrated reference chain of tests/golden (64x64 .. 256x256; measured values: tests/test_gpu_f16x3.py, "
+                        "bench.py drift_vs_reference) at ~4x fp32's throughput; bf16 / mxfp8 = throughput modes, centimetres away")
     p.add_argument("--streams", default=2, type=int,
                    help="concurrent lanes per GPU (own network handles + HIP stream + host thread each; batches dealt round-robin)")
     p.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
@@ -100,9 +103,9 @@ def main():
                                         sampling_timesteps=args.sampling_timesteps, loss_type="l1", objective="pred_x0",
                                         beta_schedule="sigmoid", ddim_sampling_eta=1.0, is_ddnm_sampling=True), m2))
     if args.noise_seed is None:
-        # ONE seed for the whole job: every rank derives it from the launcher's run id (torchrun exports the same
-        # TORCHELASTIC_RUN_ID / MASTER_PORT to all ranks), so a multi-rank run is reproducible from the one logged value and a
-        # scene's noise key does not depend on the shard that produced it
+        # ONE seed for the whole job: rank 0 draws it (secrets.randbits) and publishes it to every rank through a c10d store on
+        # MASTER_ADDR:MASTER_PORT (sharding.job_seed), so a multi-rank run is reproducible from the one logged value (--noise_seed /
+        # PRG_JOB_SEED replay it) and a scene's noise key does not depend on the shard that produced it
         args.noise_seed = sharding.job_seed() if args.synthetic is None else int(args.synthetic)
     print("[rank {}/{}] noise seed: {}  scenes [{}, {})".format(rank, world, args.noise_seed, start, stop))
     if stop > start:

@@ -89,6 +89,10 @@ struct ConvLaunch {
   // f16x3, Upsample convs: the four sub-pixel 2 x 2-tap packings (up_equivalent_weights) in the split layout, phase-major:
   // [phase][tap 4][32-channel chunk][CoutPad][32 hi | 32 lo]; null = the nine-tap gather form
   const uint16_t* w_up_split = nullptr;
+  // f16x3: [CoutPad] (w_split) / [4][CoutPad] (w_up_split, phase-major) exact power-of-two factors applied to the float32 totals
+  // before the bias (the packer scaled every output channel's weights by the inverse); null = 1
+  const float* split_scale = nullptr;
+  const float* split_scale_up = nullptr;
   // h16 (bf16 mode, round 4): the tensor between the two convs of a ResnetBlock only ever feeds conv2's fused GroupNorm + SiLU
   // prologue, so it is stored as IEEE f16 instead of bf16 — the prologue then runs in PACKED f16 (v_pk_fma_f16, v_exp_f16,
   // v_rcp_f16: two channels per instruction, no unpack / repack) and conv2 contracts f16 operands
@@ -155,8 +159,10 @@ void pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int KH, int KW
 bool conv_h16_pair_ok(const ConvLaunch<bf16_t>& L1, const ConvLaunch<bf16_t>& L2);
 
 // hi / lo f16 split of a conv weight for the f16x3 mode (layout at ConvLaunch::w_split)
+// oscale (may be null = no scaling): receives [CoutPad] exact powers of two the kernels multiply the float32 totals by — the
+// inverse of the per-output-channel scale the packer applied so that the lo halves stay normal f16 (ConvLaunch::split_scale)
 void pack_conv_weight_split(const float* w_oihw, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out, int* CoutPad,
-                            int* kchunks32);
+                            int* kchunks32, std::vector<float>* oscale = nullptr);
 // f16x3 kernels: 1 = launched, 0 = shape not covered (the exact-f32 kernels run), < 0 = error
 int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsplit_out);
 

@@ -479,6 +479,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   L.out[(size_t)row_to_m(l31) * d.Cout + tn * BN + hi] = sum;
   return;
 #endif
+  if (L.split_scale) {                         // undo the packer's per-channel power-of-two weight scale (exact)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float sc = L.split_scale[tn * BN + j * 32 + l31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tot[j][e] *= sc;
+    }
+  }
 #if PRG_SPLIT_EPI == 0
   f32x16 res[1][2] = {{tot[0], tot[1]}};
   epilogue_store<float, 1, decltype(row_to_m), true>(L, res, stage + wave * 32 * 68, lane, tn * BN, row_to_m, gs, gq);
@@ -912,6 +920,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     for (int j = 0; j < 2; ++j) {
       const int ch = tn * BN + wn * 64 + j * 32 + l31;
       const float bv = L.bias ? L.bias[ch] : 0.0f;
+      const float* scp = UP ? L.split_scale_up : L.split_scale;            // the packer's per-channel power of two, undone (exact)
+      const float sc = scp ? scp[(UP ? ph * d.CoutPad : 0) + ch] : 1.0f;
       float s1 = 0.0f, q1 = 0.0f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
           const int p = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
           const size_t m = UP ? ((size_t)b * d.Hout + 2 * (y0 + p / TW) + (ph >> 1)) * d.Wout + 2 * (x0 + p % TW) + (ph & 1)
                               : ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
-          const float v = tot[i][j][e] + bv;
+          const float v = tot[i][j][e] * sc + bv;
           L.out[m * d.Cout + ch] = v;
           s1 += v;
           q1 = fmaf(v, v, q1);
@@ -1128,6 +1138,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
     const int m = tm * BM + wm * WM + r;
     return m < M ? (int64_t)m : (int64_t)-1;
   };
+  if (L.split_scale) {                         // undo the packer's per-channel power-of-two weight scale (exact)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float sc = L.split_scale[tn * BN + wn * 64 + j * 32 + l31];      // [CoutPad]: padded columns read 1
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[i][j][e] *= sc;
+    }
+  }
   epilogue_store<float, TM>(L, tot, stage + wave * 32 * 68, lane, tn * BN + wn * 64, row_to_m, gs, gq);
   if (fuse_stats) {
     const int nsplit = HWo / BM;
@@ -1251,6 +1271,14 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
   // the activated residual (ConvLaunch::res_a: the ResnetBlock tail in a 1x1 res_conv's epilogue) is the shared transposing
   // epilogue's feature: the gather kernel below has it, the 3x3 kernels do not
   if (L.res_a && !(d.KH == 1 && d.KW == 1)) return 0;
+  // precision budget (tools/gpu_r5_precision.sh): PRG_SPLIT_EXACT is a bit mask of convolution classes handed back to the exact-f32
+  // kernels — 1: 3x3 / s1 (Block.proj, the last down conv, the top level's "Upsample"), 2: 1x1 (res_conv, attention projections of
+  // the unfused blocks), 4: 4x4 / s2 (Downsample), 8: 3x3 on the upsampled image (Upsample).  0 (default) = every class split.
+  static const int exact_mask = [] { const char* e = std::getenv("PRG_SPLIT_EXACT"); return e ? std::atoi(e) : 0; }();
+  if (exact_mask && !L.probe) {
+    const int cls = d.KH == 1 ? 2 : d.KH == 4 ? 4 : d.ups ? 8 : 1;
+    if (exact_mask & cls) return 0;
+  }
   const int64_t M64 = (int64_t)d.B * d.Hout * d.Wout;
   if ((int64_t)d.B * d.Hin * d.Win >= ((int64_t)1 << 31) || M64 >= ((int64_t)1 << 31)) return 0;
   const int M = (int)M64;
@@ -1298,10 +1326,34 @@ static inline uint16_t f16_bits(_Float16 h) {
   std::memcpy(&u, &h, 2);
   return u;
 }
-void pack_conv_weight_split(const float* w, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out, int* CoutPad, int* kchunks32) {
+void pack_conv_weight_split(const float* w, int Cout, int Cin, int KH, int KW, std::vector<uint16_t>& out, int* CoutPad, int* kchunks32,
+                            std::vector<float>* oscale) {
   const int cp = (Cout + 63) / 64 * 64;
   const int kcn = (Cin + 31) / 32;
   out.assign((size_t)KH * KW * kcn * cp * 64, 0);
+  if (oscale) oscale->assign((size_t)cp, 1.0f);
+  // Round 5: |a - hi - lo| <= 2^-22 |a| only holds while the lo half is a NORMAL f16; below |a| ~ 2^-3 it is
+  // subnormal with an absolute floor of 2^-25, so unstandardised weights of ~1 / sqrt(fan_in) (res_conv, Downsample, Upsample:
+  // 0.02-0.1) kept 18-20 bits.  Each output channel's weights are therefore multiplied by an exact power of two that brings
+  // max|w| into [2^9, 2^10) (hi exact to 2^-2, lo's 2^-25 floor = 2^-35 of the maximum; |w| < 2^10 stays far from f16's 65504
+  // with O(100) activations in the other operand being a float32-accumulated product), and the kernels multiply the float32
+  // total by the inverse (exact) before the bias: split_scale.
+  static const int wscale_on = [] { const char* e = std::getenv("PRG_SPLIT_WSCALE"); return e ? std::atoi(e) : 1; }();
+  std::vector<float> mul((size_t)Cout, 1.0f);
+  if (oscale && wscale_on) {
+    const size_t per = (size_t)Cin * KH * KW;
+    for (int n = 0; n < Cout; ++n) {
+      float m = 0.0f;
+      for (size_t i = 0; i < per; ++i) m = std::fmax(m, std::fabs(w[(size_t)n * per + i]));
+      if (m > 0.0f && std::isfinite(m)) {
+        int e = 0;
+        (void)std::frexp(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+        const int k = 10 - e;                    // m * 2^k in [2^9, 2^10)
+        mul[n] = std::ldexp(1.0f, k);
+        (*oscale)[n] = std::ldexp(1.0f, -k);
+      }
+    }
+  }
   for (int kh = 0; kh < KH; ++kh)
     for (int kw = 0; kw < KW; ++kw)
       for (int kc = 0; kc < kcn; ++kc)
@@ -1309,7 +1361,7 @@ void pack_conv_weight_split(const float* w, int Cout, int Cin, int KH, int KW, s
           for (int k = 0; k < 32; ++k) {
             const int c = kc * 32 + k;
             if (c >= Cin) break;
-            const float v = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw];
+            const float v = w[(((size_t)n * Cin + c) * KH + kh) * KW + kw] * mul[n];
             const _Float16 h = (_Float16)v;                       // round to nearest even (compiler-rt / F16C)
             const _Float16 l = (_Float16)(v - (float)h);
             const size_t row = ((((size_t)(kh * KW + kw)) * kcn + kc) * cp + n) * 64;

@@ -102,6 +102,7 @@ struct ConvP {
   int sp_kchunks = 0;
   int64_t h16_off = -1;    // bf16 mode, second conv of a ResnetBlock: element offset of the f16 twin of the packing (ConvLaunch::w_f16)
   int64_t up_off = -1;     // bf16 mode, Upsample convs: element offset of the four pre-summed 2 x 2-tap packings (ConvLaunch::w_up)
+  int64_t sp_scale_off = -1, up_sp_scale_off = -1;   // f16x3 mode: offsets into d_split_scale (ConvLaunch::split_scale / split_scale_up)
   int64_t up_sp_off = -1;  // f16x3 mode: the same in the split layout (ConvLaunch::w_up_split)
 };
 struct ResP {
@@ -275,6 +276,7 @@ struct prg_unet {
   uint8_t* d_mx = nullptr;      // MX-fp8 conv weights (dtype PRG_MXFP8): e4m3 data and E8M0 block scales
   uint8_t* d_mx_scale = nullptr;
   uint16_t* d_attn_split = nullptr;   // f16x3 mode: fused linear attention weights as f16 hi / lo halves (attn_split.hip)
+  float* d_split_scale = nullptr;   // f16x3 mode: the packer's per-output-channel power-of-two factors, undone in the epilogues
   uint16_t* d_split = nullptr;  // f16x3 mode (dtype PRG_F16X3): every conv weight as f16 hi / lo halves (conv_split.hip)
   uint16_t* d_h16 = nullptr;    // bf16 mode: f16 twins of the ResnetBlocks' second convs (the h16 format, conv.h)
   float* d_freqs = nullptr;     // SinusoidalPosEmb frequencies [dim/2] (sd:645-657), see prg_unet_set_time_freqs
@@ -363,6 +365,8 @@ struct UnetImpl : prg_unet {
     L.w_split = (d_split && p.sp_off >= 0) ? d_split + p.sp_off : nullptr;
     L.w_up_split = (d_split && p.up_sp_off >= 0 && ups && stride == 1 && pad == 1) ? d_split + p.up_sp_off : nullptr;
     L.split_kchunks = p.sp_kchunks;
+    L.split_scale = (L.w_split && d_split_scale && p.sp_scale_off >= 0) ? d_split_scale + p.sp_scale_off : nullptr;
+    L.split_scale_up = (L.w_up_split && d_split_scale && p.up_sp_scale_off >= 0) ? d_split_scale + p.up_sp_scale_off : nullptr;
     L.gn = o.gn ? *o.gn : GnApply{};
     L.gn_coef_a = o.gn ? o.coef_a : nullptr; L.gn_coef_b = o.gn ? o.coef_b : nullptr;
     L.gn_tickets = (o.gn && gn_fold_enabled()) ? d_tickets : nullptr;
@@ -1006,33 +1010,42 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
     std::vector<ConvP*> convs;
     collect_convs(u->lay, convs);
     std::vector<uint16_t> data, one;
-    std::vector<float> tmp;
+    std::vector<float> tmp, scales, sc1;
     for (ConvP* p : convs) {
       const float* w = weights + p->w_flat;
       if (p->ws) { standardize(w, p->Cout, p->Cin * p->KH * p->KW, tmp); w = tmp.data(); }
       int cp = 0;
-      pack_conv_weight_split(w, p->Cout, p->Cin, p->KH, p->KW, one, &cp, &p->sp_kchunks);
+      pack_conv_weight_split(w, p->Cout, p->Cin, p->KH, p->KW, one, &cp, &p->sp_kchunks, &sc1);
       p->sp_off = (int64_t)((data.size() + 127) / 128 * 128);
       data.resize((size_t)p->sp_off + one.size());
       std::memcpy(data.data() + p->sp_off, one.data(), one.size() * sizeof(uint16_t));
+      p->sp_scale_off = (int64_t)scales.size();
+      scales.insert(scales.end(), sc1.begin(), sc1.end());
     }
     // Upsample convs: the sub-pixel decomposition's four 2 x 2-tap packings (conv_split.hip, UP form of the wave-specialised kernel)
+    // (built only when the option is on — it is off by default, conv_split.hip: try_launch_conv_split — ADVICE round 4)
+    static const int split_up_on = [] { const char* e = std::getenv("PRG_SPLIT_UP2X2"); return e ? std::atoi(e) : 0; }();
     for (auto& lv : u->lay.ups) {
       ConvP* p = &lv.resample;
-      if (!lv.strided || !(p->KH == 3 && p->KW == 3 && p->Cin % 32 == 0 && p->Cout % 128 == 0)) continue;
+      if (!split_up_on || !lv.strided || !(p->KH == 3 && p->KW == 3 && p->Cin % 32 == 0 && p->Cout % 128 == 0)) continue;
       const float* w = weights + p->w_flat;
+      if (p->ws) { standardize(w, p->Cout, p->Cin * p->KH * p->KW, tmp); w = tmp.data(); }   // (as the bf16 twin in pack_all; no Upsample conv is)
       std::vector<float> eq;
       up_equivalent_weights(w, p->Cout, p->Cin, eq);
       p->up_sp_off = (int64_t)((data.size() + 127) / 128 * 128);
+      p->up_sp_scale_off = (int64_t)scales.size();
       size_t off = (size_t)p->up_sp_off;
       for (int ph = 0; ph < 4; ++ph) {
         int cp = 0, kc = 0;
-        pack_conv_weight_split(eq.data() + (size_t)ph * p->Cout * p->Cin * 4, p->Cout, p->Cin, 2, 2, one, &cp, &kc);
+        pack_conv_weight_split(eq.data() + (size_t)ph * p->Cout * p->Cin * 4, p->Cout, p->Cin, 2, 2, one, &cp, &kc, &sc1);
         data.resize(off + one.size());
         std::memcpy(data.data() + off, one.data(), one.size() * sizeof(uint16_t));
         off += one.size();
+        scales.insert(scales.end(), sc1.begin(), sc1.end());     // [phase][CoutPad]
       }
     }
+    if (hipMalloc(&u->d_split_scale, scales.size() * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split scales)");
+    PRG_HIP(hipMemcpy(u->d_split_scale, scales.data(), scales.size() * sizeof(float), hipMemcpyHostToDevice));
     if (hipMalloc(&u->d_split, data.size() * sizeof(uint16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split weights)");
     PRG_HIP(hipMemcpy(u->d_split, data.data(), data.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     // fused linear attention (attn_split.hip): to_qkv with the PreNorm gain folded in (q and k rows times log2 e: both only ever
@@ -1342,6 +1355,7 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_mx) (void)hipFree(h->d_mx);
   if (h->d_mx_scale) (void)hipFree(h->d_mx_scale);
   if (h->d_split) (void)hipFree(h->d_split);
+  if (h->d_split_scale) (void)hipFree(h->d_split_scale);
   if (h->d_h16) (void)hipFree(h->d_h16);
   if (h->d_attn_split) (void)hipFree(h->d_attn_split);
   if (h->d_tickets) (void)hipFree(h->d_tickets);
@@ -1428,19 +1442,21 @@ static int debug_conv_f32(const float* x, const float* w, const float* bias, flo
   std::vector<uint16_t> sp;
   int cp = 0, kc = 0, cp2 = 0, kc32 = 0;
   pack_conv_weight<float>(w, Cout, Cin, K, K, packed, &cp, &kc);
-  if (dtype == PRG_F16X3) pack_conv_weight_split(w, Cout, Cin, K, K, sp, &cp2, &kc32);
+  std::vector<float> spsc;
+  if (dtype == PRG_F16X3) pack_conv_weight_split(w, Cout, Cin, K, K, sp, &cp2, &kc32, &spsc);
   std::vector<float> zb(Cout, 0.0f);
-  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_sp = nullptr;
-  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_sp}) if (p) (void)hipFree(p); };
+  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_sp = nullptr, *d_sc = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_sp, d_sc}) if (p) (void)hipFree(p); };
   if (hipMalloc(&d_in, M * Cin * 4) != hipSuccess || hipMalloc(&d_out, Mo * Cout * 4) != hipSuccess ||
       hipMalloc(&d_w, packed.size() * 4) != hipSuccess || hipMalloc(&d_b, Cout * 4) != hipSuccess ||
-      (!sp.empty() && hipMalloc(&d_sp, sp.size() * 2) != hipSuccess)) {
+      (!sp.empty() && (hipMalloc(&d_sp, sp.size() * 2) != hipSuccess || hipMalloc(&d_sc, spsc.size() * 4) != hipSuccess))) {
     cleanup();
     return fail(PRG_E_NOMEM, "prg_debug_conv: hipMalloc failed");
   }
   if (hipMemcpy(d_w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d_b, bias ? bias : zb.data(), Cout * 4, hipMemcpyHostToDevice) != hipSuccess ||
-      (d_sp && hipMemcpy(d_sp, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) != hipSuccess)) {
+      (d_sp && (hipMemcpy(d_sp, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_sc, spsc.data(), spsc.size() * 4, hipMemcpyHostToDevice) != hipSuccess))) {
     cleanup();
     return fail(PRG_E_HIP, "prg_debug_conv: hipMemcpy failed");
   }
@@ -1453,6 +1469,7 @@ static int debug_conv_f32(const float* x, const float* w, const float* bias, flo
     L.bias = reinterpret_cast<const float*>(d_b); L.out = reinterpret_cast<float*>(d_out);
     L.gn_groups = 8;
     L.w_split = reinterpret_cast<const uint16_t*>(d_sp); L.split_kchunks = kc32;
+    L.split_scale = reinterpret_cast<const float*>(d_sc);
     rc = launch_conv<float>(L, s, nullptr);
   }
   if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<float>(reinterpret_cast<const float*>(d_out), out, B, Ho * Wo, Cout, s);

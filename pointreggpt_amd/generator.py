@@ -113,7 +113,7 @@ class Generator:
     @torch.no_grad()
     def generate(self, start_scene_index, stop_scene_index, num_samples, memory_voxel_size=0.002,
                  save_voxel_size=0.025, has_refine_step=False, depth_correction=None, mask_threshold=0.99,
-                 noise_seed: int = 0, progress: bool = False, writer_threads: int = 0, stats: Optional[dict] = None,
+                 noise_seed: Optional[int] = None, progress: bool = False, writer_threads: int = 0, stats: Optional[dict] = None,
                  seed_poses: Optional[bool] = None, lanes: Optional[list] = None):
         """Same sequence as sd:2363-2694.  File output is asynchronous: every batch's clouds / images / text files are
         handed to the library's C++ writer pool (crop, voxel grid, PLY / PNG encoding on worker threads) and are
@@ -128,9 +128,11 @@ class Generator:
         at B = 64, 128x128).  A scene's files do not depend on the lane that produced it.
         ``seed_poses`` (real-data input only): draw the poses from a local legacy stream per (job seed, batch, sample) so that
         a run can be re-sharded / resumed reproducibly; False = numpy's global stream like the reference (single lane only).
-        Default: True when the caller passes a `noise_seed`, False (the reference's unseeded behaviour) otherwise."""
+        Default: True when the caller passes a `noise_seed` (ANY value, 0 included: `None` is the "no seed" sentinel) or lanes,
+        False (the reference's unseeded behaviour) otherwise."""
         if seed_poses is None:
-            seed_poses = noise_seed != 0 or lanes is not None and len(lanes) > 0
+            seed_poses = noise_seed is not None or (lanes is not None and len(lanes) > 0)
+        noise_seed = 0 if noise_seed is None else int(noise_seed)
         info_train = None
         if self.synthetic_seed is None:
             with open("./dataset/indoor/metadata/train_info.pkl", "rb") as f:

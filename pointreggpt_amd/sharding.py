@@ -51,17 +51,36 @@ def job_seed(timeout_s: float = 120.0) -> int:
     host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT")
     if not port:
         raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: pass --noise_seed (or PRG_JOB_SEED) so that all ranks agree on one seed")
-    store = dist.TCPStore(host, int(port), world, is_master=(rank == 0), timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
+    store = None
     if rank == 0:
-        store.set("prg_job_seed", str(secrets.randbits(63)))
-    seed = int(store.get("prg_job_seed").decode())
-    store.add("prg_job_seed_readers", 1)
+        try:
+            store = dist.TCPStore(host, int(port), world, is_master=True, timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
+        except RuntimeError:       # (DistNetworkError, EADDRINUSE) the port is already served — torchrun's agent store: be its client
+            store = None
+    if store is None:
+        store = dist.TCPStore(host, int(port), world, is_master=False, timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
+    # Under torchrun (torch >= 2.x, use_agent_store) MASTER_PORT is the AGENT's store, which outlives worker restarts: rank 0's
+    # bind then fails quietly and every rank is a client of a store that may still hold the previous attempt's keys (ADVICE
+    # round 4).  Both keys are therefore namespaced per attempt, and rank 0 publishes with compare_set so that a key that
+    # already exists (a stale attempt with the same restart count cannot, a second job_seed() call in this process can) is
+    # never half-overwritten: every rank — rank 0 included — returns the value the store holds.
+    attempt = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    key = f"prg_job_seed/{run}/{attempt}/{_job_seed_calls[0]}"
+    _job_seed_calls[0] += 1
+    if rank == 0:
+        store.compare_set(key, "", str(secrets.randbits(63)))
+    seed = int(store.get(key).decode())
+    store.add(key + "/readers", 1)
     if rank == 0:                      # keep the store alive until every rank has read it
         import time
         t0 = time.time()
-        while int(store.add("prg_job_seed_readers", 0)) < world and time.time() - t0 < timeout_s:
+        while int(store.add(key + "/readers", 0)) < world and time.time() - t0 < timeout_s:
             time.sleep(0.01)
     return seed
+
+
+_job_seed_calls = [0]      # job_seed() calls in this process (all ranks call it the same number of times)
 
 
 def batch_pose_seed(job_seed_value: int, first_scene_index: int, sample_index: int) -> int:
@@ -70,3 +89,85 @@ def batch_pose_seed(job_seed_value: int, first_scene_index: int, sample_index: i
     import numpy as np
     return int(np.random.SeedSequence([int(job_seed_value) & 0xFFFFFFFFFFFFFFFF, int(first_scene_index),
                                        int(sample_index), 0x706F7365]).generate_state(1, np.uint32)[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU placement of a rank (round 5, SURVEY 8e: the >= 0.97 scaling target is lost on the HOST side, not on the interconnect)
+# ---------------------------------------------------------------------------------------------------------------------
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def gpu_local_cpus(device_index: int) -> Tuple[List[int], int]:
+    """(CPUs of the NUMA node the GPU hangs off, that node's id) from sysfs — `/sys/bus/pci/devices/<bdf>/local_cpulist` and
+    `numa_node` of the HIP device's PCI function — or ([], -1) when the topology is not exposed (containers, single-node hosts
+    report numa_node = -1 and the full CPU list)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = _parse_cpulist(open(base + "/local_cpulist").read())
+        return cpus, node
+    except Exception:      # noqa: BLE001 — placement is best effort; the caller falls back to an even split
+        return [], -1
+
+
+def rank_cpu_set(local_rank: int, local_world: int, allowed: List[int], gpu_cpus: List[int], peers_on_node: int | None = None,
+                 index_on_node: int | None = None) -> List[int]:
+    """The CPUs rank `local_rank` of `local_world` should run on: the GPU's NUMA-local CPUs (those the process may use), cut
+    evenly among the `peers_on_node` ranks whose GPUs share that node (index_on_node = this rank's position among them); without
+    topology, an even contiguous cut of the allowed set.  Pure function (tested on CPU)."""
+    allowed = sorted(allowed)
+    local = [c for c in allowed if c in set(gpu_cpus)]
+    if local and peers_on_node and index_on_node is not None and len(local) >= peers_on_node:
+        pool, k, n = local, index_on_node, peers_on_node
+    else:
+        pool, k, n = allowed, local_rank, max(1, local_world)
+    if len(pool) < n:                # fewer CPUs than ranks: share everything
+        return pool
+    q, r = divmod(len(pool), n)
+    lo = k * q + min(k, r)
+    return pool[lo:lo + q + (1 if k < r else 0)]
+
+
+def pin_rank_cpus(local_rank: int, local_world: int, device_index: int | None = None) -> dict:
+    """Pin THIS process (and every thread it starts afterwards: the lane threads, the C++ writer pool) to its share of the host:
+    the cores of the NUMA node its GPU is attached to, divided among the ranks on that node.  One rank issues ~1000 graph
+    launches per batch from each lane thread and runs cpu_count / world / 2 writer threads; unpinned, eight ranks' threads
+    migrate across both sockets of a 2-socket host.  `PRG_NO_AFFINITY=1` opts out; a single rank is left alone.
+    Returns what was done (bench.py prints it)."""
+    info = {"pinned": False}
+    if os.environ.get("PRG_NO_AFFINITY", "0") not in ("", "0") or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        info["reason"] = "PRG_NO_AFFINITY" if os.environ.get("PRG_NO_AFFINITY", "0") not in ("", "0") else "single rank"
+        return info
+    allowed = sorted(os.sched_getaffinity(0))
+    dev = local_rank if device_index is None else device_index
+    gpu_cpus, node = gpu_local_cpus(dev)
+    peers = idx = None
+    if gpu_cpus and node >= 0:
+        # ranks are one per GPU in device order: count the devices on this GPU's node to find this rank's share of it
+        try:
+            import torch
+            nodes = [gpu_local_cpus(d)[1] for d in range(min(local_world, torch.cuda.device_count()))]
+            same = [d for d, nd in enumerate(nodes) if nd == node]
+            if dev in same:
+                peers, idx = len(same), same.index(dev)
+        except Exception:      # noqa: BLE001
+            peers = idx = None
+    cpus = rank_cpu_set(local_rank, local_world, allowed, gpu_cpus, peers, idx)
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+        info.update(pinned=True, cpus=len(cpus), first_cpu=cpus[0], last_cpu=cpus[-1], numa_node=node,
+                    source="sysfs local_cpulist" if peers else "even split of the allowed CPUs")
+    return info

@@ -159,14 +159,20 @@ def test_chain8_dim64_128_f16x3(hip, golden):
 LONG = ["G19_chain1000_ancestral_64", "G20_ddim250_128", "G21_ddim250_256", "G21b_ddim250_256", "G22_chain1000_ancestral_128"]
 
 
-@pytest.mark.parametrize("name", LONG)
-def test_long_chain_f16x3_north_star(hip, golden, name):
+# (fixture, batch): every chain at 8 replicated slots, and — round 5 — the two benchmarked launch shapes at their FULL batch
+# (G22 = the headline chain at B = 64, G21b = the shipped 256 x 256 / 250-step DDIM setting at B = 16), so that a batch-keyed f16x3
+# kernel (the persistent 64-channel kernel only takes launches that fill the chip) is covered where bench.py times it
+LONG_CASES = [(n, 8) for n in LONG] + [("G22_chain1000_ancestral_128", 64), ("G21b_ddim250_256", 16)]
+
+
+@pytest.mark.parametrize("name,batch", LONG_CASES)
+def test_long_chain_f16x3_north_star(hip, golden, name, batch):
     """The intermediate mode on the reference's own chains of real length, at the batch the benchmark launches (the scene
-    replicated; every slot must agree bit for bit): the north-star tolerance, literally."""
+    replicated; every slot must agree bit for bit — `_run_long_chain` asserts it): the north-star tolerance, literally."""
     from conftest import GOLDEN, LONG_CHAINS
     if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
         pytest.skip("fixture not generated yet")
-    nb = min(8, LONG_CHAINS[name]["batch"])
+    nb = min(batch, LONG_CHAINS[name]["batch"])
     g, rep, img = _run_long_chain(hip, golden, name, "f16x3", batch=nb)
     spread = float(g["xyz_spread_1_vs_8_threads_m"])
     print(f"{name} f16x3 (B={nb}): point-XYZ L-inf vs reference {rep['xyz_linf_m']:.3e} m (north star 1e-4 m; reference 1-vs-8 threads "
@@ -174,15 +180,40 @@ def test_long_chain_f16x3_north_star(hip, golden, name):
           f"mean {rep['depth_mean_m']:.3e} m; |hip - exact|max {maxerr(torch.from_numpy(img), g['sampled_exact']) * 10:.3e} m; "
           f"saturated {rep['saturated_fraction']:.4f}")
     assert rep["same_valid_mask"] and rep["points"][0] == rep["points"][1]
-    if name == "G21b_ddim250_256":
-        # The 250-step DDIM chain at 256x256 is the one chain where 22-bit operands show: 1.7e-4 m (fp32 mode 3.6e-5 m; the
-        # reference itself sits 6.2e-5 m from its float64 twin and moves by 4.7e-5 m between 1 and 8 threads).  An exact SiLU in the
-        # prologue does not change it (1.69e-4 -> 1.75e-4, A/B'd): it is the contraction's operand precision.  Mean 2.5e-6 m.
-        assert rep["xyz_linf_m"] <= 2.5e-4 and rep["depth_mean_m"] <= 1e-5, rep
-    elif name != "G21_ddim250_256":
-        assert rep["xyz_linf_m"] <= 1e-4, rep          # G19 5.4e-6, G20 6.6e-5, G22 (the headline chain) 8.7e-6 m
+    if name != "G21_ddim250_256":
+        # Round 5: literal on every calibrated chain, the 256 x 256 one included.  Round 4 stood at 1.6-1.7e-4 m on G21b: the lo
+        # halves of the UNSTANDARDISED weights (res_conv, Downsample, Upsample: |w| ~ 1 / sqrt(fan_in) < 2^-3) were subnormal f16
+        # and kept 18-20 bits instead of 22; the packer now scales every output channel by an exact power of two (conv_split.hip,
+        # PRG_SPLIT_WSCALE) and the mean in-painted error halved on every chain (G21b 2.5e-6 -> 1.26e-6 m, the exact-f32 kernels:
+        # 1.1e-6).  Observed: G19 4.5e-6, G20 3.3e-5, G21b 5.7e-5, G22 7.5e-6 m.
+        assert rep["xyz_linf_m"] <= 1e-4, rep
+        assert rep["depth_mean_m"] <= 5e-6, rep
     else:
         # G21 (seed-21 weights at 256x256): 16.6 % of the REFERENCE's own in-painted pixels end on the clamp and the reference sits
         # 4.3e-4 m from its float64 twin — a pixel that saturates in one evaluation order and not in the other moves by millimetres
         # (observed here: max 3.2e-3 m on a handful of pixels, mean 1.1e-5 m, median 3.3e-6 m).  Bounded in the stable statistics.
         assert rep["depth_mean_m"] <= 5e-5 and rep["depth_median_m"] <= 1e-5, rep
+
+
+def test_split_conv_small_unstandardised_weights(hip):
+    """weights of ~1 / sqrt(fan_in) (res_conv, Downsample, Upsample, to_qkv: never weight-standardised) have f16
+    lo halves in the SUBNORMAL range and kept only 18-20 bits.  With the packer's per-output-channel power-of-two scale the
+    split convolution of such weights must sit at torch-CPU's own float32 distance from a float64 convolution, as it does for
+    unit-variance weights (test_split_conv_against_float64), channel by channel over six binades of channel magnitude."""
+    for (B, Cin, Cout, H, Wd, K, stride) in [(2, 128, 64, 16, 16, 1, 1), (1, 768, 512, 16, 16, 1, 1), (2, 64, 64, 32, 32, 4, 2), (1, 512, 128, 16, 16, 3, 1)]:
+        g = torch.Generator().manual_seed(Cin + Cout + K)
+        x = torch.nn.functional.silu(torch.randn((B, Cin, H, Wd), generator=g) * 2.0)
+        fan = Cin * K * K
+        w = (torch.rand((Cout, Cin, K, K), generator=g) * 2 - 1) * (3.0 / fan) ** 0.5
+        w = w * torch.exp2(torch.randint(-5, 1, (Cout, 1, 1, 1), generator=g).float())       # channels down to 2^-5 of the nominal size
+        bias = torch.zeros((Cout,))
+        pad = 0 if K == 1 else 1
+        got = _conv(hip, x, w, bias, hip.lib.PRG_F16X3, K, stride)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=stride, padding=pad)
+        cpu32 = torch.nn.functional.conv2d(x, w, None, stride=stride, padding=pad)
+        ch_rms = ref.pow(2).mean(dim=(0, 2, 3)).sqrt()
+        e = ((got.double() - ref).pow(2).mean(dim=(0, 2, 3)).sqrt() / ch_rms)
+        c = ((cpu32.double() - ref).pow(2).mean(dim=(0, 2, 3)).sqrt() / ch_rms)
+        print(f"\nsmall-weight split conv {Cin}->{Cout} {K}x{K}/{stride}: per-channel relative rms error max {float(e.max()):.3e} "
+              f"(torch-CPU fp32 {float(c.max()):.3e}), max|w| {float(w.abs().max()):.3e}")
+        assert float(e.max()) <= 4.0 * float(c.max()) + 2e-7, (float(e.max()), float(c.max()))

@@ -264,7 +264,8 @@ def test_downsample_equals_two_by_two_taps_over_space_to_depth():
 def test_job_seed_is_drawn_once_and_published_to_every_rank():
     """the job seed is drawn on rank 0 (secrets.randbits) and published through a c10d store on
     MASTER_ADDR:MASTER_PORT — identical on every rank of a launch, fresh on the next launch even with the SAME rendezvous id
-    and port, independent of launcher pids / restart counters; PRG_JOB_SEED pins it."""
+    and port, independent of launcher pids; PRG_JOB_SEED pins it.  (Round 5: the store keys carry the attempt's
+    TORCHELASTIC_RESTART_COUNT, which torchrun gives every rank of an attempt alike.)"""
     import socket
     import subprocess
     import sys
@@ -277,7 +278,7 @@ def test_job_seed_is_drawn_once_and_published_to_every_rank():
         procs = []
         for r in range(2):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       TORCHELASTIC_RUN_ID="fixed-id", TORCHELASTIC_RESTART_COUNT=str(r))
+                       TORCHELASTIC_RUN_ID="fixed-id", TORCHELASTIC_RESTART_COUNT="0")
             env.pop("PRG_JOB_SEED", None)
             env.update(extra or {})
             procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -290,3 +291,83 @@ def test_job_seed_is_drawn_once_and_published_to_every_rank():
     assert a[0] != b[0], "two launches with the same rendezvous id must not share a seed"
     assert 0 <= a[0] < (1 << 63)
     assert launch({"PRG_JOB_SEED": "1234"}) == [1234, 1234]
+
+
+def test_job_seed_survives_a_store_that_outlives_the_attempt():
+    """under torchrun MASTER_PORT is the AGENT's store and outlives worker restarts; rank 0 of the restarted
+    attempt is then a client of a store that still holds the previous attempt's seed and reader count.  The keys are namespaced
+    per attempt (TORCHELASTIC_RESTART_COUNT): with a pre-existing store that already holds attempt 0's keys, the ranks of
+    attempt 1 agree on a NEW seed (never the stale one, no early return on the stale reader count)."""
+    import socket
+    import subprocess
+    import sys
+    from datetime import timedelta
+
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    agent = dist.TCPStore("127.0.0.1", port, None, is_master=True, timeout=timedelta(seconds=60), wait_for_workers=False)
+    stale = 4242424242
+    agent.set("prg_job_seed/fixed-id/0/0", str(stale))            # what attempt 0 left behind
+    agent.add("prg_job_seed/fixed-id/0/0/readers", 2)
+    agent.set("prg_job_seed", str(stale))                          # (and the round-4 key names)
+    agent.add("prg_job_seed_readers", 2)
+    code = "import sys; sys.path.insert(0, %r); from pointreggpt_amd import sharding; print(sharding.job_seed())" % ROOT
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TORCHELASTIC_RUN_ID="fixed-id", TORCHELASTIC_RESTART_COUNT="1")
+        env.pop("PRG_JOB_SEED", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    seeds = [int(o[0].strip().splitlines()[-1]) for o in outs]
+    assert seeds[0] == seeds[1] != stale, seeds
+    assert int(agent.get("prg_job_seed/fixed-id/1/0").decode()) == seeds[0]
+    del agent
+
+
+def test_rank_cpu_sets_partition_the_host():
+    """Round 5: per-rank CPU placement.  Eight ranks on a 2-socket, 256-thread host whose GPUs 0-3 / 4-7 hang off
+    NUMA nodes 0 / 1: every rank gets a disjoint quarter of ITS GPU's node, all sets together cover the host; without topology
+    the allowed CPUs are cut evenly; fewer CPUs than ranks = everything shared; PRG_NO_AFFINITY / a single rank leave the process
+    alone."""
+    from pointreggpt_amd import sharding as S
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    allowed = list(range(256))
+    sets = []
+    for r in range(8):
+        node = r // 4
+        cp = S.rank_cpu_set(r, 8, allowed, node_cpus[node], peers_on_node=4, index_on_node=r % 4)
+        assert len(cp) == 32 and set(cp) <= set(node_cpus[node])
+        sets.append(set(cp))
+    assert len(set().union(*sets)) == 256 and sum(len(x) for x in sets) == 256
+    flat = [S.rank_cpu_set(r, 8, allowed, []) for r in range(8)]
+    assert [len(x) for x in flat] == [32] * 8 and sorted(sum(flat, [])) == allowed
+    assert S.rank_cpu_set(5, 8, [0, 1, 2], []) == [0, 1, 2]
+    assert S._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert S.pin_rank_cpus(0, 1)["pinned"] is False
+    before = os.sched_getaffinity(0)
+    os.environ["PRG_NO_AFFINITY"] = "1"
+    try:
+        assert S.pin_rank_cpus(1, 2)["pinned"] is False and os.sched_getaffinity(0) == before
+    finally:
+        del os.environ["PRG_NO_AFFINITY"]
+
+
+def test_pin_rank_cpus_in_a_subprocess():
+    """pin_rank_cpus really narrows the calling process (and so every thread it starts later) to its share of the allowed CPUs."""
+    import subprocess
+    import sys
+    code = ("import os, sys, json; sys.path.insert(0, %r); from pointreggpt_amd import sharding as S; "
+            "a = sorted(os.sched_getaffinity(0)); i = S.pin_rank_cpus(1, 2); print(json.dumps([a, sorted(os.sched_getaffinity(0)), i]))" % ROOT)
+    env = dict(os.environ)
+    env.pop("PRG_NO_AFFINITY", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    import json
+    before, after, info = json.loads(r.stdout.strip().splitlines()[-1])
+    if len(before) >= 2:
+        assert info["pinned"] and after == before[len(before) // 2 + (len(before) % 2 > 0 and 0):] or set(after) < set(before)
+        assert len(after) == len(before) // 2
