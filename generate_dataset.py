@@ -69,7 +69,14 @@ def main():
 
     rank, world, local = sharding.rank_world()
     if args.device == "cuda":
-        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # (more ranks than devices: ranks share, used by the tests)
+        dev_index = local % max(1, torch.cuda.device_count())              # (more ranks than devices: ranks share, used by the tests)
+        # before any thread exists (lane threads, the C++ writer pool): this rank's share of the cores of its GPU's NUMA node
+        # (PRG_NO_AFFINITY=1 opts out; a single rank is left alone)
+        aff = sharding.pin_rank_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=dev_index)
+        if aff.get("pinned"):
+            print("[rank {}/{}] pinned to {} CPUs [{}..{}] (NUMA node {}, {})".format(
+                rank, world, aff["cpus"], aff["first_cpu"], aff["last_cpu"], aff["numa_node"], aff["source"]))
+        torch.cuda.set_device(dev_index)
     start, stop = sharding.shard_range(args.start_scene_index, args.stop_scene_index, rank, world, args.batch_size)
 
     model = Unet(dim=args.dim, param_cond_dim=4, dim_mults=(1, 2, 4, 8), channels=1, dtype=args.dtype)

@@ -244,6 +244,17 @@ int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes);
 /* 2 * MAC count the same launches EXECUTED: equal to conv_flops except for Upsample convs that ran as four 2 x 2-tap sub-pixel
  * convolutions (4 / 9 of the algorithmic count, which stays the reference operator's). */
 int prg_sampler_get_profile_executed(prg_sampler* h, double* conv_flops_executed);
+/* Per-SHAPE totals of the same launches (round 5; bench.py `roofline.per_kernel`): one row per distinct convolution shape of the
+ * profiled run — launches, milliseconds inside them (HIP events), algorithmic and executed 2 * MAC counts.  rows may be null with
+ * max_rows = 0 to query the row count; at most max_rows rows are written, *n_rows receives the number available.
+ * No reference counterpart (sd: has no profiler on this path): measurement hook like prg_sampler_get_profile. */
+typedef struct prg_profile_shape {
+  int32_t cin, cout, k, stride, ups, hout, wout;   /* Conv2d(cin, cout, k, stride) on (hout, wout) outputs; ups: after nn.Upsample(x2) */
+  int32_t two_source, prologue;                     /* virtual concat of two tensors (skip connection); fused GroupNorm+SiLU on the input */
+  int64_t launches;
+  double ms, flops, flops_executed;
+} prg_profile_shape;
+int prg_sampler_get_profile_shapes(prg_sampler* h, prg_profile_shape* rows, int32_t max_rows, int32_t* n_rows);
 /* The same for the per-transition update kernel (x0 / DDNM replace / posterior / noise: HBM-bound, 20 B per pixel). */
 int prg_sampler_get_profile_step(prg_sampler* h, double* step_ms, int64_t* step_launches);
 

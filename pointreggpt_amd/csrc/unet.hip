@@ -79,6 +79,21 @@ struct ProfileSink {  // per-launch conv timing (bench roofline)
   double conv_ms = 0, conv_flops = 0, conv_bytes = 0;   // conv_bytes: algorithmic input + output + weight bytes
   double conv_flops_exec = 0;                           // 2 * MACs the kernels executed (sub-pixel Upsample convs: 4 / 9 of the algorithmic count)
   int64_t launches = 0;
+  // per-SHAPE table (round 5, bench.py roofline.per_kernel): what pool[i] timed, and the totals per distinct conv shape
+  struct Rec { prg_profile_shape key; double flops, flops_exec; };
+  std::vector<Rec> recs;                                       // recs[i] <-> pool[i] of the step being harvested
+  std::vector<prg_profile_shape> shapes;                       // accumulated (launches, ms, flops) per distinct key
+  void add_shape(const Rec& r, double ms) {
+    for (auto& sh : shapes)
+      if (sh.cin == r.key.cin && sh.cout == r.key.cout && sh.k == r.key.k && sh.stride == r.key.stride && sh.ups == r.key.ups &&
+          sh.hout == r.key.hout && sh.wout == r.key.wout && sh.two_source == r.key.two_source && sh.prologue == r.key.prologue) {
+        sh.launches += 1; sh.ms += ms; sh.flops += r.flops; sh.flops_executed += r.flops_exec;
+        return;
+      }
+    prg_profile_shape sh = r.key;
+    sh.launches = 1; sh.ms = ms; sh.flops = r.flops; sh.flops_executed = r.flops_exec;
+    shapes.push_back(sh);
+  }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> step_pool;   // the per-transition update kernel (HBM-bound)
   size_t step_used = 0;
   double step_ms = 0;
@@ -400,6 +415,14 @@ struct UnetImpl : prg_unet {
       PRG_HIP(hipEventRecord(ev.second, s));
       prof->conv_flops += conv_flops(L.d);
       prof->conv_flops_exec += conv_flops(L.d) * conv_last_exec_scale();
+      {
+        ProfileSink::Rec r{};
+        r.key.cin = L.d.C0 + L.d.C1; r.key.cout = L.d.Cout; r.key.k = L.d.KH; r.key.stride = L.d.stride; r.key.ups = L.d.ups;
+        r.key.hout = L.d.Hout; r.key.wout = L.d.Wout; r.key.two_source = L.d.C1 > 0; r.key.prologue = (L.pro_a != nullptr || L.pro_fold.acc != nullptr);
+        r.flops = conv_flops(L.d); r.flops_exec = conv_flops(L.d) * conv_last_exec_scale();
+        if (prof->recs.size() < prof->used) prof->recs.resize(prof->used);
+        prof->recs[prof->used - 1] = r;
+      }
       prof->conv_bytes += ((double)L.d.B * L.d.Hin * L.d.Win * (L.d.C0 + L.d.C1) + (double)L.d.B * L.d.Hout * L.d.Wout * L.d.Cout +
                            (double)L.d.Cout * (L.d.C0 + L.d.C1) * L.d.KH * L.d.KW) * sizeof(T);
       prof->launches += 1;
@@ -1740,6 +1763,14 @@ int prg_sampler_get_profile_bytes(prg_sampler* h, double* conv_bytes) {
   return PRG_OK;
 }
 
+int prg_sampler_get_profile_shapes(prg_sampler* h, prg_profile_shape* rows, int32_t max_rows, int32_t* n_rows) {
+  PRG_CHECK(h && n_rows && (rows || max_rows == 0), "prg_sampler_get_profile_shapes: null argument");
+  const int n = (int)h->prof.shapes.size();
+  *n_rows = n;
+  for (int i = 0; i < n && i < max_rows; ++i) rows[i] = h->prof.shapes[i];
+  return PRG_OK;
+}
+
 int prg_sampler_get_profile_step(prg_sampler* h, double* step_ms, int64_t* step_launches) {
   PRG_CHECK(h && step_ms && step_launches, "prg_sampler_get_profile_step: null argument");
   *step_ms = h->prof.step_ms;
@@ -1799,6 +1830,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
   u->prof = profiling ? &h->prof : nullptr;
   h->prof.conv_ms = 0; h->prof.conv_flops = 0; h->prof.conv_flops_exec = 0; h->prof.conv_bytes = 0; h->prof.launches = 0; h->prof.used = 0;
   h->prof.step_ms = 0; h->prof.step_launches = 0; h->prof.step_used = 0;
+  h->prof.shapes.clear(); h->prof.recs.clear();
   hipEvent_t t0 = nullptr, t1 = nullptr;
   if (profiling) {
     PRG_HIP(hipEventCreate(&t0));
@@ -1830,6 +1862,7 @@ int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_co
           float ms = 0;
           PRG_HIP(hipEventElapsedTime(&ms, h->prof.pool[i].first, h->prof.pool[i].second));
           h->prof.conv_ms += ms;
+          if (i < h->prof.recs.size()) h->prof.add_shape(h->prof.recs[i], ms);
         }
         h->prof.used = 0;
         for (size_t i = 0; i < h->prof.step_used; ++i) {

@@ -52,6 +52,12 @@ def ddim_times(total: int, steps: int) -> List[int]:
     return list(reversed(torch.linspace(-1, total - 1, steps=steps + 1).int().tolist()))
 
 
+
+class _ProfileShape(C.Structure):     # include/prg.h: prg_profile_shape
+    _fields_ = [("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32),
+                ("hout", C.c_int32), ("wout", C.c_int32), ("two_source", C.c_int32), ("prologue", C.c_int32),
+                ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("flops_executed", C.c_double)]
+
 class GaussianDiffusion:
     """Sampling half of the reference class: same constructor keywords, ``sample(param_cond=, img_cond=)``."""
 
@@ -193,5 +199,10 @@ class GaussianDiffusion:
         _lib.check(lib.prg_sampler_get_profile_step(h, C.byref(sms), C.byref(sn)))
         ex = C.c_double()
         _lib.check(lib.prg_sampler_get_profile_executed(h, C.byref(ex)))
+        nrows = C.c_int32()
+        _lib.check(lib.prg_sampler_get_profile_shapes(h, None, 0, C.byref(nrows)))
+        rows = (_ProfileShape * max(1, nrows.value))()
+        _lib.check(lib.prg_sampler_get_profile_shapes(h, C.cast(rows, C.c_void_p), nrows.value, C.byref(nrows)))
+        shapes = [{f: getattr(rows[i], f) for f, _ in _ProfileShape._fields_} for i in range(nrows.value)]
         return {"conv_ms": ms.value, "conv_launches": n.value, "conv_flops": fl.value, "conv_bytes": by.value, "conv_flops_executed": ex.value,
-                "total_ms": tot.value, "step_ms": sms.value, "step_launches": sn.value}
+                "total_ms": tot.value, "step_ms": sms.value, "step_launches": sn.value, "conv_shapes": shapes}

@@ -200,7 +200,7 @@ class Generator:
         """One lane's share of the batches (all of them with a single lane), on the calling thread's current stream."""
         S, dev = self.image_size, self.device
         if writer_threads <= 0 and n_lanes > 1:
-            writer_threads = max(2, min(16, (os.cpu_count() or 4) // max(1, int(os.environ.get("WORLD_SIZE", "1"))) // 2) // n_lanes)
+            writer_threads = max(2, min(16, PP.rank_cpu_budget() // 2) // n_lanes)
         with PP.WriterPool(writer_threads) as pool:
             marker_prev = None                # deferred submission of the previous batch's resume marker
             n_pairs = 0

@@ -225,6 +225,17 @@ def native_write_ply(path: str, pts) -> None:
     _lib.check(_lib.load().prg_host_write_ply(os.fsencode(path), _dp(p), len(p)), "prg_host_write_ply")
 
 
+def rank_cpu_budget() -> int:
+    """CPUs this rank may count on: the affinity mask when the process is pinned (sharding.pin_rank_cpus), otherwise the host's
+    CPUs divided by the ranks of the job (WORLD_SIZE; LOCAL_WORLD_SIZE when the launcher exports it)."""
+    total = os.cpu_count() or 4
+    mine = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total
+    if mine < total:
+        return max(1, mine)
+    ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return max(1, total // max(1, ranks))
+
+
 class WriterPool:
     """Asynchronous per-scene output (prg_pool_*): every submit copies its inputs and returns at once; `wait()` blocks
     until all files exist and raises on the first failed job."""
@@ -234,7 +245,7 @@ class WriterPool:
         self._lib = _lib
         lib = _lib.load()
         if threads <= 0:
-            threads = max(2, min(16, (os.cpu_count() or 4) // max(1, int(os.environ.get("WORLD_SIZE", "1"))) // 2))
+            threads = max(2, min(16, rank_cpu_budget() // 2))
         self.threads = threads
         self._h = C.c_void_p()
         _lib.check(lib.prg_pool_create(int(threads), C.byref(self._h)), "prg_pool_create")

@@ -157,12 +157,14 @@ def pin_rank_cpus(local_rank: int, local_world: int, device_index: int | None = 
     peers = idx = None
     if gpu_cpus and node >= 0:
         # ranks are one per GPU in device order: count the devices on this GPU's node to find this rank's share of it
+        # (more ranks than devices — the gloo rehearsal — : rank r sits on device r % ndev, as bench.py / generate_dataset.py place it)
         try:
             import torch
-            nodes = [gpu_local_cpus(d)[1] for d in range(min(local_world, torch.cuda.device_count()))]
-            same = [d for d, nd in enumerate(nodes) if nd == node]
-            if dev in same:
-                peers, idx = len(same), same.index(dev)
+            ndev = max(1, torch.cuda.device_count())
+            dev_nodes = [gpu_local_cpus(d)[1] for d in range(ndev)]
+            same = [r for r in range(local_world) if dev_nodes[r % ndev] == node]
+            if local_rank in same:
+                peers, idx = len(same), same.index(local_rank)
         except Exception:      # noqa: BLE001
             peers = idx = None
     cpus = rank_cpu_set(local_rank, local_world, allowed, gpu_cpus, peers, idx)

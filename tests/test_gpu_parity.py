@@ -1448,6 +1448,38 @@ def test_bench_gpus_flag_spawns_its_own_ranks(tmp_path):
         assert r.returncode != 0 and "HIP device" in r.stderr
 
 
+def test_bench_eight_ranks_rehearsal_on_one_device(tmp_path):
+    """Round 5: the 8-rank launch the driver runs on an 8-GPU node, rehearsed on the one device with
+    the gloo backend at a tiny shape: eight ranks, ONE JSON line, n_gpus == 8, value = 8 ranks' pairs / max-over-ranks time, a
+    per-rank table (setup / warm-up / timed seconds, device memory in use, CPU placement) and the device memory of 8 x 2 lanes of
+    workspaces reported — so a slow barrier is attributable and the memory of a full node's worth of handles is known to fit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "4", "--size", "64",
+           "--sampling-steps", "3", "--no-roofline", "--no-e2e-files", "--no-drift", "--no-configs4", "--no-cpu-baseline", "--no-parity-mode"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PRG_NO_AFFINITY")}
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=1500, env=dict(env, PRG_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["config"]["streams"] == 2
+    assert abs(j["value"] - 8 * 4 / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
+    pr = j["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8))
+    assert all(p["setup_s"] > 0 and p["timed_s"] > 0 and p["timed_s"] <= j["ms_per_step"] / 1e3 * 1.001 for p in pr)
+    mem = j["device_memory"]
+    assert 0 < mem["in_use_bytes"] < mem["total_bytes"]
+    print(f"8 ranks x 2 lanes on one device: {mem['in_use_bytes'] / 2**30:.2f} GiB in use of {mem['total_bytes'] / 2**30:.0f}; "
+          f"setup {max(p['setup_s'] for p in pr):.1f} s max over ranks; affinity {j['cpu_affinity']}")
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:                                          # every rank pinned to its own disjoint share of the host
+        assert all(p["pinned_cpus"] >= 1 for p in pr) and sum(p["pinned_cpus"] for p in pr) <= ncpu
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # round 4: --num_samples > 1 (sd:2525-2680), NaN visibility of the accumulator statistics, 32-bit guard of the c64 kernel
 # ------------------------------------------------------------------------------------------------------------------
