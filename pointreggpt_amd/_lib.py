@@ -98,7 +98,12 @@ def load():
         lib = C.CDLL(str(LIB_PATH))
     except OSError as e:  # missing ROCm runtime etc.
         raise PrgError(f"cannot load {LIB_PATH}: {e}") from e
+    # PRG_HIP_LIB_ALLOW_MISSING=1 (diagnostics only, with PRG_HIP_LIB=<an older build>: same-box A/B against a previous round's
+    # library, tools/gpu_r5_call2.sh): entry points that library predates are skipped; calling one fails at the call site
+    lenient = os.environ.get("PRG_HIP_LIB_ALLOW_MISSING", "0") not in ("", "0") and bool(os.environ.get("PRG_HIP_LIB"))
     for name, (res, args) in PROTOTYPES.items():
+        if lenient and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args

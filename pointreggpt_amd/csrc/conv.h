@@ -201,10 +201,10 @@ inline double conv_flops(const ConvDesc& d) {
 
 // Direct (VALU) stem conv 7x7 pad 3: float32 NCHW (B,Cin,H,W) with Cin in {1,3} -> T NHWC (B,H,W,Cout).
 // wk = float32 [49*Cin][Cout] (tap-major, then cin), bias float32 [Cout].
-// stem on MFMA (bf16 path, Cin 1 -> 64): fragments packed once by pack_stem_mfma_weights
+// stem on MFMA (bf16 path, Cin 1 or 3 -> 64): fragments packed once by pack_stem_mfma_weights
 bool stem_conv_mfma_supported(int Cin, int Cout, int H, int W);
-int launch_stem_conv_mfma(const float* x, const bf16_t* wf, const float* bias, bf16_t* out, int B, int H, int W, hipStream_t s);
-void pack_stem_mfma_weights(const float* w, std::vector<bf16_t>& out);
+int launch_stem_conv_mfma(const float* x, const bf16_t* wf, const float* bias, bf16_t* out, int B, int Cin, int H, int W, hipStream_t s);
+void pack_stem_mfma_weights(const float* w, int Cin, std::vector<bf16_t>& out);
 template <typename T>
 int launch_stem_conv(const float* x, const float* wk, const float* bias, T* out, int B, int Cin, int H, int W,
                      int Cout, hipStream_t s);

@@ -979,6 +979,363 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1, Cout = 64: the PERSISTENT wave-specialised form (round 5) — levels 0 / 1 and the narrow Upsample
+// ---------------------------------------------------------------------------------------------
+// The 64-channel convolutions (64 -> 64, the two-source 128 -> 64 of the up path, Upsample 128 -> 64: sixteen launches per
+// evaluation, 29 % of the f16x3 mode's time) ran on the symmetric kernel at 0.33-0.41 MFMA-busy: with K = 576 a tile is 18 taps
+// and a one-tile workgroup exposes its first halo's HBM latency and its epilogue, which only two co-resident (lock-step,
+// LDS-read-bound) workgroups hid.  Here ONE 512-thread workgroup per CU walks a strided list of 16 x 16-pixel x 64-channel tiles
+// with conv3x3_split_ws_kernel's division of labour, and the pipelines never drain between tiles:
+//   waves 0-3  CONSUMERS, 64 pixels (four tile rows) x 64 channels each: per tap 16 fragment loads for 24 MFMAs, double-buffered
+//              per k16 step; after a tile's last tap they run the direct epilogue (scale, bias, GroupNorm partial sums per
+//              (tile, wave) slab, dword stores — no LDS, no barrier) while the producers are already a chunk / three taps ahead;
+//   waves 4-5  HALO producers: chunk g + 1's 18 x 18 halo — of the NEXT tile when chunk g is a tile's last — loaded at tap 0 of
+//              chunk g (eleven passes, 88 staging registers), prologue + split + ds_write two passes per tap at taps 2-7;
+//   waves 6-7  WEIGHT producers: the (tap, chunk) tile sequence simply repeats per pixel tile (K = 576: 18 tiles of 8 KB, L2
+//              resident), LDS-DMA three taps ahead into a ring of four, counted vmcnt.
+// One raw s_barrier per tap for the eight waves, numbered through the whole tile list (invariants as in the kernel above);
+// LDS = 2 x 50,688 (halos, 144-byte pixels, rows of 0 mod 16 slots) + 4 x 8,192 (weights) = 134,144 bytes.
+// The arithmetic is the symmetric kernel's, term for term (same MFMA sequence per accumulator, 288-term partials, same epilogue
+// expression): only the GroupNorm slab partition differs.
+template <int NS>
+__global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLaunch<float> L, const int tiles_x, const int tiles_y,
+                                                                   const int ntiles, const int fuse_stats) {
+  constexpr int TH = 16, TW = 16, BN = 64, CH = 32, NT = 9;
+  constexpr int HP = TW + 2, HALO = (TH + 2) * HP, PITCH = 144;
+  constexpr int RSTRIDE = (HP * PITCH + 255) / 256 * 256, HBYTES = (TH + 2) * RSTRIDE;
+  constexpr int NHP = (HALO * 4 + 127) / 128;            // halo staging passes of the 128 halo-producer threads (11)
+  constexpr int WPW = BN / 8 / 2;                        // global_load_lds instructions per weight-producer wave and tile (4)
+  static_assert(NS == 4 && NHP == 11, "ring / passes");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ah = smem;                                 // [2][18 rows of RSTRIDE bytes]
+  char* const Bs = smem + 2 * HBYTES;                    // [NS][64][128 B], units XOR-swizzled by (row >> 1) & 7
+
+  const ConvDesc& d = L.d;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nchunks = (d.C0 + d.C1) / CH;
+  // this workgroup's tiles: t_first + k * t_stride, k < t_count.  With a grid that is a multiple of 8, XCD x (workgroups b with
+  // b % 8 = x: observed) owns a contiguous eighth of the tile list and its workgroups walk it interleaved, so tiles that share halo
+  // rows run at the same time on one L2.
+  int t_first, t_stride, t_count;
+  {
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    if ((G & 7) == 0) {
+      const int xcd = bid & 7, idx = bid >> 3, per = G >> 3;
+      const int q = ntiles >> 3, r = ntiles & 7;
+      const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      const int cnt = q + (xcd < r ? 1 : 0);
+      t_first = start + idx; t_stride = per; t_count = idx < cnt ? (cnt - idx + per - 1) / per : 0;
+    } else {
+      t_first = bid; t_stride = G; t_count = bid < ntiles ? (ntiles - bid + G - 1) / G : 0;
+    }
+  }
+  const int nchunks_total = t_count * nchunks, niter = nchunks_total * NT;
+  if (niter == 0) return;                                // (uniform over the workgroup: no barrier is ever reached)
+  const size_t wstep = (size_t)d.CoutPad * 128;
+  const int Hs = d.Hout, Ws = d.Wout;
+  const int tiles_img = tiles_x * tiles_y;
+
+  if (wave >= 6) {
+    // ------------------------------------------------ weight producers ------------------------------------------------
+    const int pw = wave - 6;
+    int wsrc[WPW];
+#pragma unroll
+    for (int r = 0; r < WPW; ++r) {
+      const int n = (pw * WPW + r) * 8 + (lane >> 3);
+      wsrc[r] = n * 128 + (((lane & 7) ^ ((n >> 1) & 7)) << 4);
+    }
+    const char* wtile = reinterpret_cast<const char*>(L.w_split);
+    int c_n = 0, tap_n = 0;                              // (chunk, tap) of the next tile to fetch: the sequence repeats per pixel tile
+    auto gload_next = [&](int it) {
+      const char* p = wtile + (size_t)(tap_n * L.split_kchunks + c_n) * wstep;
+      char* dst = Bs + ((it & (NS - 1)) * BN + pw * WPW * 8) * 128;
+#pragma unroll
+      for (int r = 0; r < WPW; ++r)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
+                                         (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
+      if (++tap_n == NT) { tap_n = 0; if (++c_n == nchunks) c_n = 0; }
+    };
+    gload_next(0);
+    gload_next(1);
+    gload_next(2);                                       // (niter >= 18)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WPW) : "memory");     // tiles 0 and 1 landed -> barrier(0)
+    for (int it = 0; it < niter; ++it) {
+      if (it + 3 < niter) {
+        gload_next(it + 3);                              // into tile it - 1's slot, free since barrier(it)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WPW) : "memory");   // tile it + 2 landed -> barrier(it + 1)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    return;
+  }
+  if (wave >= 4) {
+    // ------------------------------------------------- halo producers -------------------------------------------------
+    const int pt = tid - 256, q = pt & 3, prow = pt >> 2;  // channels q * 8 .. + 7 of halo pixels prow + 32 k
+    int hyx[NHP], wl[NHP];                               // tile-independent: halo coordinates and LDS address of pass k
+#pragma unroll
+    for (int k = 0; k < NHP; ++k) {
+      const int hp = prow + k * 32;
+      const int hy = hp / HP, hx = hp - hy * HP;
+      hyx[k] = hp < HALO ? ((hy << 8) | hx) : -1;
+      wl[k] = hy * RSTRIDE + hx * PITCH + q * 16;
+    }
+    int hsrc[NHP];                                       // source pixel index (or -1: padding / beyond the halo) for the tile being staged
+    int img = 0;
+    auto set_tile = [&](int kt) {
+      int lin = t_first + kt * t_stride;
+      const int tx = lin % tiles_x; lin /= tiles_x;
+      const int ty = lin % tiles_y;
+      img = lin / tiles_y;
+      const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+      for (int k = 0; k < NHP; ++k) {
+        hsrc[k] = -1;
+        if (hyx[k] >= 0) {
+          int y = y0 - 1 + (hyx[k] >> 8), x = x0 - 1 + (hyx[k] & 255);
+          if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) {
+            if (d.ups) { y >>= 1; x >>= 1; }
+            hsrc[k] = (img * d.Hin + y) * d.Win + x;
+          }
+        }
+      }
+    };
+    float4 g0[NHP], g1[NHP];
+    auto load_chunk = [&](int chunk) {
+      const int c = chunk * CH + q * 8;
+      const bool first = c < d.C0;
+      const float* base = first ? L.src0 : L.src1;
+      const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+#pragma unroll
+      for (int k = 0; k < NHP; ++k) {
+        const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
+        g0[k] = p[0];
+        g1[k] = p[1];
+      }
+    };
+    float pa[8], pb[8];
+    auto pro_load = [&](int chunk) {
+      if (L.pro_a) {
+        const float4* a4 = reinterpret_cast<const float4*>(L.pro_a + (size_t)img * d.C0 + chunk * CH + q * 8);
+        const float4* b4 = reinterpret_cast<const float4*>(L.pro_b + (size_t)img * d.C0 + chunk * CH + q * 8);
+        const float4 a0 = a4[0], a1 = a4[1], b0 = b4[0], b1 = b4[1];
+        pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w; pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+        pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
+      }
+    };
+    auto write_pass = [&](int buf, auto K) {
+      constexpr int k = decltype(K)::value;
+      if (hyx[k] >= 0) {
+        float v[8] = {g0[k].x, g0[k].y, g0[k].z, g0[k].w, g1[k].x, g1[k].y, g1[k].z, g1[k].w};
+        if (L.pro_a) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = silu_fast(fmaf(v[u], pa[u], pb[u]));
+        }
+        if (hsrc[k] < 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = 0.0f;
+        }
+        uint4 vh, vl;
+        split8(v, vh, vl);
+        char* p = Ah + buf * HBYTES + wl[k];
+        *reinterpret_cast<uint4*>(p) = vh;
+        *reinterpret_cast<uint4*>(p + 64) = vl;
+      }
+    };
+    set_tile(0);
+    pro_load(0);
+    load_chunk(0);
+    write_pass(0, IC<0>()); write_pass(0, IC<1>()); write_pass(0, IC<2>()); write_pass(0, IC<3>());
+    write_pass(0, IC<4>()); write_pass(0, IC<5>()); write_pass(0, IC<6>()); write_pass(0, IC<7>());
+    write_pass(0, IC<8>()); write_pass(0, IC<9>()); write_pass(0, IC<10>());
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");               // -> barrier(0)
+    int kt = 0, c = 0;
+    for (int g = 0; g < nchunks_total; ++g) {
+      const bool more = g + 1 < nchunks_total;
+      int c1 = c + 1, kt1 = kt;
+      if (c1 == nchunks) { c1 = 0; kt1 = kt + 1; }
+      const int nb = (g + 1) & 1;
+      // tap 0: the next chunk's (the next TILE's first chunk's) coordinates, coefficients and ALL its halo loads; taps 2 .. 7: two
+      // passes each converted and written (the other halo buffer was last read during the previous chunk's tap 8, i.e. before
+      // barrier(9 g)); tap 8: nothing — the consumers fetch the next chunk's first fragments during it
+      if (more) {
+        if (c1 == 0) set_tile(kt1);
+        pro_load(c1);
+        load_chunk(c1);
+      }
+      asm volatile("s_barrier" ::: "memory");                                     // -> barrier(9 g + 1)
+      asm volatile("s_barrier" ::: "memory");                                     // -> barrier(9 g + 2)
+      if (more) { write_pass(nb, IC<0>()); write_pass(nb, IC<1>()); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) { write_pass(nb, IC<2>()); write_pass(nb, IC<3>()); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) { write_pass(nb, IC<4>()); write_pass(nb, IC<5>()); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) { write_pass(nb, IC<6>()); write_pass(nb, IC<7>()); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) { write_pass(nb, IC<8>()); write_pass(nb, IC<9>()); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (more) write_pass(nb, IC<10>());
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // -> barrier(9 g + 8)
+      asm volatile("s_barrier" ::: "memory");                                     // -> barrier(9 g + 9)
+      c = c1;
+      kt = kt1;
+    }
+    return;
+  }
+  // ---------------------------------------------------- consumers -----------------------------------------------------
+  const int l31 = lane & 31, hi = lane >> 5;
+  int a_lane[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = wave * 64 + i * 32 + l31;
+    a_lane[i] = (pix / TW) * RSTRIDE + (pix % TW) * PITCH + hi * 16;
+  }
+  int b_lane[2][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int sw = (l31 >> 1) & 7, unit = 2 * st + hi;
+    b_lane[st][0] = l31 * 128 + ((unit ^ sw) << 4);
+    b_lane[st][1] = l31 * 128 + (((4 + unit) ^ sw) << 4);
+  }
+  f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }
+  f16x8 fa[2][4], fw[2][4];                              // [k16 step][A: (hi, lo) x row tile | W: (hi, lo) x column tile]
+  auto reads = [&](auto ST, auto TAP, int cb, int slot) {
+    constexpr int st = decltype(ST)::value, T = decltype(TAP)::value;
+    constexpr int toff = (T / 3) * RSTRIDE + (T % 3) * PITCH;
+    const char* A = Ah + cb * HBYTES + toff + st * 32;
+    const char* Bb = Bs + slot * (BN * 128);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[st][2 * i] = ld_frag(reinterpret_cast<const uint4*>(A + a_lane[i]));
+      fa[st][2 * i + 1] = ld_frag(reinterpret_cast<const uint4*>(A + a_lane[i] + 64));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fw[st][2 * j] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][0] + j * 4096));
+      fw[st][2 * j + 1] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][1] + j * 4096));
+    }
+  };
+  auto mfmas = [&](auto ST) {
+    constexpr int st = decltype(ST)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i + 1], fw[st][2 * j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j + 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j], acc[i][j], 0, 0, 0);
+  };
+  // one tap of global chunk g (halo buffer g & 1); `more` = another chunk (of this or of the next tile) follows
+  auto body = [&](auto TAP, int g, bool more) {
+    constexpr int T = decltype(TAP)::value;
+    const int it = g * NT + T;
+    // barrier #it (the very first tap runs straight after the prologue's barrier #0): weight tiles it, it + 1 are in LDS, tile
+    // it - 1's slot is free for the producers, this chunk's halo is complete.  No wait: a consumer's outstanding fragment loads
+    // read only images that stay valid for another tap.
+    if (it > 0) asm volatile("s_barrier" ::: "memory");
+    reads(IC<1>(), TAP, g & 1, it & (NS - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<0>());
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), g & 1, (it + 1) & (NS - 1));
+    else if (more) reads(IC<0>(), IC<0>(), (g + 1) & 1, (it + 1) & (NS - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(IC<1>());
+    if constexpr (T == NT - 1) {                         // the 288-term partial of this channel chunk
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
+    }
+  };
+  asm volatile("s_barrier" ::: "memory");                // barrier(0): the producers' prologue — tile 0's first halo, weight tiles 0 and 1
+  reads(IC<0>(), IC<0>(), 0, 0);
+  const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 64;          // 8, 16, 32 or 64 when the statistics are fused
+  const int nsplit = tiles_img * 4;
+  int g = 0;
+  for (int kt = 0; kt < t_count; ++kt) {
+    for (int c = 0; c < nchunks; ++c, ++g) {
+      const bool more = g + 1 < nchunks_total;
+      body(IC<0>(), g, more); body(IC<1>(), g, more); body(IC<2>(), g, more); body(IC<3>(), g, more); body(IC<4>(), g, more);
+      body(IC<5>(), g, more); body(IC<6>(), g, more); body(IC<7>(), g, more); body(IC<8>(), g, more);
+    }
+    // DIRECT epilogue of tile kt (as in the kernels above): register e of lane half hi is pixel row (e & 3) + 8 (e >> 2) + 4 hi of
+    // the 32-pixel row tile, lanes 0-31 are 32 consecutive channels: a dword store per register writes two full 128-byte lines per
+    // wave-instruction; GroupNorm partial sums by lane reductions, one slab per (tile, wave).  The next tile's first fragments are
+    // already in flight, the producers are a chunk / three taps ahead.
+    int lin = t_first + kt * t_stride;
+    const int tx = lin % tiles_x; lin /= tiles_x;
+    const int ty = lin % tiles_y;
+    const int b = lin / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    double sd[2], qd[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = j * 32 + l31;
+      const float bv = L.bias ? L.bias[ch] : 0.0f;
+      const float sc = L.split_scale ? L.split_scale[ch] : 1.0f;         // the packer's per-channel power of two, undone (exact)
+      float s1 = 0.0f, q1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int p = wave * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+          const size_t m = ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
+          const float v = tot[i][j][e] * sc + bv;
+          L.out[m * d.Cout + ch] = v;
+          s1 += v;
+          q1 = fmaf(v, v, q1);
+          tot[i][j][e] = 0.0f;
+        }
+      sd[j] = (double)s1;
+      qd[j] = (double)q1;
+    }
+    if (fuse_stats) {
+      const int width = cpg < 32 ? cpg : 32;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        sd[j] += __shfl_xor(sd[j], 32, 64);
+        qd[j] += __shfl_xor(qd[j], 32, 64);
+        for (int o = 1; o < width; o <<= 1) {
+          sd[j] += __shfl_xor(sd[j], o, 64);
+          qd[j] += __shfl_xor(qd[j], o, 64);
+        }
+      }
+      float* slab = L.gn_partials + ((size_t)b * nsplit + (ty * tiles_x + tx) * 4 + wave) * L.gn_groups * 2;
+      if (cpg == 64) {
+        if (lane == 0) {
+          slab[0] = (float)(sd[0] + sd[1]);
+          slab[1] = (float)(qd[0] + qd[1]);
+        }
+      } else if (hi == 0 && (l31 & (width - 1)) == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int gr = (j * 32 + l31) / cpg;
+          slab[gr * 2] = (float)sd[j];
+          slab[gr * 2 + 1] = (float)qd[j];
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier(niter)
+}
+
+// ---------------------------------------------------------------------------------------------
 // gather form (1x1, 4x4 stride 2, small / ragged shapes): structure of conv_igemm_kernel (conv.hip)
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, bool ONE>
@@ -1238,6 +1595,30 @@ static int launch_split_ws(const ConvLaunch<float>& L, hipStream_t s, int fuse_s
   return PRG_OK;
 }
 
+// the persistent Cout = 64 kernel: 16 x 16-pixel tiles, one 512-thread workgroup per CU
+static int launch_split_p64(const ConvLaunch<float>& L, hipStream_t s, int fuse_stats, int* nsplit) {
+  constexpr int NS = 4, HB = 18 * ((18 * 144 + 255) / 256 * 256);
+  const ConvDesc& d = L.d;
+  const int tiles_x = d.Wout / 16, tiles_y = d.Hout / 16;
+  const int ntiles = tiles_x * tiles_y * d.B;
+  const size_t lds = (size_t)2 * HB + NS * 64 * 128;
+  if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * 4 : 0;
+  static std::atomic<int> num_cus{0};
+  if (!num_cus.load(std::memory_order_acquire)) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    PRG_HIP(hipGetDevice(&dev));
+    PRG_HIP(hipGetDeviceProperties(&p, dev));
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_p64_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    num_cus.store(p.multiProcessorCount, std::memory_order_release);
+  }
+  int grid = ntiles < num_cus.load() ? ntiles : num_cus.load();
+  if (grid >= 8) grid &= ~7;                             // multiple of 8: XCD-contiguous tile runs
+  conv3x3_split_p64_kernel<NS><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, ntiles, fuse_stats);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
 template <int BM, int BN>
 static int launch_split_igemm(const ConvLaunch<float>& L, int M, hipStream_t s, int want_stats, int* nsplit) {
   const ConvDesc& d = L.d;
@@ -1306,6 +1687,15 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
       const int tiles = (W / 16) * (H / 8) * 2;
       const int f = want_stats && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 && tiles <= kGnMaxSplit;
       if (f || !want_stats) { rc = launch_split_ws(L, s, f, gn_nsplit_out); return rc ? rc : 1; }
+    }
+    // Cout = 64 and a launch that fills the chip (>= one 16 x 16 tile per CU): the persistent kernel; PRG_SPLIT_P64=0: never,
+    // PRG_SPLIT_P64=<n>: from n tiles (tests force it at small shapes)
+    static const int p64_min = [] { const char* e = std::getenv("PRG_SPLIT_P64"); return e ? std::atoi(e) : 256; }();
+    if (p64_min > 0 && d.Cout == 64 && W % 16 == 0 && H % 16 == 0 && !L.residual && !L.res_a && d.B * (W / 16) * (H / 16) >= p64_min &&
+        (d.C0 + d.C1) >= 64) {
+      const int tiles = (W / 16) * (H / 16) * 4;
+      const int f = want_stats && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 && tiles <= kGnMaxSplit;
+      if (f || !want_stats) { rc = launch_split_p64(L, s, f, gn_nsplit_out); return rc ? rc : 1; }
     }
     static const int pref32 = [] { const char* e = std::getenv("PRG_SPLIT_TW32"); return e ? std::atoi(e) : 0; }();
     if (pref32 && W % 32 == 0 && H % 4 == 0) { rc = launch_split_halo<4, 32>(L, s, fuse(4, 32, 64), gn_nsplit_out); return rc ? rc : 1; }

@@ -954,7 +954,16 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
       const bool ok = (hedge[k] & ld_tedge) == 0 && !(PRG_W256_EXP & 2);   // 2: timing experiment, every unit loads the tile origin
       const unsigned pix = ok ? hpix[k] : ld_dummy;
       const unsigned voff = __umul24(pix, ld_cs2) + (unsigned)(slot * 16);
-      hreg[k] = *reinterpret_cast<const w2_u32x4*>(ld_base + voff);
+      if constexpr (!PRO && (PRG_W256_EXP & 64)) {
+        // 64: CAP EXPERIMENT (tools/gpu_r5_mxcap.sh): what "MX activations in memory" could buy at most — the unit gathers 8 bytes
+        // (as if the producer had stored e4m3) plus one dword standing in for the block scales, and write_unit stores them as they
+        // are (masked to finite e4m3, scale 1): HALF the gather bytes, NO quantisation arithmetic.  Results are meaningless.
+        const uint2 h = *reinterpret_cast<const uint2*>(ld_base + (voff >> 1));
+        const unsigned sc = *reinterpret_cast<const unsigned*>(ld_base + ((voff >> 5) << 2));
+        hreg[k] = w2_u32x4{h.x, h.y, sc, 0u};
+      } else {
+        hreg[k] = *reinterpret_cast<const w2_u32x4*>(ld_base + voff);
+      }
       hvalid_nxt |= (ok ? 1u : 0u) << k;
     };
     // one unit = 8 channels of one halo pixel: optional prologue (its result rounded to bf16, like the tensor it replaces),
@@ -973,6 +982,11 @@ __global__ __launch_bounds__(512) void conv3x3_w256mx_kernel(const ConvLaunch<bf
           v[j] = w2_pack(w2_silu(fmaf(w2_lo(v[j]), a8[2 * j], b8[2 * j])), w2_silu(fmaf(w2_hi(v[j]), a8[2 * j + 1], b8[2 * j + 1])));
       }
       if (!((hvalid >> k) & 1u)) v = w2_u32x4{0u, 0u, 0u, 0u};
+      if constexpr (!PRO && (PRG_W256_EXP & 64)) {          // cap experiment (see issue_unit): finite e4m3 bytes, unit scale
+        *reinterpret_cast<uint2*>(Ah0 + buf * G::AH + k * RPP * MXROW) = make_uint2(v[0] & 0x77777777u, v[1] & 0x77777777u);
+        Hs0[buf * G::HS + k * RPP * 2] = (unsigned char)(127u + (v[2] & 0u));
+        return;
+      }
       if (PRG_W256_EXP & 32) {                               // timing experiment: no quantisation arithmetic
         *reinterpret_cast<uint2*>(Ah0 + buf * G::AH + k * RPP * MXROW) = make_uint2(v[0], v[1]);
         return;

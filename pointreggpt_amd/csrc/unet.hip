@@ -708,7 +708,7 @@ struct UnetImpl : prg_unet {
     bool stem_done = false;
     if constexpr (std::is_same<T, bf16_t>::value) {
       if (!arena.dry && d_stem_frag && stem_conv_mfma_supported(L.cfg.in_channels, d0, S, S)) {
-        if ((rc = launch_stem_conv_mfma(x_nchw, d_stem_frag, F(L.stem_b), x0, B, S, S, s))) return rc;
+        if ((rc = launch_stem_conv_mfma(x_nchw, d_stem_frag, F(L.stem_b), x0, B, L.cfg.in_channels, S, S, s))) return rc;
         stem_done = true;
       }
     }
@@ -1135,9 +1135,10 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
   }
   if (hipMalloc(&u->d_tickets, kMaxTicketImages * sizeof(int)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(tickets)");
   PRG_HIP(hipMemset(u->d_tickets, 0, kMaxTicketImages * sizeof(int)));
-  if (std::is_same<T, bf16_t>::value && L.cfg.in_channels == 1 && L.cfg.dim == 64) {
+  static const int stem3_on = [] { const char* e = std::getenv("PRG_STEM_MFMA3"); return e ? std::atoi(e) : 1; }();   // 0: MaskUnet's stem on the direct kernel
+  if (std::is_same<T, bf16_t>::value && (L.cfg.in_channels == 1 || (L.cfg.in_channels == 3 && stem3_on)) && L.cfg.dim == 64) {
     std::vector<bf16_t> sf;
-    pack_stem_mfma_weights(weights + L.stem_w, sf);
+    pack_stem_mfma_weights(weights + L.stem_w, L.cfg.in_channels, sf);
     if (hipMalloc(&u->d_stem_frag, sf.size() * sizeof(bf16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(stem fragments)");
     PRG_HIP(hipMemcpy(u->d_stem_frag, sf.data(), sf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
   }

@@ -130,6 +130,66 @@ def test_f16x3_subpixel_upsample_option(tmp_path):
     assert 0.0 < d <= 1e-5                                   # (> 0: the option really took the other kernel)
 
 
+_P64_CONV_SCRIPT = """
+import sys, json, ctypes as C, numpy as np, torch
+sys.path.insert(0, {root!r})
+from pointreggpt_amd import _lib
+lib = _lib.load()
+res = []
+for (B, Cin, H, Wd) in [(2, 64, 32, 32), (3, 64, 48, 32), (5, 128, 16, 48), (1, 64, 16, 16)]:
+    g = torch.Generator().manual_seed(Cin + H + Wd)
+    x = torch.nn.functional.silu(torch.randn((B, Cin, H, Wd), generator=g) * torch.exp(torch.randn((1, Cin, 1, 1), generator=g)))
+    w = torch.randn((64, Cin, 3, 3), generator=g)
+    bias = torch.randn((64,), generator=g)
+    out = torch.empty((B, 64, H, Wd), dtype=torch.float32, device="cuda")
+    wh, bh = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(bias.numpy())
+    _lib.check(lib.prg_debug_conv(_lib.ptr(x.cuda().contiguous()), wh.ctypes.data_as(C.c_void_p), bh.ctypes.data_as(C.c_void_p), _lib.ptr(out),
+                                  B, Cin, 64, H, Wd, _lib.PRG_F16X3, 3, 1, _lib.stream_ptr()), "prg_debug_conv")
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    ref_abs = torch.nn.functional.conv2d(x.double().abs(), w.double().abs(), None, padding=1)
+    err = (out.cpu().double() - ref).abs()
+    tol = 2.0 ** -19 * ref_abs + 2.0 ** -22 * ref.abs().max()
+    res.append(dict(shape=[B, Cin, H, Wd], max=float(err.max()), ok=bool((err <= tol).all()), sha=__import__("hashlib").sha256(out.cpu().numpy().tobytes()).hexdigest()))
+print("RES " + json.dumps(res))
+"""
+
+
+def test_f16x3_persistent_c64_kernel(tmp_path):
+    """Round 5: conv3x3_split_p64_kernel (persistent, wave-specialised, Cout = 64) — forced at small shapes (PRG_SPLIT_P64=1: from one
+    tile) so that workgroups own several tiles, uneven tile counts per XCD, grids that are not multiples of 8, one- and four-chunk
+    K — against float64 convolutions, and BIT FOR BIT against the symmetric kernel it replaces (PRG_SPLIT_P64=0): the same MFMA
+    sequence per accumulator, the same 288-term partials, the same epilogue expression.  Then the whole dim-64 U-Net at 128 x 128
+    both ways (fused prologue, two-source and Upsample launches, fused GroupNorm slabs) against the reference."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in {"p64": {"PRG_SPLIT_P64": "1"}, "symmetric": {"PRG_SPLIT_P64": "0"}}.items():
+        r = subprocess.run([sys.executable, "-c", _P64_CONV_SCRIPT.format(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RES ")][-1][4:])
+    for a, b in zip(outs["p64"], outs["symmetric"]):
+        print(f"split conv {a['shape']}: persistent max err {a['max']:.3e}, symmetric {b['max']:.3e}, identical bits {a['sha'] == b['sha']}")
+        assert a["ok"] and b["ok"]
+        assert a["sha"] == b["sha"], a["shape"]
+    gold = os.path.join(root, "tests", "golden", "G13_unet_dim64_128.npz")
+    ref = np.load(gold)["y"].astype(np.float64)
+    ys = {}
+    for name, env in {"p64": {"PRG_SPLIT_P64": "1"}, "symmetric": {"PRG_SPLIT_P64": "0"}}.items():
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", _UP_SCRIPT.format(root=root, gold=gold, out=out)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ys[name] = np.load(out)["y"].astype(np.float64)
+        e = float(np.abs(ys[name] - ref).max())
+        print(f"f16x3 U-Net, 64-channel convs on the {name} kernel: max err vs reference {e:.3e}")
+        assert e <= 2e-5
+    dd = float(np.abs(ys["p64"] - ys["symmetric"]).max())
+    print(f"persistent vs symmetric: {dd:.3e}")
+    assert 0.0 < dd <= 1e-5                                  # (> 0: the GroupNorm slab partition differs, so the option really took the other kernel)
+
+
 @pytest.mark.parametrize("dim", [8, 16])
 def test_unet_small_f16x3(hip, golden, dim):
     """dim 8 / 16 networks (ragged 32-channel chunks, Cout below a tile): every conv on the gather kernel."""

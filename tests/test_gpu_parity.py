@@ -1448,6 +1448,29 @@ def test_bench_gpus_flag_spawns_its_own_ranks(tmp_path):
         assert r.returncode != 0 and "HIP device" in r.stderr
 
 
+def test_maskunet_stem_on_mfma(hip, golden):
+    """Round 5: MaskUnet's 7x7 stem over the three DepthAugment planes runs on the MFMA stem kernel in bf16 mode
+    (stem_mfma_kernel<3>: hi / lo split inputs and weights, ~16 significant bits) instead of the direct VALU kernel (541 us per
+    call, 3.9e7 LDS bank conflicts).  Its output tensor against the float32 handle's (the direct fmaf chain, bit-identical to
+    torch): the only difference allowed is the bf16 rounding of the stored result."""
+    g = golden("G15_maskunet_dim64_128")
+    sd = W.synth_state_dict(W.maskunet_config(64), 15, final_bias=6.0)
+    x = D(g["depth"])
+    B = x.shape[0]
+    taps = {}
+    for dt in ("fp32", "bf16"):
+        net = hip.MaskUnet(64, dtype=dt).load_state_dict(sd)
+        net.set_taps(True)
+        net(x)
+        taps[dt] = net.get_tap("init_conv", B).double().cpu()
+        net.close()
+    ref, got = taps["fp32"], taps["bf16"]
+    err = (got - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 1e-4                    # half an ulp of bf16 is 2^-9 relative; the split GEMM itself carries ~2^-16
+    print(f"MaskUnet stem on MFMA: max |bf16 - fp32| {float(err.max()):.3e} on |ref| <= {float(ref.abs().max()):.2f}")
+    assert bool((err <= tol).all()), float((err - tol).max())
+
+
 def test_bench_eight_ranks_rehearsal_on_one_device(tmp_path):
     """Round 5: the 8-rank launch the driver runs on an 8-GPU node, rehearsed on the one device with
     the gloo backend at a tiny shape: eight ranks, ONE JSON line, n_gpus == 8, value = 8 ranks' pairs / max-over-ranks time, a

@@ -11,6 +11,7 @@ import sys
 
 SHAPES = [  # (label, B, Cin, Cout, H, W, K, stride)
     ("L0 64->64 @128", 64, 64, 64, 128, 128, 3, 1),
+    ("L0 128->64 @128 (K=1152)", 64, 128, 64, 128, 128, 3, 1),
     ("L1 64->64 @64", 64, 64, 64, 64, 64, 3, 1),
     ("L2 128->128 @32", 64, 128, 128, 32, 32, 3, 1),
     ("L3 256->256 @16", 64, 256, 256, 16, 16, 3, 1),
