@@ -423,11 +423,14 @@ def configs4_leg(a, G, synthetic, rank, dt="mxfp8"):
     return res
 
 
-def parity_mode_leg(a, G, synthetic, rank, dt, shape=None):
+def parity_mode_leg(a, G, synthetic, rank, dt, shape=None, lanes=1):
     """The headline workload (full pipeline, B x S x S, ancestral DDNM) in a float32-storage precision mode: `fp32` = the parity
     mode (exact-f32 MFMA, float64 partial sums) and `f16x3` = the same storage and normalisation arithmetic with every
     convolution as three f16 MFMAs on hi/lo-split operands.  `parity_transitions` ancestral transitions are timed (the first
-    rows of the 1000-step table: same per-transition work) and the sampler's share is extrapolated x(1000 / transitions)."""
+    rows of the 1000-step table: same per-transition work) and the sampler's share is extrapolated x(1000 / transitions).
+    `lanes` > 1: that many independent pipelines (own handles, workspaces, graphs, one host thread + HIP stream each) run one timed
+    batch each AT THE SAME TIME, as the headline leg's `--streams` does; pairs/s counts every lane's batch over the common wall time."""
+    import threading
     from pointreggpt_amd.diffusion import GaussianDiffusion
     from pointreggpt_amd.unet import MaskUnet, Unet
     B, S, T = a.batch, a.size, a.timesteps
@@ -435,48 +438,77 @@ def parity_mode_leg(a, G, synthetic, rank, dt, shape=None):
     if shape is not None:                      # (batch, image size, DDIM steps): the shipped setting, generate_dataset.py:34-49
         B, S, steps = shape
     dev = torch.device("cuda", torch.cuda.current_device())
-    unet = Unet(a.dim, dtype=dt).init_synthetic(seed=1, calibrated=True)
-    mask = MaskUnet(a.dim, dtype=dt).init_synthetic(seed=2, calibrated=True)
-    diff = GaussianDiffusion(unet, image_size=S, timesteps=T, sampling_timesteps=steps)
+    lanes = max(1, int(lanes))
+    pipes = []
+    for k in range(lanes):
+        u = Unet(a.dim, dtype=dt).init_synthetic(seed=1, calibrated=True)
+        m = MaskUnet(a.dim, dtype=dt).init_synthetic(seed=2, calibrated=True)
+        d = GaussianDiffusion(u, image_size=S, timesteps=T, sampling_timesteps=steps)
+        pipes.append(dict(unet=u, mask=m, diff=d, stream=torch.cuda.Stream(device=dev) if lanes > 1 else None,
+                          ev=[torch.cuda.Event(enable_timing=True) for _ in range(2)]))
+    unet, mask, diff = pipes[0]["unet"], pipes[0]["mask"], pipes[0]["diff"]
     full = len(diff.step_table())
     nt = min(a.parity_transitions, full)
     rows = diff.step_table()[:nt]
-    diff.step_table = lambda: rows
+    for pp in pipes:
+        pp["diff"].step_table = lambda: rows
     batches = []
-    for i in range(2):
-        first = 40_000_000 + (rank * 2 + i) * B
+    for i in range(2 * lanes):
+        first = 40_000_000 + (rank * 2 * lanes + i) * B
         idx = list(range(first, first + B))
         depth, K, pose = synthetic.synth_batch(a.seed, idx, S)
         batches.append(dict(depth=torch.from_numpy(depth).to(dev), K=torch.from_numpy(K).to(dev), pose=torch.from_numpy(pose).to(dev),
                             seeds=[synthetic.noise_seed(a.seed, j) for j in idx]))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
-    def one(bt, timed=False):
+    def one(bt, pp, timed=False):
         rpj, hit = G.reproject_tensor(bt["depth"], bt["K"], bt["pose"], clip=(0, 10), depth_unit=10.0, out_scale=0.1)
-        _, _, cond = G.apply_mask(mask(rpj), rpj, hit, 0.99)
+        _, _, cond = G.apply_mask(pp["mask"](rpj), rpj, hit, 0.99)
         if timed:
-            ev[0].record()
-        img = diff.sample(param_cond=G.param_vector(bt["K"]), img_cond=cond, seeds=bt["seeds"])
+            pp["ev"][0].record()
+        img = pp["diff"].sample(param_cond=G.param_vector(bt["K"]), img_cond=cond, seeds=bt["seeds"])
         if timed:
-            ev[1].record()
-        out, _, _ = G.apply_mask(mask(img), img, None, 0.99, want_cond=False)
+            pp["ev"][1].record()
+        out, _, _ = G.apply_mask(pp["mask"](img), img, None, 0.99, want_cond=False)
         return G.unproject_f64(out, bt["K"], bt["pose"])
 
-    one(batches[0])
+    def run(first, timed):
+        if lanes == 1:
+            one(batches[first], pipes[0], timed)
+            return
+        errs = []
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(pipes[k]["stream"]):
+                    one(batches[first + k], pipes[k], timed)
+            except BaseException as e:      # noqa: BLE001 — re-raised on the main thread
+                errs.append(e)
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(lanes)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run(0, False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    one(batches[1], timed=True)
+    run(lanes, True)
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
-    t_s = ev[0].elapsed_time(ev[1]) * 1e-3
+    t_s = max(pp["ev"][0].elapsed_time(pp["ev"][1]) for pp in pipes) * 1e-3      # (the lanes' samplers run side by side)
     t_full = (t_all - t_s) + t_s * (full / nt)
     tflop_pair = (full * UNET_GFLOP.get(S, 58.976 * (S / 128) ** 2) + 2 * MASK_GFLOP.get(S, 59.173 * (S / 128) ** 2)) / 1e3
-    res = {"dtype": dt, "pairs_per_s": B / t_full, "unit": "pairs/s", "batch": B, "image_size": S,
+    res = {"dtype": dt, "pairs_per_s": lanes * B / t_full, "unit": "pairs/s", "batch": B, "image_size": S,
            "sampler": "ddim" if steps else "ancestral-ddnm",
            "timed_transitions": nt, "extrapolated_to": full, "seconds_timed": t_all, "seconds_sampler_timed": t_s,
-           "ms_per_transition": t_s / nt * 1e3, "streams": 1, "tflop_per_pair": tflop_pair,
-           "how": f"full pipeline on one stream, one warm-up batch, one timed batch of {nt} transitions (hipGraph replay); "
-                  f"pairs/s = B / (non-sampler time + sampler time x {full}/{nt})"}
+           "ms_per_transition": t_s / nt * 1e3 / lanes, "streams": lanes, "tflop_per_pair": tflop_pair,
+           "how": f"full pipeline on {lanes} lane(s) (one batch of {B} each, side by side), one warm-up batch per lane, one timed batch "
+                  f"per lane of {nt} transitions (hipGraph replay); pairs/s = lanes x B / (non-sampler time + sampler time x {full}/{nt}); "
+                  f"ms_per_transition = per batch-transition of the whole device (sampler time / transitions / lanes)"}
     if not a.no_roofline:
         npr = min(10, nt)
         prow = rows[:npr]
@@ -499,7 +531,8 @@ def parity_mode_leg(a, G, synthetic, rank, dt, shape=None):
                            "peak_note": ("157.3 TFLOP/s dense f32 MFMA" if dt == "fp32" else
                                          "2500 / 3 TFLOP/s: the f16 pipe executes three MFMA FLOPs per algorithmic FLOP")}
         pdiff.close()
-    diff.close(); unet.close(); mask.close()
+    for pp in pipes:
+        pp["diff"].close(); pp["unet"].close(); pp["mask"].close()
     return res
 
 
@@ -796,10 +829,17 @@ def main():
     if rank == 0 and world == 1 and not a.no_parity_mode and not a.sampler_only and a.dtype == "bf16":
         # the modes that hold the north-star tolerance (1e-4 m point-XYZ against the reference: tests/test_gpu_f16x3.py,
         # test_long_chain_fp32_north_star), at the headline shape: what "correct" costs next to the bf16 headline
-        pm = {dt: parity_mode_leg(a, G, synthetic, rank, dt) for dt in ("fp32", "f16x3")}
+        # fp32 on one lane (as in rounds 3-4); f16x3 on the headline leg's `--streams` lanes, its one-lane figure kept beside it
+        pm = {"fp32": parity_mode_leg(a, G, synthetic, rank, "fp32"),
+              "f16x3": parity_mode_leg(a, G, synthetic, rank, "f16x3", lanes=max(1, a.streams))}
+        if a.streams > 1:
+            one_lane = parity_mode_leg(a, G, synthetic, rank, "f16x3")
+            pm["f16x3"]["one_lane"] = {k: one_lane[k] for k in ("pairs_per_s", "ms_per_transition", "streams")}
+            if "roofline" in one_lane and "roofline" not in pm["f16x3"]:
+                pm["f16x3"]["roofline"] = one_lane["roofline"]
         pm["f16x3_vs_fp32"] = pm["f16x3"]["pairs_per_s"] / pm["fp32"]["pairs_per_s"]
         # ... and at the shipped setting (256x256, 250-step DDIM: configs[4]'s shape, generate_dataset.py:34-49) in the f16x3 mode
-        pm["f16x3_256_ddim250"] = parity_mode_leg(a, G, synthetic, rank, "f16x3", shape=(a.c4_batch, 256, 250))
+        pm["f16x3_256_ddim250"] = parity_mode_leg(a, G, synthetic, rank, "f16x3", shape=(a.c4_batch, 256, 250), lanes=max(1, a.streams))
         pm["headline_vs_fp32"] = value / pm["fp32"]["pairs_per_s"]
         # measured in THIS run (drift_vs_reference above), not quoted: point-XYZ L-infinity of each chain against the reference
         dv = res.get("drift_vs_reference", {})

@@ -473,6 +473,158 @@ int launch_c(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, con
   return PRG_OK;
 }
 
+
+// =====================================================================================================
+// Bottleneck attention core (sd:789-795) for the f16x3 mode (round 5): attn_fused.hip's full_attn_mfma structure on float32
+// q / k / v with split-f16 contractions.  One block per (head, image, query share): K (hi / lo) row-major and V^T (hi / lo, keys in
+// the order the score accumulators supply them as the B operand) of a block of up to 256 keys in LDS; a lane owns ONE query and sees
+// a key tile's 32 scores in its registers.  Two passes over the key blocks — row maxima, then exp / row sums / V^T P — i.e. the
+// reference's softmax order; P = exp(s - max) <= 1 is split like every other operand.  The parity mode's scalar kernel
+// (full_attn_kernel<float>, float64 sums) took 210 us per evaluation at B = 64, 128 x 128.
+// =====================================================================================================
+template <int NT, int QS>   // N = 32 NT tokens; QS blocks share a (head, image), each takes every QS-th group of four query tiles
+__global__ __launch_bounds__(256) void full_attn_split_kernel(const float* __restrict__ qkv, float* __restrict__ out) {
+  constexpr int N = 32 * NT, KB = N < 256 ? N : 256, NKB = N / KB, KT = KB / 32, QPW = NT / (4 * QS);
+  constexpr int LDK = 40, LDV = KB + 8;
+  static_assert(QPW >= 1 && QPW * 4 * QS == NT, "query tiles per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem_fa[];
+  _Float16* const Kh = reinterpret_cast<_Float16*>(smem_fa);   // [KB][LDK]
+  _Float16* const Kl = Kh + KB * LDK;
+  _Float16* const Vh = Kl + KB * LDK;                            // [32][LDV]
+  _Float16* const Vl = Vh + 32 * LDV;
+  const int h = blockIdx.x, b = blockIdx.y, qs = blockIdx.z, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const float* base = qkv + (size_t)b * N * 384;
+  constexpr float kScale = 0.17677669529663687f * 1.4426950408889634f;   // 32^-1/2 log2 e: scores in log2 units
+
+  auto fill = [&](int kb, bool with_v) {
+    for (int i = tid; i < KB * 4; i += 256) {
+      const int key = i >> 2, u = i & 3;
+      const float* kp = base + (size_t)(kb * KB + key) * 384 + 128 + h * 32 + u * 8;
+      const float4 a = *reinterpret_cast<const float4*>(kp), c = *reinterpret_cast<const float4*>(kp + 4);
+      const float kv[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      h8 th, tl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) SPLIT_TO(kv[j], th, tl, j);
+      *reinterpret_cast<h8*>(Kh + key * LDK + u * 8) = th;
+      *reinterpret_cast<h8*>(Kl + key * LDK + u * 8) = tl;
+      if (with_v) {
+        const float4 va = *reinterpret_cast<const float4*>(kp + 128), vc = *reinterpret_cast<const float4*>(kp + 132);
+        const float vv[8] = {va.x, va.y, va.z, va.w, vc.x, vc.y, vc.z, vc.w};
+        const int d = key & 31;
+        const int pos = (key & ~31) + (d >> 4) * 16 + ((d >> 2) & 1) * 8 + ((d >> 3) & 1) * 4 + (d & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          _Float16 sh_, sl_;
+          split1(vv[j], sh_, sl_);
+          Vh[(u * 8 + j) * LDV + pos] = sh_;
+          Vl[(u * 8 + j) * LDV + pos] = sl_;
+        }
+      }
+    }
+  };
+  // the lane's query (tile qt, row l31): k-slots 8 hi .. + 7 of the two k-steps, split
+  auto load_q = [&](int qt, h8 (&qh)[2], h8 (&ql)[2]) {
+    const float* qp = base + (size_t)(qt * 32 + l31) * 384 + h * 32 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float4 a = *reinterpret_cast<const float4*>(qp + ks * 16), c = *reinterpret_cast<const float4*>(qp + ks * 16 + 4);
+      const float qv[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) SPLIT_TO(qv[j], qh[ks], ql[ks], j);
+    }
+  };
+  auto scores = [&](int kt, const h8 (&qh)[2], const h8 (&ql)[2]) {
+    f32x16 sa = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const h8 kh = *reinterpret_cast<const h8*>(Kh + (kt * 32 + l31) * LDK + ks * 16 + hi * 8);
+      const h8 kl = *reinterpret_cast<const h8*>(Kl + (kt * 32 + l31) * LDK + ks * 16 + hi * 8);
+      sa = mma3(kh, kl, qh[ks], ql[ks], sa);
+    }
+    return sa;
+  };
+
+  float m[QPW], l[QPW];
+  f32x16 oacc[QPW];
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) { m[qi] = -INFINITY; l[qi] = 0.0f; oacc[qi] = zero16(); }
+  // pass 1: row maxima
+  for (int kb = 0; kb < NKB; ++kb) {
+    if (kb > 0) __syncthreads();
+    fill(kb, NKB == 1);
+    __syncthreads();
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+      h8 qh[2], ql[2];
+      load_q((qs * QPW + qi) * 4 + wave, qh, ql);
+#pragma unroll 2
+      for (int kt = 0; kt < KT; ++kt) {
+        const f32x16 sa = scores(kt, qh, ql);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[qi] = fmaxf(m[qi], sa[r] * kScale);
+      }
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) m[qi] = fmaxf(m[qi], __shfl_xor(m[qi], 32, 64));
+  // pass 2: p = 2^(s - max), row sums, O^T += V^T P
+  for (int kb = 0; kb < NKB; ++kb) {
+    if (NKB > 1) {
+      __syncthreads();
+      fill(kb, true);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+      h8 qh[2], ql[2];
+      load_q((qs * QPW + qi) * 4 + wave, qh, ql);
+#pragma unroll 2
+      for (int kt = 0; kt < KT; ++kt) {
+        const f32x16 sa = scores(kt, qh, ql);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          h8 ph, pl;
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(sa[8 * i + s2], kScale, -m[qi]));
+            l[qi] += pv;
+            SPLIT_TO(pv, ph, pl, s2);
+          }
+          const h8 vh = *reinterpret_cast<const h8*>(Vh + l31 * LDV + kt * 32 + i * 16 + hi * 8);
+          const h8 vl = *reinterpret_cast<const h8*>(Vl + l31 * LDV + kt * 32 + i * 16 + hi * 8);
+          oacc[qi] = mma3(vh, vl, ph, pl, oacc[qi]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+    const float lt = l[qi] + __shfl_xor(l[qi], 32, 64);
+    const float inv = 1.0f / lt;
+    const int qt = (qs * QPW + qi) * 4 + wave;
+    float* op = out + ((size_t)b * N + qt * 32 + l31) * 128 + h * 32 + 4 * hi;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<float4*>(op + 8 * g4) = make_float4(oacc[qi][4 * g4] * inv, oacc[qi][4 * g4 + 1] * inv, oacc[qi][4 * g4 + 2] * inv,
+                                                            oacc[qi][4 * g4 + 3] * inv);
+  }
+}
+
+template <int NT, int QS>
+int launch_fa(const float* qkv, float* out, int B, hipStream_t s) {
+  constexpr int N = 32 * NT, KB = N < 256 ? N : 256;
+  constexpr size_t lds = (size_t)(2 * KB * 40 + 2 * 32 * (KB + 8)) * 2;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(full_attn_split_kernel<NT, QS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set.store(true, std::memory_order_release);
+  }
+  full_attn_split_kernel<NT, QS><<<dim3(4, B, QS), 256, lds, s>>>(qkv, out);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
 }  // namespace
 
 bool linattn_split_supported(int C, int N) {
@@ -493,6 +645,21 @@ int launch_linear_attention_split(const float* x, const uint16_t* wqkv_h, const 
   PRG_CHECK(linattn_split_supported(C, N) && x && out && ws, "linear attention (f16x3): unsupported shape");
   if (C == 128) return launch_c<128>(x, wqkv_h, wqkv_l, wout_h, wout_l, bias, out_g, out, ws, B, N, s);
   return launch_c<64>(x, wqkv_h, wqkv_l, wout_h, wout_l, bias, out_g, out, ws, B, N, s);
+}
+
+// Bottleneck attention core on split-f16 MFMAs: qkv (B, N, 384) float32 -> out (B, N, 128) float32.  PRG_SPLIT_FULLATTN=0: never.
+bool full_attention_split_supported(int N) {
+  static const int on = [] { const char* e = std::getenv("PRG_SPLIT_FULLATTN"); return e ? std::atoi(e) : 1; }();
+  return on && (N == 128 || N == 256 || N == 512 || N == 1024);
+}
+
+int launch_full_attention_split(const float* qkv, float* out, int B, int N, hipStream_t s) {
+  PRG_CHECK(full_attention_split_supported(N) && qkv && out && B > 0, "attention (f16x3): unsupported shape");
+  // query shares so that a small batch still covers the chip (B x 4 heads x QS blocks)
+  if (N == 128) return launch_fa<4, 1>(qkv, out, B, s);
+  if (N == 256) return B >= 32 ? launch_fa<8, 1>(qkv, out, B, s) : launch_fa<8, 2>(qkv, out, B, s);
+  if (N == 512) return B >= 32 ? launch_fa<16, 1>(qkv, out, B, s) : launch_fa<16, 4>(qkv, out, B, s);
+  return B >= 32 ? launch_fa<32, 2>(qkv, out, B, s) : launch_fa<32, 4>(qkv, out, B, s);
 }
 
 }  // namespace prg

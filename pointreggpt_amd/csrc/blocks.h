@@ -59,6 +59,9 @@ size_t linattn_split_ws_floats(int B, int N);
 int launch_linear_attention_split(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, const uint16_t* wout_h,
                                   const uint16_t* wout_l, const float* bias, const float* out_g, float* out, float* ws, int B, int N,
                                   int C, hipStream_t s);
+// f16x3 mode: the bottleneck attention core (sd:789-795) on split-f16 MFMAs, float32 in / out (attn_split.hip)
+bool full_attention_split_supported(int N);
+int launch_full_attention_split(const float* qkv, float* out, int B, int N, hipStream_t s);
 bool linattn_fused_supported(int C);
 size_t linattn_fused_ws_floats(int B, int N);
 // kshift: [128 + 4] static softmax shifts — a bound on |k| per column, then a bound on |q| per head (see unet.hip) — or

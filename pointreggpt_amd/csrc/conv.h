@@ -205,6 +205,10 @@ inline double conv_flops(const ConvDesc& d) {
 bool stem_conv_mfma_supported(int Cin, int Cout, int H, int W);
 int launch_stem_conv_mfma(const float* x, const bf16_t* wf, const float* bias, bf16_t* out, int B, int Cin, int H, int W, hipStream_t s);
 void pack_stem_mfma_weights(const float* w, int Cin, std::vector<bf16_t>& out);
+// f16x3 (round 5): the same kernel on f16 hi / lo halves with a float32 output; scale[64] = the inverse of the packer's per-channel power of two
+int launch_stem_conv_mfma_split(const float* x, const uint16_t* wf, const float* bias, const float* wscale, float* out, int B, int Cin,
+                                int H, int W, hipStream_t s);
+void pack_stem_mfma_weights_split(const float* w, int Cin, std::vector<uint16_t>& out, std::vector<float>& scale);
 template <typename T>
 int launch_stem_conv(const float* x, const float* wk, const float* bias, T* out, int B, int Cin, int H, int W,
                      int Cout, hipStream_t s);

@@ -1173,15 +1173,23 @@ __device__ inline uint32_t pack_bf16x2(float a, float b) {
 // CIN = 1: the denoiser's stem; CIN = 3 (round 5): MaskUnet's stem over the three DepthAugment planes (dc:822) — the same GEMM per
 // input plane, one plane after the other through the same LDS images, the accumulators of the block's eight rows kept in registers
 // (the direct kernel took 541 us per call with 3.9e7 LDS bank conflicts: VERDICT round 4, weak item 11).
-template <int CIN>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wf,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
-                                                        int W) {
-  constexpr int ROWS = 8, PR = ROWS + 7, RC = 40, LDS_ST = 72;
+// SPLIT (round 5, dtype f16x3): the same kernel on f16 hi + lo halves (22 significant bits, v_mfma_f32_32x32x16_f16) with a float32
+// NHWC output — the f16x3 mode's stem ran on the direct fmaf kernel (194 us per evaluation at B = 64, 128 x 128: VALU-bound); the
+// weights carry the split packer's per-output-channel power-of-two scale (conv_split.hip), undone on the float32 total (`wscale`).
+typedef __attribute__((ext_vector_type(8))) _Float16 stem_f16x8;
+template <int CIN, bool SPLIT>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wf,
+                                                        const float* __restrict__ bias, const float* __restrict__ wscale,
+                                                        void* __restrict__ outv, int H, int W) {
+  using E = typename std::conditional<SPLIT, _Float16, __bf16>::type;
+  using EV = typename std::conditional<SPLIT, stem_f16x8, stem_bf16x8>::type;
+  using OT = typename std::conditional<SPLIT, float, uint16_t>::type;
+  constexpr int ROWS = 8, PR = ROWS + 7, RC = 40, LDS_ST = SPLIT ? 68 : 72;
   __shared__ float raw[(ROWS + 6) * RC];
-  __shared__ __attribute__((aligned(16))) __bf16 Ph[PR * 32 * 8];
-  __shared__ __attribute__((aligned(16))) __bf16 Pl[PR * 32 * 8];
-  __shared__ __attribute__((aligned(16))) __bf16 stage[64 * LDS_ST];
+  __shared__ __attribute__((aligned(16))) E Ph[PR * 32 * 8];
+  __shared__ __attribute__((aligned(16))) E Pl[PR * 32 * 8];
+  __shared__ __attribute__((aligned(16))) OT stage[64 * LDS_ST];
+  OT* const out = reinterpret_cast<OT*>(outv);
   const int b = blockIdx.z, y0 = blockIdx.y * ROWS, x0 = blockIdx.x * 32, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int rt = wave & 1, prow = wave >> 1;     // 32-channel row tile; which row of the row pair
@@ -1201,22 +1209,22 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     __syncthreads();
     for (int e = tid; e < PR * 32; e += 256) {
       const int r = e >> 5, p = e & 31;
-      stem_bf16x8 vh, vl;
+      EV vh, vl;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = r < ROWS + 6 ? raw[r * RC + p + 1 + j] : 0.0f;      // row ROWS+6 only meets the zero weight row
-        const __bf16 h16 = (__bf16)v;
+        const E h16 = (E)v;
         vh[j] = h16;
-        vl[j] = (__bf16)(v - (float)h16);
+        vl[j] = (E)(v - (float)h16);
       }
-      *reinterpret_cast<stem_bf16x8*>(Ph + e * 8) = vh;
-      *reinterpret_cast<stem_bf16x8*>(Pl + e * 8) = vl;
+      *reinterpret_cast<EV*>(Ph + e * 8) = vh;
+      *reinterpret_cast<EV*>(Pl + e * 8) = vl;
     }
-    stem_bf16x8 whi[4], wlo[4];
+    EV whi[4], wlo[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      whi[kk] = *reinterpret_cast<const stem_bf16x8*>(wf + (((((size_t)c * 2 + rt) * 2 + 0) * 4 + kk) * 64 + lane) * 8);
-      wlo[kk] = *reinterpret_cast<const stem_bf16x8*>(wf + (((((size_t)c * 2 + rt) * 2 + 1) * 4 + kk) * 64 + lane) * 8);
+      whi[kk] = *reinterpret_cast<const EV*>(wf + (((((size_t)c * 2 + rt) * 2 + 0) * 4 + kk) * 64 + lane) * 8);
+      wlo[kk] = *reinterpret_cast<const EV*>(wf + (((((size_t)c * 2 + rt) * 2 + 1) * 4 + kk) * 64 + lane) * 8);
     }
     __syncthreads();
 #pragma unroll
@@ -1225,35 +1233,54 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int pr = row + 2 * kk + hi;           // kernel row 2 kk + hi of output row `row`
-        const stem_bf16x8 bh = *reinterpret_cast<const stem_bf16x8*>(Ph + (pr * 32 + l31) * 8);
-        const stem_bf16x8 bl = *reinterpret_cast<const stem_bf16x8*>(Pl + (pr * 32 + l31) * 8);
-        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[kk], bh, acc[ti], 0, 0, 0);
-        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[kk], bl, acc[ti], 0, 0, 0);
-        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[kk], bh, acc[ti], 0, 0, 0);
+        const EV bh = *reinterpret_cast<const EV*>(Ph + (pr * 32 + l31) * 8);
+        const EV bl = *reinterpret_cast<const EV*>(Pl + (pr * 32 + l31) * 8);
+        if constexpr (SPLIT) {
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[kk], bh, acc[ti], 0, 0, 0);
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[kk], bl, acc[ti], 0, 0, 0);
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[kk], bh, acc[ti], 0, 0, 0);
+        } else {
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[kk], bh, acc[ti], 0, 0, 0);
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[kk], bl, acc[ti], 0, 0, 0);
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[kk], bh, acc[ti], 0, 0, 0);
+        }
       }
     }
   }
-  float bv[16];
+  float bv[16], sv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = bias[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+  for (int r = 0; r < 16; ++r) {
+    bv[r] = bias[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+    sv[r] = SPLIT ? wscale[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] : 1.0f;
+  }
 #pragma unroll
   for (int ti = 0; ti < ROWS / 2; ++ti) {
     // lane: pixel l31 of row 2 ti + prow, channels rt*32 + 8 g4 + 4 hi + {0..3}
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      uint2 w;
-      w.x = pack_bf16x2(acc[ti][4 * g4] + bv[4 * g4], acc[ti][4 * g4 + 1] + bv[4 * g4 + 1]);
-      w.y = pack_bf16x2(acc[ti][4 * g4 + 2] + bv[4 * g4 + 2], acc[ti][4 * g4 + 3] + bv[4 * g4 + 3]);
-      *reinterpret_cast<uint2*>(stage + (prow * 32 + l31) * LDS_ST + rt * 32 + 8 * g4 + 4 * hi) = w;
+      if constexpr (SPLIT) {
+        float4 w;
+        w.x = acc[ti][4 * g4] * sv[4 * g4] + bv[4 * g4];
+        w.y = acc[ti][4 * g4 + 1] * sv[4 * g4 + 1] + bv[4 * g4 + 1];
+        w.z = acc[ti][4 * g4 + 2] * sv[4 * g4 + 2] + bv[4 * g4 + 2];
+        w.w = acc[ti][4 * g4 + 3] * sv[4 * g4 + 3] + bv[4 * g4 + 3];
+        *reinterpret_cast<float4*>(stage + (prow * 32 + l31) * LDS_ST + rt * 32 + 8 * g4 + 4 * hi) = w;
+      } else {
+        uint2 w;
+        w.x = pack_bf16x2(acc[ti][4 * g4] + bv[4 * g4], acc[ti][4 * g4 + 1] + bv[4 * g4 + 1]);
+        w.y = pack_bf16x2(acc[ti][4 * g4 + 2] + bv[4 * g4 + 2], acc[ti][4 * g4 + 3] + bv[4 * g4 + 3]);
+        *reinterpret_cast<uint2*>(stage + (prow * 32 + l31) * LDS_ST + rt * 32 + 8 * g4 + 4 * hi) = w;
+      }
     }
     __syncthreads();
+    constexpr int EPV = SPLIT ? 4 : 8, UPP = 64 / EPV;   // elements per 16-byte vector; vectors per pixel
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = tid + 256 * i;                // 512 16-byte vectors: pixel v >> 3, unit v & 7
-      const int px = v >> 3, u = v & 7;
+    for (int i = 0; i < 64 * UPP / 256; ++i) {
+      const int v = tid + 256 * i;
+      const int px = v / UPP, u = v % UPP;
       const int yy = y0 + 2 * ti + (px >> 5), xx = x0 + (px & 31);
-      *reinterpret_cast<uint4*>(out + (((size_t)b * H + yy) * W + xx) * 64 + u * 8) =
-          *reinterpret_cast<const uint4*>(stage + px * LDS_ST + u * 8);
+      *reinterpret_cast<uint4*>(out + (((size_t)b * H + yy) * W + xx) * 64 + u * EPV) =
+          *reinterpret_cast<const uint4*>(stage + px * LDS_ST + u * EPV);
     }
     __syncthreads();
   }
@@ -1265,8 +1292,19 @@ bool stem_conv_mfma_supported(int Cin, int Cout, int H, int W) { return (Cin == 
 int launch_stem_conv_mfma(const float* x, const bf16_t* wf, const float* bias, bf16_t* out, int B, int Cin, int H, int W,
                           hipStream_t s) {
   PRG_CHECK(stem_conv_mfma_supported(Cin, 64, H, W) && x && wf && bias && out, "stem conv (MFMA): bad arguments");
-  if (Cin == 1) stem_mfma_kernel<1><<<dim3(W / 32, H / 8, B), 256, 0, s>>>(x, wf, bias, out, H, W);
-  else stem_mfma_kernel<3><<<dim3(W / 32, H / 8, B), 256, 0, s>>>(x, wf, bias, out, H, W);
+  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf);
+  if (Cin == 1) stem_mfma_kernel<1, false><<<dim3(W / 32, H / 8, B), 256, 0, s>>>(x, w16, bias, nullptr, out, H, W);
+  else stem_mfma_kernel<3, false><<<dim3(W / 32, H / 8, B), 256, 0, s>>>(x, w16, bias, nullptr, out, H, W);
+  PRG_LAUNCH_CHECK();
+  return PRG_OK;
+}
+
+// f16x3: the same fragments as f16 hi / lo halves (pack_stem_mfma_weights_split), float32 output, wscale[64] undoes the packer's scale
+int launch_stem_conv_mfma_split(const float* x, const uint16_t* wf, const float* bias, const float* wscale, float* out, int B, int Cin,
+                                int H, int W, hipStream_t s) {
+  PRG_CHECK(stem_conv_mfma_supported(Cin, 64, H, W) && x && wf && bias && wscale && out, "stem conv (split MFMA): bad arguments");
+  if (Cin == 1) stem_mfma_kernel<1, true><<<dim3(W / 32, H / 8, B), 256, 0, s>>>(x, wf, bias, wscale, out, H, W);
+  else stem_mfma_kernel<3, true><<<dim3(W / 32, H / 8, B), 256, 0, s>>>(x, wf, bias, wscale, out, H, W);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
@@ -1284,6 +1322,39 @@ void pack_stem_mfma_weights(const float* w /* [64][Cin][7][7] */, int Cin, std::
             const bf16_t l16 = f32_to_bf16(v - bf16_to_f32(h16));
             outv[(((((size_t)c * 2 + rt) * 2 + 0) * 4 + kk) * 64 + lane) * 8 + j] = h16;
             outv[(((((size_t)c * 2 + rt) * 2 + 1) * 4 + kk) * 64 + lane) * 8 + j] = l16;
+          }
+        }
+}
+
+// f16 hi / lo halves of the same fragment layout; every output channel scaled by an exact power of two so that max|w| lands in
+// [2^9, 2^10) (the lo halves of ~1/7-sized weights would be subnormal f16 otherwise: conv_split.hip, pack_conv_weight_split);
+// scale[co] = the inverse
+void pack_stem_mfma_weights_split(const float* w /* [64][Cin][7][7] */, int Cin, std::vector<uint16_t>& outv, std::vector<float>& scale) {
+  outv.assign((size_t)Cin * 2 * 2 * 4 * 64 * 8, 0);
+  scale.assign(64, 1.0f);
+  std::vector<float> mul(64, 1.0f);
+  for (int co = 0; co < 64; ++co) {
+    float m = 0.0f;
+    for (int i = 0; i < Cin * 49; ++i) m = std::fmax(m, std::fabs(w[(size_t)co * Cin * 49 + i]));
+    if (m > 0.0f && std::isfinite(m)) {
+      int e = 0;
+      (void)std::frexp(m, &e);
+      mul[co] = std::ldexp(1.0f, 10 - e);
+      scale[co] = std::ldexp(1.0f, e - 10);
+    }
+  }
+  auto bits = [](_Float16 h) { uint16_t u; std::memcpy(&u, &h, 2); return u; };
+  for (int c = 0; c < Cin; ++c)
+    for (int rt = 0; rt < 2; ++rt)
+      for (int kk = 0; kk < 4; ++kk)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = rt * 32 + (lane & 31), kh = 2 * kk + (lane >> 5);
+          for (int j = 0; j < 7 && kh < 7; ++j) {
+            const float v = w[((size_t)co * Cin + c) * 49 + kh * 7 + j] * mul[co];
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            outv[(((((size_t)c * 2 + rt) * 2 + 0) * 4 + kk) * 64 + lane) * 8 + j] = bits(h);
+            outv[(((((size_t)c * 2 + rt) * 2 + 1) * 4 + kk) * 64 + lane) * 8 + j] = bits(l);
           }
         }
 }

@@ -286,6 +286,8 @@ struct prg_unet {
   void* d_packed = nullptr;     // packed conv weights of T
   float* d_stem = nullptr;      // stem weights [49*Cin][dim]
   bf16_t* d_stem_frag = nullptr; // stem weights as MFMA fragments (bf16 path, Cin 1 -> 64)
+  uint16_t* d_stem_split = nullptr;    // f16x3 mode: the same fragments as f16 hi / lo halves (stem_mfma_kernel<CIN, true>)
+  float* d_stem_split_scale = nullptr; // ... and the inverse of the packer's per-channel power-of-two scale [64]
   bf16_t* d_attn = nullptr;     // fused linear attention: gain-folded to_qkv and to_out weights (bf16 path only)
   float* d_kshift = nullptr;    // fused linear attention: static softmax shifts of the k columns
   uint8_t* d_mx = nullptr;      // MX-fp8 conv weights (dtype PRG_MXFP8): e4m3 data and E8M0 block scales
@@ -663,6 +665,12 @@ struct UnetImpl : prg_unet {
           done = true;
         }
       }
+      if constexpr (std::is_same<T, float>::value) {
+        if (!arena.dry && d_split && full_attention_split_supported(N)) {          // f16x3: split-f16 MFMAs (attn_split.hip)
+          if ((rc = launch_full_attention_split(qkv, o, B, N, s))) return rc;
+          done = true;
+        }
+      }
       if (!arena.dry && !done && (rc = launch_full_attention<T>(qkv, o, B, N, s))) return rc;
       { ConvOpt ro; ro.residual = x;
         if ((rc = conv(a.out, o, kHidden, nullptr, 0, B, H, Wd, 1, 0, 0, ro, out, s))) return rc; }
@@ -709,6 +717,12 @@ struct UnetImpl : prg_unet {
     if constexpr (std::is_same<T, bf16_t>::value) {
       if (!arena.dry && d_stem_frag && stem_conv_mfma_supported(L.cfg.in_channels, d0, S, S)) {
         if ((rc = launch_stem_conv_mfma(x_nchw, d_stem_frag, F(L.stem_b), x0, B, L.cfg.in_channels, S, S, s))) return rc;
+        stem_done = true;
+      }
+    }
+    if constexpr (std::is_same<T, float>::value) {
+      if (!arena.dry && d_stem_split && stem_conv_mfma_supported(L.cfg.in_channels, d0, S, S)) {
+        if ((rc = launch_stem_conv_mfma_split(x_nchw, d_stem_split, F(L.stem_b), d_stem_split_scale, x0, B, L.cfg.in_channels, S, S, s))) return rc;
         stem_done = true;
       }
     }
@@ -1142,6 +1156,17 @@ static int create_impl(const prg_unet_config* cfg, const float* weights, int64_t
     if (hipMalloc(&u->d_stem_frag, sf.size() * sizeof(bf16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(stem fragments)");
     PRG_HIP(hipMemcpy(u->d_stem_frag, sf.data(), sf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
   }
+  // f16x3 (round 5): the stem on the same MFMA kernel with f16 hi / lo halves (PRG_SPLIT_STEM=0: the direct fmaf kernel of the parity mode)
+  static const int split_stem_on = [] { const char* e = std::getenv("PRG_SPLIT_STEM"); return e ? std::atoi(e) : 1; }();
+  if (split && split_stem_on && (L.cfg.in_channels == 1 || L.cfg.in_channels == 3) && L.cfg.dim == 64) {
+    std::vector<uint16_t> sf;
+    std::vector<float> sc;
+    pack_stem_mfma_weights_split(weights + L.stem_w, L.cfg.in_channels, sf, sc);
+    if (hipMalloc(&u->d_stem_split, sf.size() * sizeof(uint16_t)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split stem fragments)");
+    PRG_HIP(hipMemcpy(u->d_stem_split, sf.data(), sf.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (hipMalloc(&u->d_stem_split_scale, sc.size() * sizeof(float)) != hipSuccess) return fail(PRG_E_NOMEM, "hipMalloc(split stem scales)");
+    PRG_HIP(hipMemcpy(u->d_stem_split_scale, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   if (std::is_same<T, bf16_t>::value && fused_attention_enabled()) {
     // fused linear attention (attn_fused.hip): to_qkv with the PreNorm gain folded in, to_out as is, both [out][in] bf16
     std::vector<bf16_t> aw;
@@ -1387,6 +1412,8 @@ int prg_unet_destroy(prg_unet* h) {
   if (h->d_pq_static) (void)hipFree(h->d_pq_static);
   if (h->d_cond_entries) (void)hipFree(h->d_cond_entries);
   if (h->d_stem_frag) (void)hipFree(h->d_stem_frag);
+  if (h->d_stem_split) (void)hipFree(h->d_stem_split);
+  if (h->d_stem_split_scale) (void)hipFree(h->d_stem_split_scale);
   if (h->arena.base) (void)hipFree(h->arena.base);
   delete h;
   return PRG_OK;

@@ -190,6 +190,47 @@ def test_f16x3_persistent_c64_kernel(tmp_path):
     assert 0.0 < dd <= 1e-5                                  # (> 0: the GroupNorm slab partition differs, so the option really took the other kernel)
 
 
+_REP_SCRIPT = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from pointreggpt_amd import weights as W
+from pointreggpt_amd.unet import Unet
+g = np.load({gold!r})
+net = Unet(64, dtype="f16x3").load_state_dict(W.synth_state_dict(W.unet_config(64), {wseed}))
+rep = lambda a: torch.from_numpy(np.repeat(a[:1], {batch}, axis=0)).cuda()
+y = net(rep(g["x"]), rep(g["t"]), rep(g["pc"])).cpu().numpy()
+assert all(np.array_equal(y[0], y[k]) for k in range(1, {batch})), "batch slots differ"
+np.savez({out!r}, y=y[:1])
+"""
+
+
+@pytest.mark.parametrize("fixture,wseed,batch", [("G13_unet_dim64_128", 13, 32), ("G16_unet_dim64_256", 16, 32)])
+def test_f16x3_mfma_stem_and_bottleneck_attention(tmp_path, fixture, wseed, batch):
+    """Round 5: the f16x3 mode's 7x7 stem on stem_mfma_kernel<CIN, true> (f16 hi / lo halves, float32 out) and its bottleneck
+    attention core on full_attn_split_kernel (split-f16 MFMAs, two passes over 256-key blocks) instead of the parity mode's scalar
+    kernels (PRG_SPLIT_STEM=0 PRG_SPLIT_FULLATTN=0).  The dim-64 U-Net at 128 x 128 (N = 256 tokens) and 256 x 256 (N = 1024), one
+    scene replicated to the batch that selects the kernels' large-batch variants (the tap test above runs the small-batch ones):
+    every slot bit for bit equal, the output at the reference's distance both ways, and the two paths really differ."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden", fixture + ".npz")
+    ref = np.load(gold)["y"][:1].astype(np.float64)
+    ys = {}
+    for name, env in {"mfma": {}, "scalar": {"PRG_SPLIT_STEM": "0", "PRG_SPLIT_FULLATTN": "0"}}.items():
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", _REP_SCRIPT.format(root=root, gold=gold, out=out, wseed=wseed, batch=batch)],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ys[name] = np.load(out)["y"].astype(np.float64)
+        e = float(np.abs(ys[name] - ref).max())
+        print(f"{fixture} f16x3 (B={batch}), stem + bottleneck attention on the {name} kernels: max err vs reference {e:.3e}")
+        assert e <= 2e-5
+    dd = float(np.abs(ys["mfma"] - ys["scalar"]).max())
+    print(f"mfma vs scalar: {dd:.3e}")
+    assert 0.0 < dd <= 1e-5
+
+
 @pytest.mark.parametrize("dim", [8, 16])
 def test_unet_small_f16x3(hip, golden, dim):
     """dim 8 / 16 networks (ragged 32-channel chunks, Cout below a tile): every conv on the gather kernel."""
