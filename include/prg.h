@@ -185,6 +185,10 @@ int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float
  * K = 1 and 1 otherwise; w (Cout,Cin,K,K), out (B,Cout,Ho,Wo) float32.  Also accepts PRG_BF16 / PRG_MXFP8 for K = 3 / 4.  */
 int prg_debug_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                    int dtype, int K, int stride, void* stream);
+/* nn.Upsample(x2, nearest) + Conv2d(3, pad 1) (sd:592-594) in any storage mode (PRG_F16X3: the sub-pixel form of the split
+ * wave-specialised kernel when Cout % 128 == 0; round 5).  out: (B, Cout, 2H, 2W) float32. */
+int prg_debug_upsample_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                            int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler: GaussianDiffusion.sample / p_sample_loop / ddim_sample (sd:1283-1409), DDNM replacement included

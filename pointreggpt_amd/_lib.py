@@ -56,6 +56,7 @@ PROTOTYPES = {
     "prg_debug_upsample_conv3x3": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "prg_debug_conv4x4s2": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "prg_debug_conv": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "prg_debug_upsample_conv": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "prg_unet_set_taps": (C.c_int, [_P, _I]),
     "prg_unet_get_tap": (C.c_int, [_P, C.c_char_p, _P, _L, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P]),
     "prg_sampler_create": (C.c_int, [_P, C.POINTER(StepC), _I, _I, _I, C.POINTER(_P)]),

@@ -1674,9 +1674,13 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
     };
     // Cout % 128 == 0: the wave-specialised kernel (128-pixel x 128-channel tiles, one workgroup per CU); PRG_SPLIT_WS=0: never
     static const int ws_on = [] { const char* e = std::getenv("PRG_SPLIT_WS"); return e ? std::atoi(e) : 1; }();
-    // OFF by default: 2 % of an f16x3 evaluation (0.3 ms), and the same accuracy per evaluation — but every change of the rounding
-    // pattern re-draws the long chains' distance from the reference, and this one moves the 250-step DDIM chain G20 from 5.9e-5 m
-    // to 1.03e-4 m (mean error 3.2e-6 -> 3.4e-6 m): the mode's claim is the literal 1e-4 m on that chain, so the nine-tap form stays
+    // The Upsample convs as four 2 x 2-tap sub-pixel convolutions (4 / 9 of their MFMAs: 0.3 ms = 2.5 % of an f16x3 evaluation): OFF by
+    // default.  Per evaluation it is as accurate as the nine-tap form (test_split_upsample_conv_against_float64: rms 2.0e-7 against
+    // torch-CPU's 2.9e-7), but every change of the rounding pattern RE-DRAWS the long chains' distance from the reference — over nine
+    // equal-precision variants of the mode's arithmetic the 250-step 256 x 256 chain G21b sits anywhere in 3.7e-5 .. 8.8e-5 m at B = 1
+    // (profiles/r05_chain_metric_spread_f16x3.txt; the reference's own 1-vs-8-thread spread is 4.7e-5 m) — and round 5 tried it as the
+    // default: G21b drew 5.9e-5 m at B = 1 and 1.001e-4 m at B = 8 (the batch that selects the persistent 64-channel kernel).  The
+    // mode's claim is the LITERAL 1e-4 m on that chain at the tested batches, so the nine-tap form stays.  PRG_SPLIT_UP2X2=1: on.
     static const int up_on = [] { const char* e = std::getenv("PRG_SPLIT_UP2X2"); return e ? std::atoi(e) : 0; }();
     if (ws_on && up_on && d.ups && L.w_up_split && d.C1 == 0 && d.Cout % 128 == 0 && d.Win % 16 == 0 && d.Hin % 8 == 0 && d.Hout == 2 * d.Hin &&
         d.Wout == 2 * d.Win && !L.residual && !L.pro_a && !want_stats) {

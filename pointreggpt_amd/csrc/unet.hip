@@ -1485,9 +1485,9 @@ int prg_maskunet_forward(prg_unet* h, const float* depth, float* prob, int B, in
 // ---------------------------------------------------------------------------------------------
 // float32-storage handles (PRG_F32: the exact-f32 kernels; PRG_F16X3: the split-operand kernels of conv_split.hip)
 static int debug_conv_f32(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
-                          int dtype, int K, int stride, int pad, hipStream_t s) {
+                          int dtype, int K, int stride, int pad, hipStream_t s, int ups = 0) {
   const size_t M = (size_t)B * H * W;
-  const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+  const int Ho = ups ? 2 * H : (H + 2 * pad - K) / stride + 1, Wo = ups ? 2 * W : (W + 2 * pad - K) / stride + 1;
   const size_t Mo = (size_t)B * Ho * Wo;
   std::vector<float> packed;
   std::vector<uint16_t> sp;
@@ -1495,14 +1495,35 @@ static int debug_conv_f32(const float* x, const float* w, const float* bias, flo
   pack_conv_weight<float>(w, Cout, Cin, K, K, packed, &cp, &kc);
   std::vector<float> spsc;
   if (dtype == PRG_F16X3) pack_conv_weight_split(w, Cout, Cin, K, K, sp, &cp2, &kc32, &spsc);
+  // Upsample (nearest x2, then the 3x3): the sub-pixel form's four 2 x 2-tap packings, as create_impl builds them (ADVICE round 4:
+  // the UP form of conv3x3_split_ws_kernel gets a kernel-level test)
+  std::vector<uint16_t> spu;
+  std::vector<float> spusc;
+  if (ups && dtype == PRG_F16X3 && K == 3 && Cin % 32 == 0 && Cout % 128 == 0) {
+    std::vector<float> eq, sc1;
+    std::vector<uint16_t> one;
+    up_equivalent_weights(w, Cout, Cin, eq);
+    for (int ph = 0; ph < 4; ++ph) {
+      int cpu_ = 0, kcu_ = 0;
+      pack_conv_weight_split(eq.data() + (size_t)ph * Cout * Cin * 4, Cout, Cin, 2, 2, one, &cpu_, &kcu_, &sc1);
+      spu.insert(spu.end(), one.begin(), one.end());
+      spusc.insert(spusc.end(), sc1.begin(), sc1.end());
+    }
+  }
   std::vector<float> zb(Cout, 0.0f);
-  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_sp = nullptr, *d_sc = nullptr;
-  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_sp, d_sc}) if (p) (void)hipFree(p); };
+  void *d_in = nullptr, *d_out = nullptr, *d_w = nullptr, *d_b = nullptr, *d_sp = nullptr, *d_sc = nullptr, *d_spu = nullptr, *d_scu = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_w, d_b, d_sp, d_sc, d_spu, d_scu}) if (p) (void)hipFree(p); };
   if (hipMalloc(&d_in, M * Cin * 4) != hipSuccess || hipMalloc(&d_out, Mo * Cout * 4) != hipSuccess ||
       hipMalloc(&d_w, packed.size() * 4) != hipSuccess || hipMalloc(&d_b, Cout * 4) != hipSuccess ||
-      (!sp.empty() && (hipMalloc(&d_sp, sp.size() * 2) != hipSuccess || hipMalloc(&d_sc, spsc.size() * 4) != hipSuccess))) {
+      (!sp.empty() && (hipMalloc(&d_sp, sp.size() * 2) != hipSuccess || hipMalloc(&d_sc, spsc.size() * 4) != hipSuccess)) ||
+      (!spu.empty() && (hipMalloc(&d_spu, spu.size() * 2) != hipSuccess || hipMalloc(&d_scu, spusc.size() * 4) != hipSuccess))) {
     cleanup();
     return fail(PRG_E_NOMEM, "prg_debug_conv: hipMalloc failed");
+  }
+  if (d_spu && (hipMemcpy(d_spu, spu.data(), spu.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_scu, spusc.data(), spusc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+    cleanup();
+    return fail(PRG_E_HIP, "prg_debug_conv: hipMemcpy failed");
   }
   if (hipMemcpy(d_w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d_b, bias ? bias : zb.data(), Cout * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1514,13 +1535,15 @@ static int debug_conv_f32(const float* x, const float* w, const float* bias, flo
   int rc = launch_nchw_f32_to_nhwc<float>(x, reinterpret_cast<float*>(d_in), B, H * W, Cin, s);
   if (rc == PRG_OK) {
     ConvLaunch<float> L{};
-    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = 0; L.d.KH = K; L.d.KW = K; L.d.stride = stride; L.d.pad = pad;
+    L.d.B = B; L.d.Hin = H; L.d.Win = W; L.d.C0 = Cin; L.d.C1 = 0; L.d.ups = ups; L.d.KH = K; L.d.KW = K; L.d.stride = stride; L.d.pad = pad;
     L.d.Hout = Ho; L.d.Wout = Wo; L.d.Cout = Cout; L.d.CoutPad = cp; L.d.kchunks = kc;
     L.src0 = reinterpret_cast<const float*>(d_in); L.w = reinterpret_cast<const float*>(d_w);
     L.bias = reinterpret_cast<const float*>(d_b); L.out = reinterpret_cast<float*>(d_out);
     L.gn_groups = 8;
     L.w_split = reinterpret_cast<const uint16_t*>(d_sp); L.split_kchunks = kc32;
     L.split_scale = reinterpret_cast<const float*>(d_sc);
+    L.w_up_split = reinterpret_cast<const uint16_t*>(d_spu);
+    L.split_scale_up = reinterpret_cast<const float*>(d_scu);
     rc = launch_conv<float>(L, s, nullptr);
   }
   if (rc == PRG_OK) rc = launch_nhwc_to_nchw_f32<float>(reinterpret_cast<const float*>(d_out), out, B, Ho * Wo, Cout, s);
@@ -1535,7 +1558,7 @@ static int debug_conv(const float* x, const float* w, const float* bias, float* 
   PRG_CHECK(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0, "prg_debug_conv3x3: bad shape");
   PRG_CHECK(dtype == PRG_BF16 || dtype == PRG_MXFP8 || dtype == PRG_F32 || dtype == PRG_F16X3, "prg_debug_conv3x3: bad dtype");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == PRG_F32 || dtype == PRG_F16X3) return debug_conv_f32(x, w, bias, out, B, Cin, Cout, H, W, dtype, K, stride, K == 1 ? 0 : 1, s);
+  if (dtype == PRG_F32 || dtype == PRG_F16X3) return debug_conv_f32(x, w, bias, out, B, Cin, Cout, H, W, dtype, K, stride, K == 1 ? 0 : 1, s, ups);
   const size_t M = (size_t)B * H * W;
   const int Ho = ups ? 2 * H : H / stride, Wo = ups ? 2 * W : W / stride;
   const size_t Mo = (size_t)B * Ho * Wo;
@@ -1694,6 +1717,11 @@ int prg_debug_conv(const float* x, const float* w, const float* bias, float* out
 int prg_debug_upsample_conv3x3(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                                void* stream) {
   return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, PRG_BF16, 3, 1, stream, 1);
+}
+
+int prg_debug_upsample_conv(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                            int dtype, void* stream) {
+  return debug_conv(x, w, bias, out, B, Cin, Cout, H, W, dtype, 3, 1, stream, 1);
 }
 
 int prg_debug_conv4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,

@@ -78,6 +78,60 @@ def test_split_conv_against_float64(hip, B, Cin, Cout, H, Wd, K, stride):
     assert e32 <= 1.5 * c_rms + 1e-7, (e32, c_rms)
 
 
+_UPCONV_SCRIPT = """
+import sys, json, ctypes as C, numpy as np, torch
+sys.path.insert(0, {root!r})
+from pointreggpt_amd import _lib
+lib = _lib.load()
+res = []
+for (B, Cin, Cout, H, Wd) in [(2, 128, 128, 16, 16), (1, 256, 128, 8, 32), (1, 512, 256, 8, 16), (2, 128, 64, 16, 16)]:
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.nn.functional.silu(torch.randn((B, Cin, H, Wd), generator=g) * 2.0)
+    w = (torch.rand((Cout, Cin, 3, 3), generator=g) * 2 - 1) * (3.0 / (Cin * 9)) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    out = torch.empty((B, Cout, 2 * H, 2 * Wd), dtype=torch.float32, device="cuda")
+    wh = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    bh = np.ascontiguousarray(bias.numpy(), dtype=np.float32)
+    _lib.check(lib.prg_debug_upsample_conv(_lib.ptr(x.cuda().contiguous()), wh.ctypes.data_as(C.c_void_p), bh.ctypes.data_as(C.c_void_p),
+                                           _lib.ptr(out), B, Cin, Cout, H, Wd, _lib.PRG_F16X3, _lib.stream_ptr()), "prg_debug_upsample_conv")
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(up.double(), w.double(), bias.double(), padding=1)
+    ref_abs = torch.nn.functional.conv2d(up.double().abs(), w.double().abs(), None, padding=1)
+    cpu32 = torch.nn.functional.conv2d(up, w, bias, padding=1)
+    err = (out.cpu().double() - ref).abs()
+    tol = 2.0 ** -19 * ref_abs + 2.0 ** -22 * ref.abs().max()
+    res.append(dict(shape=[B, Cin, Cout, H, Wd], max=float(err.max()), rms=float(err.pow(2).mean().sqrt()),
+                    cpu_rms=float((cpu32.double() - ref).pow(2).mean().sqrt()), ok=bool((err <= tol).all()),
+                    sha=__import__("hashlib").sha256(out.cpu().numpy().tobytes()).hexdigest()))
+print("RES " + json.dumps(res))
+"""
+
+
+def test_split_upsample_conv_against_float64():
+    """nn.Upsample(x2, nearest) + Conv2d(3, pad 1) (sd:592-594) in the f16x3 mode, one kernel at a time through
+    prg_debug_upsample_conv (round 5), with PRG_SPLIT_UP2X2=1 — Cout % 128 == 0 takes the SUB-PIXEL form of the wave-specialised
+    split kernel (four 2 x 2-tap convolutions of the source image with pre-summed, per-channel-scaled split weights:
+    conv3x3_split_ws_kernel<NS, true>; ADVICE round 4 asked for a kernel-level test of it) — and with the default nine-tap gather:
+    both against a float64 convolution of the upsampled image, unstandardised (1 / sqrt(fan_in)) weights as the Upsample convs
+    have; the wide shapes must really differ between the two forms, the Cout = 64 shape (no sub-pixel form) must not."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in {"subpixel": {"PRG_SPLIT_UP2X2": "1"}, "nine_tap": {"PRG_SPLIT_UP2X2": "0"}}.items():
+        r = subprocess.run([sys.executable, "-c", _UPCONV_SCRIPT.format(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RES ")][-1][4:])
+        for a in outs[name]:
+            print(f"split Upsample conv {a['shape']} {name}: max {a['max']:.3e} rms {a['rms']:.3e}; torch-CPU fp32 rms {a['cpu_rms']:.3e}")
+            assert a["ok"], a
+            assert a["rms"] <= 4.0 * a["cpu_rms"] + 1e-7, a
+    for a, b in zip(outs["subpixel"], outs["nine_tap"]):
+        wide = a["shape"][2] % 128 == 0
+        assert (a["sha"] != b["sha"]) == wide, a["shape"]
+
+
 @pytest.mark.parametrize("fixture,wseed,B", [("G13_unet_dim64_128", 13, 2), ("G16_unet_dim64_256", 16, 1)])
 def test_unet_dim64_full_size_taps_f16x3(hip, golden, fixture, wseed, B):
     g = golden(fixture)
@@ -107,7 +161,7 @@ np.savez({out!r}, y=y.cpu().numpy())
 
 
 def test_f16x3_subpixel_upsample_option(tmp_path):
-    """PRG_SPLIT_UP2X2=1 (off by default, DESIGN 4.8): the two wide Upsample convs of the f16x3 mode as four 2 x 2-tap sub-pixel
+    """PRG_SPLIT_UP2X2=1 (off by default, DESIGN 4.6 / 4.8): the two wide Upsample convs of the f16x3 mode as four 2 x 2-tap sub-pixel
     convolutions (UP form of the wave-specialised split kernel, pre-summed split weights).  One dim-64 evaluation at 128 x 128
     against the reference with the option on and off: both inside the mode's per-evaluation bound, and within 1e-5 of each other."""
     import subprocess
@@ -116,7 +170,7 @@ def test_f16x3_subpixel_upsample_option(tmp_path):
     gold = os.path.join(root, "tests", "golden", "G13_unet_dim64_128.npz")
     ref = np.load(gold)["y"].astype(np.float64)
     ys = {}
-    for name, env in {"nine_tap": {}, "subpixel": {"PRG_SPLIT_UP2X2": "1"}}.items():
+    for name, env in {"nine_tap": {"PRG_SPLIT_UP2X2": "0"}, "subpixel": {"PRG_SPLIT_UP2X2": "1"}}.items():
         out = str(tmp_path / f"{name}.npz")
         r = subprocess.run([sys.executable, "-c", _UP_SCRIPT.format(root=root, gold=gold, out=out)], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=600)
