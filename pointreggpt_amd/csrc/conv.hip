@@ -805,8 +805,18 @@ static int mx_pure_env() {
   static const int pure = [] { const char* e = std::getenv("PRG_MX_PURE"); return e ? std::atoi(e) : 0; }();
   return pure;
 }
+int try_launch_conv3x3_up_w256(const ConvLaunch<bf16_t>& L, hipStream_t s);                     // conv_w256.hip
 static int try_mx(ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* acc_done) {
   if (!L.w_mx || !L.w_mx_scale) return 0;
+  // Round 5: the wide Upsample convs of an mxfp8 handle run the bf16 SUB-PIXEL form (four 2 x 2-tap convolutions, 4 / 9 of the MACs:
+  // 64-67 us at the configs[4] shape) — the nine-tap MX launch took 77-81 us (same box, same positions:
+  // profiles/r05_configs4_conv_per_launch_bf16_vs_mxfp8.txt); PRG_MX_UP=1 / mx_pure keep them on MX operands
+  static const int mx_up = [] { const char* e = std::getenv("PRG_MX_UP"); return e ? std::atoi(e) : 0; }();
+  if (L.d.ups && !L.gn_partials && !mx_up && !L.mx_pure && !mx_pure_env()) {
+    const int r = try_launch_conv3x3_up_w256(L, s);
+    if (r == 1) g_last_exec_scale = 4.0 / 9.0;
+    if (r != 0) return r;
+  }
   {
     const int r = try_launch_conv3x3_w256mx(L, s, gn_nsplit_out, acc_done);   // 256-pixel x 128-channel tiles with MX operands
     if (r != 0) return r;

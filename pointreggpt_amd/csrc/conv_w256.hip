@@ -1249,7 +1249,10 @@ int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* g
   }
   static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
   const int grid = num_cus & ~7;
-  if (grid < 8 || total < (min_fill > 0 ? min_fill : grid / 2)) return 0;
+  // Round 5: a launch with fewer tiles than CUs stays on the bf16 kernels (the network's level-3 convs: 128 tiles on 256 CUs — measured
+  // at the configs[4] shape, same box, same positions: 25 / 29 us on conv3x3_ws_kernel against 28-29 / 38-40 us here,
+  // profiles/r05_configs4_conv_per_launch_bf16_vs_mxfp8.txt); mx_pure (the conv-level tests) keeps the old half-a-wave threshold
+  if (grid < 8 || total < (min_fill > 0 ? min_fill : (L.mx_pure ? grid / 2 : grid))) return 0;
   const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
   const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
                    tiles_x * tiles_y * 2 <= kGnMaxSplit;
