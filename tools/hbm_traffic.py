@@ -33,7 +33,7 @@ out = {
                   "WRITE_SIZE as reported; KB -> bytes x1024",
     "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace ... ; rocprofv3 --pmc WRITE_SIZE --kernel-trace ... -- python bench.py "
                "--steps 1 --warmup 0 --streams 1 --sampling-steps 2 --no-cpu-baseline --no-roofline --no-configs4 (separate passes)",
-    "round": "r04",
+    "round": "r05",
     "kernel_sources_sha256": __import__("hashlib").sha256(b"".join(
         open(__import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..",
                                         "pointreggpt_amd", "csrc", f), "rb").read()
