@@ -522,7 +522,8 @@ def parity_mode_leg(a, G, synthetic, rank, dt, shape=None, lanes=1):
         pr = pdiff.last_profile(B)
         ach = pr["conv_flops"] / (pr["conv_ms"] * 1e-3) / 1e12
         res["roofline"] = {"kernel": ("conv3x3_halo_kernel<float> + conv_igemm_kernel<float> (v_mfma_f32_32x32x2_f32, float64-summed partials)" if dt == "fp32"
-                                      else "conv3x3_split_kernel + conv_igemm_split_kernel (3 x v_mfma_f32_32x32x16_f16 per product tile)"),
+                                      else "conv3x3_split_ws_kernel (Cout % 128 = 0) + conv3x3_split_p64_kernel (Cout = 64, persistent) + conv_igemm_split_kernel (1x1, 4x4/s2): "
+                                           "3 x v_mfma_f32_32x32x16_f16 per product tile on hi/lo-split operands"),
                            "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dt], "unit": "TFLOP/s (algorithmic)",
                            "frac": ach / MFMA_PEAK_TFLOPS[dt], "traffic": None, "launches": pr["conv_launches"],
                            "avg_launch_us": pr["conv_ms"] * 1e3 / max(1, pr["conv_launches"]),

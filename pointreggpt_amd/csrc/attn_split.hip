@@ -131,7 +131,14 @@ __device__ inline void load_wfrags(h8 (&w)[COLS / 16], const uint16_t* mat, int 
 // =====================================================================================================
 // la_ctx: per slab (column maxima of k, sums of p = exp2(k - max), p^T v)
 // =====================================================================================================
-template <int C>
+// ONLINE (round 5): ONE sweep over the slab instead of two.  The two-sweep form reads x, LayerNorms it and contracts k TWICE (first
+// for the column maxima, then for p = exp2(k - max)); here the maximum of column d is a RUNNING one — a lane owns column d = 32 wave +
+// l31 of k and sees a 32-pixel half tile's 16 + 16 values in its own and its partner lane's registers — and whenever a half tile raises
+// any column's maximum (a wave-uniform test: after a slab's first tiles it almost never does) the wave rescales what it has
+// accumulated so far: row d of ctx and of the row sums times 2^(m_old - m_new), the 32 factors handed from the column-owning lanes to
+// the row-owning registers through 128 bytes of wave-private LDS.  Same result up to rounding — every p is still relative to a
+// measured maximum and <= 1, the slab leaves (max, sum, ctx) relative to its FINAL maximum, and la_fin merges the slabs as before.
+template <int C, bool ONLINE>
 __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_ctx_split_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wqkv_h,
                                                               const uint16_t* __restrict__ wqkv_l, float* __restrict__ ctxp,
                                                               float* __restrict__ sump, float* __restrict__ maxp, int N, int nslab) {
@@ -141,6 +148,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_ctx_split_kernel(cons
   _Float16* xl = xh + kTP * G::LDW;
   const int b = blockIdx.y, slab = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+  float* const scw = reinterpret_cast<float*>(xl + kTP * G::LDW) + 32 * wave;   // ONLINE: this wave's 32 rescale factors
   const int ntiles = N / kTP;
   const int tpb = sp_tpb(ntiles), t0 = slab * tpb, t1 = min(t0 + tpb, ntiles);
   h8 wkh[G::KK], wkl[G::KK], wvh[G::KK], wvl[G::KK];     // k and v rows of head `wave`
@@ -149,30 +157,29 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_ctx_split_kernel(cons
   load_wfrags<C>(wvh, wqkv_h, 2 * kHid + 32 * wave, l31, hi);
   load_wfrags<C>(wvl, wqkv_l, 2 * kHid + 32 * wave, l31, hi);
   XTileF<C> xt;
-  // ---- sweep 1: the slab's maximum of column d = 32 wave + l31 of k (log2 units: the rows carry log2 e) ----
-  float m = -INFINITY;
+  float m = -INFINITY;                                 // maximum of column d = 32 wave + l31 of k (log2 units: the rows carry log2 e)
   if (t0 < t1) xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP);
-  for (int t = t0; t < t1; ++t) {
-    xt.normalize_to(xh, xl);
-    __syncthreads();
-    if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP);
-    else xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP);            // (sweep 2 starts over)
+  if constexpr (!ONLINE) {
+    // ---- sweep 1: the slab's column maxima ----
+    for (int t = t0; t < t1; ++t) {
+      xt.normalize_to(xh, xl);
+      __syncthreads();
+      if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP);
+      else xt.load(x, (int64_t)b * N + (int64_t)t0 * kTP);            // (sweep 2 starts over)
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      f32x16 k1 = zero16();
+      for (int pt = 0; pt < 2; ++pt) {
+        f32x16 k1 = zero16();
 #pragma unroll
-      for (int kk = 0; kk < G::KK; ++kk)
-        k1 = mma3(frag(xh + pt * 32 * G::LDW, G::LDW, l31, hi, kk), frag(xl + pt * 32 * G::LDW, G::LDW, l31, hi, kk), wkh[kk], wkl[kk], k1);
+        for (int kk = 0; kk < G::KK; ++kk)
+          k1 = mma3(frag(xh + pt * 32 * G::LDW, G::LDW, l31, hi, kk), frag(xl + pt * 32 * G::LDW, G::LDW, l31, hi, kk), wkh[kk], wkl[kk], k1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, k1[r]);
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, k1[r]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
   }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  f32x16 kinit;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) kinit[e] = -m;
-  // ---- sweep 2 ----
+  // ---- the sweep that accumulates ----
   f32x16 ctx = zero16();                               // rows d, column e = l31 of head `wave`
   f32x16 psum = zero16();                              // rows d (any column)
   h8 ones;
@@ -184,12 +191,33 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_ctx_split_kernel(cons
     if (t + 1 < t1) xt.load(x, (int64_t)b * N + (int64_t)(t + 1) * kTP);
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      f32x16 k1 = kinit, v1 = zero16();
+      f32x16 k1 = zero16(), v1 = zero16();
 #pragma unroll
       for (int kk = 0; kk < G::KK; ++kk) {
         const h8 fh = frag(xh + pt * 32 * G::LDW, G::LDW, l31, hi, kk), fl = frag(xl + pt * 32 * G::LDW, G::LDW, l31, hi, kk);
         k1 = mma3(fh, fl, wkh[kk], wkl[kk], k1);
         v1 = mma3(fh, fl, wvh[kk], wvl[kk], v1);
+      }
+      if constexpr (ONLINE) {
+        float mx = k1[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, k1[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__builtin_amdgcn_ballot_w64(mx > m) != 0ull) {            // (wave-uniform) some column's maximum rose
+          const float mn = fmaxf(m, mx);
+          const float sc = __builtin_amdgcn_exp2f(m - mn);            // 1 where it did not; 0 on the slab's first half tile (m = -inf)
+          m = mn;
+          if (hi == 0) scw[l31] = sc;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {                            // registers 4 g4 .. + 3 are rows d = 8 g4 + 4 hi + {0..3}
+            const float4 s4 = *reinterpret_cast<const float4*>(scw + 8 * g4 + 4 * hi);
+            ctx[4 * g4] *= s4.x; ctx[4 * g4 + 1] *= s4.y; ctx[4 * g4 + 2] *= s4.z; ctx[4 * g4 + 3] *= s4.w;
+            psum[4 * g4] *= s4.x; psum[4 * g4 + 1] *= s4.y; psum[4 * g4 + 2] *= s4.z; psum[4 * g4 + 3] *= s4.w;
+          }
+          __builtin_amdgcn_wave_barrier();                            // (the factors are read before a later half tile rewrites them)
+        }
       }
       // p and v feed the context MFMA straight from the accumulator registers: lane (column, half hi) holds in registers
       // 8 i .. 8 i + 7 exactly the eight pixels that A's row / B's column l31 supplies for k-slots 8 hi .. + 7 of k-step i
@@ -198,7 +226,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_ctx_split_kernel(cons
         h8 ph, pl, vh, vl;
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) {
-          SPLIT_TO(__builtin_amdgcn_exp2f(k1[8 * i + s2]), ph, pl, s2);
+          SPLIT_TO(__builtin_amdgcn_exp2f(k1[8 * i + s2] - m), ph, pl, s2);
           SPLIT_TO(v1[8 * i + s2], vh, vl, s2);
         }
         ctx = mma3(ph, pl, vh, vl, ctx);
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 1) void la_out_split_kernel(cons
 }
 
 template <int C>
-constexpr size_t lds_ctx() { return (size_t)2 * kTP * SG<C>::LDW * 2; }
+constexpr size_t lds_ctx() { return (size_t)2 * kTP * SG<C>::LDW * 2 + 4 * 32 * sizeof(float); }   // x tile halves + the online form's rescale factors
 template <int C>
 constexpr size_t lds_out() {
   return (size_t)2 * kTP * SG<C>::LDW * 2 + (size_t)2 * kTP * kLdO * 2 + (size_t)kTP * (C / 32) * 2 * 4 + (size_t)kTP * (C + 4) * 4 + 2 * C * 4;
@@ -464,7 +492,10 @@ int launch_c(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, con
   uint16_t* ctxT_h = reinterpret_cast<uint16_t*>(maxp + (size_t)B * 4 * nslab * 32);
   uint16_t* ctxT_l = ctxT_h + (size_t)B * 4 * 1024;
   const dim3 grid(nslab, B);
-  la_ctx_split_kernel<C><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv_h, wqkv_l, ctxp, sump, maxp, N, nslab);
+  // PRG_SPLIT_LA_ONLINE=0: the two-sweep form of rounds 4 (column maxima first)
+  static const int online = [] { const char* e = std::getenv("PRG_SPLIT_LA_ONLINE"); return e ? std::atoi(e) : 1; }();
+  if (online) la_ctx_split_kernel<C, true><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv_h, wqkv_l, ctxp, sump, maxp, N, nslab);
+  else la_ctx_split_kernel<C, false><<<grid, 256, lds_ctx<C>(), s>>>(x, wqkv_h, wqkv_l, ctxp, sump, maxp, N, nslab);
   PRG_LAUNCH_CHECK();
   la_fin_split_kernel<<<dim3(4, B), 256, 0, s>>>(ctxp, sump, maxp, ctxT_h, ctxT_l, N, nslab);
   PRG_LAUNCH_CHECK();

@@ -184,6 +184,31 @@ def test_f16x3_subpixel_upsample_option(tmp_path):
     assert 0.0 < d <= 1e-5                                   # (> 0: the option really took the other kernel)
 
 
+def test_f16x3_one_sweep_linear_attention(tmp_path):
+    """Round 5: la_ctx_split_kernel<C, true> — ONE sweep over a slab with a running column maximum of k and a rescale of the
+    accumulated context whenever a half tile raises it — against the two-sweep form of round 4 (PRG_SPLIT_LA_ONLINE=0: column maxima
+    first).  The dim-64 U-Net at 128 x 128 (fused split linear attention at C = 64 and C = 128, slabs of 8 / 2 / 1 tiles) both ways:
+    at the reference's distance, and within rounding of each other (the two forms differ only in which float32 roundings happen)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden", "G13_unet_dim64_128.npz")
+    ref = np.load(gold)["y"].astype(np.float64)
+    ys = {}
+    for name, env in {"one_sweep": {"PRG_SPLIT_LA_ONLINE": "1"}, "two_sweeps": {"PRG_SPLIT_LA_ONLINE": "0"}}.items():
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", _UP_SCRIPT.format(root=root, gold=gold, out=out)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ys[name] = np.load(out)["y"].astype(np.float64)
+        e = float(np.abs(ys[name] - ref).max())
+        print(f"f16x3 linear attention, {name}: max err vs reference {e:.3e}")
+        assert e <= 2e-5
+    d = float(np.abs(ys["one_sweep"] - ys["two_sweeps"]).max())
+    print(f"one sweep vs two sweeps: {d:.3e}")
+    assert 0.0 < d <= 1e-5
+
+
 _P64_CONV_SCRIPT = """
 import sys, json, ctypes as C, numpy as np, torch
 sys.path.insert(0, {root!r})
