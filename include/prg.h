@@ -42,11 +42,13 @@ enum {
 /* PRG_F16X3 (round 4): float32 storage and float32 / float64 normalisation arithmetic exactly as PRG_F32, but every
  * convolution contracts on the f16 matrix pipe with both operands split into two f16 halves (a = hi + lo, three MFMAs per
  * product tile, 22-bit operands; csrc/conv_split.hip).  NOT labelled "parity" (that is PRG_F32 alone): its distance from the
- * reference is MEASURED per chain — point-XYZ L-infinity 4.5e-6 m (1000-step ancestral @64x64), 3.3e-5 m (250-step DDIM
- * @128x128), 5.7e-5 m (250-step DDIM @256x256, the shipped setting), 7.5e-6 m (the benchmarked 1000-step chain @128x128), all
- * inside the 1e-4 m north star since round 5 (round 4: 1.7e-4 m at 256x256 — the lo halves of unstandardised weights were
- * subnormal f16; the packer now scales each output channel by an exact power of two) — tests/test_gpu_f16x3.py asserts them and
- * bench.py's drift_vs_reference re-measures them in every run; at several times PRG_F32's throughput.
+ * reference is MEASURED per chain — point-XYZ L-infinity at the end of round 5: 4.5e-6 m (1000-step ancestral @64x64), 3.8e-5 m
+ * (250-step DDIM @128x128), 5.3e-5 m (250-step DDIM @256x256, the shipped setting), 7.6e-6 m (the benchmarked 1000-step chain
+ * @128x128), all inside the 1e-4 m north star since round 5 (round 4: 1.7e-4 m at 256x256 — the lo halves of unstandardised
+ * weights were subnormal f16; the packer now scales each output channel by an exact power of two).  The 256x256 figure is a
+ * draw: equal-precision re-orderings of the arithmetic move it within 3.7e-5 .. 8.8e-5 m (the reference's own 1-vs-8-thread
+ * spread there is 4.7e-5 m).  tests/test_gpu_f16x3.py asserts these and bench.py's drift_vs_reference re-measures them in every
+ * run; 3.9-4.0x PRG_F32's throughput.
  * Operand range: an activation or scaled weight beyond f16's 65504 becomes inf (visible, not silent).                      */
 enum { PRG_F32 = 0, PRG_BF16 = 1, PRG_MXFP8 = 2, PRG_F16X3 = 3 };
 
