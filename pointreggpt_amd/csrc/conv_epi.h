@@ -45,6 +45,13 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
   // coefficients are recomputed only when the row's image changes (a tile spans one image, rarely two)
   float fa[8], fb[8];
   int fimg = -1;
+  // Round 5: the row's image index m / (Hout * Wout) was a 32-bit integer DIVISION per row and lane (~25 VALU instructions, seven of
+  // them quarter-rate multiplies) — with a power-of-two image (every shape the networks produce) it is a shift; and the coefficient
+  // TABLES of the activated residual (res_a / res_b: 64 bytes per row and lane) are re-read only when the row's image changes, as the
+  // in-kernel fold already did.  The 1x1 kernels' epilogue — not their operand fetch — was what kept them at 0.18 MFMA-busy.
+  const int hw_ = L.d.Hout * L.d.Wout;
+  const int hw_sh = (hw_ & (hw_ - 1)) == 0 ? 31 - __builtin_clz((unsigned)hw_) : -1;
+  auto img_of = [&](int64_t m) -> int { return hw_sh >= 0 ? (int)((unsigned)m >> hw_sh) : (int)m / hw_; };
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     __syncthreads();  // previous pass fully read (and, first time, the main loop's LDS reads are done)
@@ -81,7 +88,7 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
           float ra[8], rb[8];
           const bool act = L.res_a != nullptr || L.res_fold.acc != nullptr;
           if (L.res_fold.acc) {
-            const int img = (int)m / (L.d.Hout * L.d.Wout);
+            const int img = img_of(m);
             if (img != fimg) {
               fimg = img;
               const GnFold& f = L.res_fold;
@@ -98,11 +105,17 @@ __device__ inline void epilogue_store(const ConvLaunch<T>& L, f32x16 (&acc)[TM][
 #pragma unroll
             for (int u = 0; u < 8; ++u) { ra[u] = fa[u]; rb[u] = fb[u]; }
           } else if (L.res_a) {
-            const size_t cb = (size_t)((int)m / (L.d.Hout * L.d.Wout)) * L.d.Cout + col;   // this row's image
-            const float4 a0 = *reinterpret_cast<const float4*>(L.res_a + cb), a1 = *reinterpret_cast<const float4*>(L.res_a + cb + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(L.res_b + cb), b1 = *reinterpret_cast<const float4*>(L.res_b + cb + 4);
-            ra[0] = a0.x; ra[1] = a0.y; ra[2] = a0.z; ra[3] = a0.w; ra[4] = a1.x; ra[5] = a1.y; ra[6] = a1.z; ra[7] = a1.w;
-            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b0.z; rb[3] = b0.w; rb[4] = b1.x; rb[5] = b1.y; rb[6] = b1.z; rb[7] = b1.w;
+            const int img = img_of(m);                                                     // this row's image
+            if (img != fimg) {
+              fimg = img;
+              const size_t cb = (size_t)img * L.d.Cout + col;
+              const float4 a0 = *reinterpret_cast<const float4*>(L.res_a + cb), a1 = *reinterpret_cast<const float4*>(L.res_a + cb + 4);
+              const float4 b0 = *reinterpret_cast<const float4*>(L.res_b + cb), b1 = *reinterpret_cast<const float4*>(L.res_b + cb + 4);
+              fa[0] = a0.x; fa[1] = a0.y; fa[2] = a0.z; fa[3] = a0.w; fa[4] = a1.x; fa[5] = a1.y; fa[6] = a1.z; fa[7] = a1.w;
+              fb[0] = b0.x; fb[1] = b0.y; fb[2] = b0.z; fb[3] = b0.w; fb[4] = b1.x; fb[5] = b1.y; fb[6] = b1.z; fb[7] = b1.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ra[u] = fa[u]; rb[u] = fb[u]; }
           }
 #pragma unroll
           for (int h = 0; h < 8 / VEC; ++h) {

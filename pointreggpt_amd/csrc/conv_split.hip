@@ -916,27 +916,39 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
   {
     const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 64;          // 16, 32 or 64 when the statistics are fused
     double sd[2], qd[2];
+    // Addresses (round 5): pixel p = 64 wm + 32 i + (e & 3) + 8 (e >> 2) + 4 hi of the 16-wide tile is tile row 4 wm + 2 i + (e >> 3),
+    // column (e & 3) + 8 ((e >> 2) & 1) + 4 hi: a WAVE-UNIFORM 64-bit tile base (scalar registers) + a 32-bit per-lane offset + uniform
+    // per-store terms (row step, pixel step) — one vector add per store.  The generic form (m * d.Cout + ch per element in 64 bits)
+    // cost ~350 of the epilogue's ~620 VALU instructions per wave, 140 of them quarter-rate integer multiplies.
+    const size_t ps = (size_t)d.Cout * (UP ? 2 : 1);                       // floats between the lane's consecutive tile columns
+    const size_t rs = (size_t)d.Wout * d.Cout * (UP ? 2 : 1);              // ... and tile rows
+    float* const lbase = L.out + (UP ? (((size_t)b * d.Hout + 2 * (y0 + wm * 4) + (ph >> 1)) * d.Wout + 2 * x0 + (ph & 1)) * d.Cout
+                                     : (((size_t)b * d.Hout + y0 + wm * 4) * d.Wout + x0) * d.Cout) + tn * BN + wn * 64 + (size_t)(4 * hi) * ps + l31;
+    float bv[2], sc[2], s1[2] = {0.0f, 0.0f}, q1[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ch = tn * BN + wn * 64 + j * 32 + l31;
-      const float bv = L.bias ? L.bias[ch] : 0.0f;
+      bv[j] = L.bias ? L.bias[ch] : 0.0f;
       const float* scp = UP ? L.split_scale_up : L.split_scale;            // the packer's per-channel power of two, undone (exact)
-      const float sc = scp ? scp[(UP ? ph * d.CoutPad : 0) + ch] : 1.0f;
-      float s1 = 0.0f, q1 = 0.0f;
+      sc[j] = scp ? scp[(UP ? ph * d.CoutPad : 0) + ch] : 1.0f;
+    }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int p = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-          const size_t m = UP ? ((size_t)b * d.Hout + 2 * (y0 + p / TW) + (ph >> 1)) * d.Wout + 2 * (x0 + p % TW) + (ph & 1)
-                              : ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
-          const float v = tot[i][j][e] * sc + bv;
-          L.out[m * d.Cout + ch] = v;
-          s1 += v;
-          q1 = fmaf(v, v, q1);
+      for (int e = 0; e < 16; ++e) {
+        float* const cp = lbase + (size_t)(2 * i + (e >> 3)) * rs + (size_t)((e & 3) + 8 * ((e >> 2) & 1)) * ps;   // (uniform offsets)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                      // (per j the values are summed in the same (i, e) order as before)
+          const float v = tot[i][j][e] * sc[j] + bv[j];
+          cp[j * 32] = v;
+          s1[j] += v;
+          q1[j] = fmaf(v, v, q1[j]);
         }
-      sd[j] = (double)s1;
-      qd[j] = (double)q1;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      sd[j] = (double)s1[j];
+      qd[j] = (double)q1[j];
     }
     if (fuse_stats) {
       const int width = cpg < 32 ? cpg : 32;
@@ -1284,6 +1296,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
     const int b = lin / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     double sd[2], qd[2];
+    // Addresses (round 5): pixel p = 64 wave + 32 i + (e & 3) + 8 (e >> 2) + 4 hi of the 16-wide tile is tile row 4 wave + 2 i + (e >> 3),
+    // column (e & 3) + 8 ((e >> 2) & 1) + 4 hi, and Cout is 64 here (the launcher's condition): ONE 64-bit base per lane and tile plus the
+    // image's row step — every store is base (+ row step) + a compile-time offset.  The generic form (m * d.Cout + ch per element) cost
+    // ~350 of the epilogue's 665 VALU instructions per tile and wave, 140 of them quarter-rate integer multiplies.
+    float* const obase = L.out + (((size_t)b * d.Hout + y0 + wave * 4) * d.Wout + x0 + 4 * hi) * BN + l31;
+    const size_t rowstep = (size_t)d.Wout * BN;                          // floats between image rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ch = j * 32 + l31;
@@ -1291,17 +1309,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
       const float sc = L.split_scale ? L.split_scale[ch] : 1.0f;         // the packer's per-channel power of two, undone (exact)
       float s1 = 0.0f, q1 = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        float* const r0 = obase + j * 32 + (size_t)(2 * i) * rowstep;
+        float* const r1 = r0 + rowstep;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int p = wave * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-          const size_t m = ((size_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
           const float v = tot[i][j][e] * sc + bv;
-          L.out[m * d.Cout + ch] = v;
+          ((e >> 3) ? r1 : r0)[((e & 3) + 8 * ((e >> 2) & 1)) * BN] = v;
           s1 += v;
           q1 = fmaf(v, v, q1);
           tot[i][j][e] = 0.0f;
         }
+      }
       sd[j] = (double)s1;
       qd[j] = (double)q1;
     }
