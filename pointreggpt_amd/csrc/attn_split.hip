@@ -56,9 +56,20 @@ __device__ inline f32x16 mma3(const h8& ah, const h8& al, const h8& bh, const h8
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
 }
+// v - hi as one v_fma_mix_f32 (conv_split.hip's split8, where it took 8 % off the persistent 64-channel kernel) bought nothing in
+// these kernels (same-box A/B, round 5: la_ctx -1 %, la_out +1-2 %): off; -DPRG_ATTN_SPLIT_MIX=1 builds it
+#ifndef PRG_ATTN_SPLIT_MIX
+#define PRG_ATTN_SPLIT_MIX 0
+#endif
 __device__ inline void split1(float v, _Float16& h, _Float16& l) {
   h = (_Float16)v;
+#if PRG_ATTN_SPLIT_MIX
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+  l = (_Float16)r;
+#else
   l = (_Float16)(v - (float)h);
+#endif
 }
 #define SPLIT_TO(v, H, L, idx)                \
   do {                                        \
