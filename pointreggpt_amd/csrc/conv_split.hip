@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
       for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j], acc[i][j], 0, 0, 0);
   };
   // one tap of global chunk g (halo buffer g & 1); `more` = another chunk (of this or of the next tile) follows
-  auto body = [&](auto TAP, int g, bool more) {
+  auto body = [&](auto TAP, int g, bool more, bool first) {
     constexpr int T = decltype(TAP)::value;
     const int it = g * NT + T;
     // barrier #it (the very first tap runs straight after the prologue's barrier #0): weight tiles it, it + 1 are in LDS, tile
@@ -1489,12 +1489,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
     __builtin_amdgcn_sched_barrier(0);
     mfmas(IC<1>());
     if constexpr (T == NT - 1) {                         // the 288-term partial of this channel chunk
+      // (a tile's FIRST partial is assigned, not added to a zeroed total: 0 + x = x, and the epilogue no longer zeroes 64 registers)
+      if (first) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
+            for (int e = 0; e < 16; ++e) { tot[i][j][e] = acc[i][j][e]; acc[i][j][e] = 0.0f; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
+      }
     }
   };
   asm volatile("s_barrier" ::: "memory");                // barrier(0): the producers' prologue — tile 0's first halo, weight tiles 0 and 1
@@ -1505,8 +1515,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
   for (int kt = 0; kt < t_count; ++kt) {
     for (int c = 0; c < nchunks; ++c, ++g) {
       const bool more = g + 1 < nchunks_total;
-      body(IC<0>(), g, more); body(IC<1>(), g, more); body(IC<2>(), g, more); body(IC<3>(), g, more); body(IC<4>(), g, more);
-      body(IC<5>(), g, more); body(IC<6>(), g, more); body(IC<7>(), g, more); body(IC<8>(), g, more);
+      const bool first = c == 0;
+      body(IC<0>(), g, more, first); body(IC<1>(), g, more, first); body(IC<2>(), g, more, first); body(IC<3>(), g, more, first);
+      body(IC<4>(), g, more, first); body(IC<5>(), g, more, first); body(IC<6>(), g, more, first); body(IC<7>(), g, more, first);
+      body(IC<8>(), g, more, first);
     }
     // DIRECT epilogue of tile kt (as in the kernels above): register e of lane half hi is pixel row (e & 3) + 8 (e >> 2) + 4 hi of
     // the 32-pixel row tile, lanes 0-31 are 32 consecutive channels: a dword store per register writes two full 128-byte lines per
@@ -1536,7 +1548,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
         float* const r1 = r0 + rowstep;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float v = tot[i][j][e] * sc + bv;
+          // (sc is an exact power of two: the fused form rounds once, exactly where the product-then-sum form rounds — same bits)
+          const float v = __builtin_fmaf(tot[i][j][e], sc, bv);
 #if PRG_SPLIT_EXP == 12
           if (v == 1.2345e-30f) r0[0] = v;     // (keeps the accumulators alive, stores nothing)
 #else
@@ -1544,7 +1557,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
 #endif
           s1 += v;
           q1 = fmaf(v, v, q1);
-          tot[i][j][e] = 0.0f;
         }
       }
       sd[j] = (double)s1;
