@@ -664,10 +664,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       const int c = it / NT, tap = it - NT * c;
       const char* p = wtile + (size_t)(tap * L.split_kchunks + c) * wstep;
       char* dst = Bs + ((it & (NS - 1)) * BN + pw * WPW * 8) * 128;
+#if PRG_SPLIT_EXP != 25      // (timing ablations of this kernel: 21 no MFMAs, 23 no halo staging, 24 no fragment reads, 25 no weight DMA)
 #pragma unroll
       for (int r = 0; r < WPW; ++r)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
                                          (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
+#else
+      (void)p; (void)dst;
+#endif
     };
     gload_b(0);
     if (niter > 1) gload_b(1);
@@ -708,12 +712,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       const bool first = c < d.C0;
       const float* base = first ? L.src0 : L.src1;
       const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+#if PRG_SPLIT_EXP != 23
 #pragma unroll
       for (int k = 0; k < NHP; ++k) {
         const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
         g0[k] = p[0];
         g1[k] = p[1];
       }
+#else
+      (void)base; (void)Cs; (void)cc;
+#endif
     };
     float4 (&g0)[NHP] = gA0;
     float4 (&g1)[NHP] = gA1;
@@ -722,12 +730,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       const bool first = c < d.C0;
       const float* base = first ? L.src0 : L.src1;
       const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
+#if PRG_SPLIT_EXP != 23
 #pragma unroll
       for (int k = 0; k < NHP; ++k) {
         const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
         g0[k] = p[0];
         g1[k] = p[1];
       }
+#else
+      (void)base; (void)Cs; (void)cc;
+#endif
     };
     float pa[8], pb[8];
     auto pro_load = [&](int chunk) {
@@ -742,7 +754,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     auto write_pass_set = [&](int buf, auto K, const float4 (&h0)[NHP], const float4 (&h1)[NHP]) {
       constexpr int k = decltype(K)::value;
       const int hp = prow + k * 32;
+#if PRG_SPLIT_EXP == 23
+      if (false) {
+#else
       if (hp < HALO) {
+#endif
         float v[8] = {h0[k].x, h0[k].y, h0[k].z, h0[k].w, h1[k].x, h1[k].y, h1[k].z, h1[k].w};
         if (L.pro_a) {
 #pragma unroll
@@ -849,6 +865,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     constexpr int toff = UP ? (T / 2) * RSTRIDE + (T % 2) * PITCH : (T / 3) * RSTRIDE + (T % 3) * PITCH;
     const char* A = Ah + cb * HBYTES + toff + st * 32 + pho;
     const char* Bb = Bs + slot * (BN * 128);
+#if PRG_SPLIT_EXP == 24
+    (void)A; (void)Bb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[st][i])); asm volatile("" : "+v"(fw[st][i])); }   // (opaque values, no LDS read)
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       fa[st][2 * i] = ld_frag(reinterpret_cast<const uint4*>(A + a_lane[i]));
@@ -862,6 +884,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
   };
   auto mfmas = [&](auto ST) {
     constexpr int st = decltype(ST)::value;
+#if PRG_SPLIT_EXP == 21
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[st][i])); asm volatile("" ::"v"(fw[st][i])); }   // (keep the fragment loads alive)
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
