@@ -201,11 +201,23 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
     c64_barrier();                                         // halo 0 is in LDS (producers' prologue)
     for (int s = 0; s < nsteps; ++s) {
       const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
+      // Round 5: the accumulators START at the bias (16 values per lane, re-read from LDS per tile: they are dead again before the
+      // fragment sets fill up) instead of at zero — the epilogue's 64 bias additions per tile and wave are gone; the sum's rounding
+      // order changes (bias first), far below the bf16 / f16 output rounding.  PRG_C64_EXP & 256: the old form (A/B builds).
       c64_f32x16 acc[4];
+      if constexpr ((PRG_C64_EXP & 256) != 0) {
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt)
+        for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[pt][e] = 0.0f;
+          for (int e = 0; e < 16; ++e) acc[pt][e] = 0.0f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) { acc[pt][4 * q] = b4.x; acc[pt][4 * q + 1] = b4.y; acc[pt][4 * q + 2] = b4.z; acc[pt][4 * q + 3] = b4.w; }
+        }
+      }
       c64_bf16x8 fx[2][4];
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) fx[0][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB);
@@ -261,8 +273,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
         float bv[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
-          bv[q][0] = b4.x; bv[q][1] = b4.y; bv[q][2] = b4.z; bv[q][3] = b4.w;
+          if constexpr ((PRG_C64_EXP & 256) != 0) {
+            const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
+            bv[q][0] = b4.x; bv[q][1] = b4.y; bv[q][2] = b4.z; bv[q][3] = b4.w;
+          } else {
+            bv[q][0] = bv[q][1] = bv[q][2] = bv[q][3] = 0.0f;        // (the bias rode in as the accumulators' initial value)
+          }
           V[q] = 0.0f;
           V[4 + q] = 0.0f;
         }
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              v[r] = acc[pt][4 * q + r] + bv[q][r];
+              v[r] = (PRG_C64_EXP & 256) ? acc[pt][4 * q + r] + bv[q][r] : acc[pt][4 * q + r];
               V[q] += v[r];
               V[4 + q] = fmaf(v[r], v[r], V[4 + q]);
             }

@@ -219,6 +219,19 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
   } while (0)
 #define W2_SB() __builtin_amdgcn_sched_barrier(0)
     w2_barrier<true>();                                      // halo 0 and weight tiles 0, 1 are in LDS; the bias too
+    // Round 5: the accumulators START at the bias (here, and again at the end of every tile's epilogue, where the bias registers are
+    // live anyway) instead of at zero: the epilogue's 128 bias additions per tile and wave are gone; the sum's rounding order changes
+    // (bias first), far below the bf16 / f16 output rounding.  PRG_W256_EXP & 128: the old form (A/B builds).
+    if constexpr (!(PRG_W256_EXP & 128)) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + wn * 64 + ct * 32 + 8 * q + 4 * hi);
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) { acc[ct][pt][4 * q] = b4.x; acc[ct][pt][4 * q + 1] = b4.y; acc[ct][pt][4 * q + 2] = b4.z; acc[ct][pt][4 * q + 3] = b4.w; }
+        }
+    }
     {
       constexpr int t0 = w2_toff<MODE, HP>(0);
       W2_LW(0, 0, 0, 0); W2_LX(0, 0, xa, t0, 0); W2_LX(0, 1, xa, t0, 0); W2_LX(0, 2, xa, t0, 0); W2_LX(0, 3, xa, t0, 0); W2_LW(0, 1, 0, 0);
@@ -300,10 +313,15 @@ __global__ __launch_bounds__(512) void conv3x3_w256_kernel(const ConvLaunch<bf16
                   float v[4];
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[ct][pt][4 * q + r] + bv[q][r];
+                    if constexpr ((PRG_W256_EXP & 128) != 0) {
+                      v[r] = acc[ct][pt][4 * q + r] + bv[q][r];
+                      acc[ct][pt][4 * q + r] = 0.0f;
+                    } else {
+                      v[r] = acc[ct][pt][4 * q + r];
+                      acc[ct][pt][4 * q + r] = bv[q][r];          // the next tile's initial value
+                    }
                     V[ct * 4 + q] += v[r];
                     V[8 + ct * 4 + q] = fmaf(v[r], v[r], V[8 + ct * 4 + q]);
-                    acc[ct][pt][4 * q + r] = 0.0f;
                   }
                   if (!MODE && o16) {
                     pk[2 * q] = h16_pack(v[0], v[1]);
