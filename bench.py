@@ -870,7 +870,10 @@ def main():
                                          "box the same binary spreads +-4 %); kernel-level comparisons (tools/prof_seq.py) are microseconds at the "
                                          "same position of the replayed graph on one box",
                            "precision": "profiles/r05_precision_budget_f16x3.txt: which contraction class needs more than 22 bits on the long chains",
-                           "power": "profiles/r04_power_pairs_per_joule.json, profiles/r03_power_1_vs_2_lanes.json: pairs per joule (power ceiling)"}
+                           "power": "profiles/r05_power_clock_mfma_busy_per_mode.json: socket power, shader clock, pairs per joule and MFMA-busy of bf16 / mxfp8 / f16x3 / fp32 "
+                                    "on one box (nominal peak x clock x busy = achieved); profiles/r04_power_pairs_per_joule.json, profiles/r03_power_1_vs_2_lanes.json",
+                           "ablations": "profiles/r05_p64_ablations.txt, profiles/r05_split_ws_ablations.txt (where the f16x3 conv kernels' time goes), "
+                                        "profiles/r05_mxcap_activations_in_memory_cap.txt (upper bound of MX operands in memory), profiles/r05_chain_metric_spread_f16x3.txt"}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
