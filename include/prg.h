@@ -237,6 +237,14 @@ int prg_sampler_set_graph(prg_sampler* h, int enable);
 int prg_sampler_run(prg_sampler* h, const float* param_cond, const float* img_cond, const float* noise,
                     int64_t noise_slabs, const uint64_t* seeds, float* out, void* stream);
 
+/* Kernel unit-test / bandwidth hook (round 6): the transition update above ALONE (sampler_step_kernel: what p_sample / ddim_sample
+ * do after model_predictions, sd:1257-1281 / sd:1369-1373) on caller tensors, `reps` launches back to back on `stream`:
+ * x (B,HW) DEVICE, updated in place by every launch; u (B,HW) DEVICE = the network output; img_cond (B,2,HW) DEVICE or NULL;
+ * seeds (B) DEVICE uint64 Philox keys (launch i draws noise index i + 1); step: HOST, the same row for every launch.
+ * *avg_us (HOST, may be NULL) = HIP-event microseconds per launch.  Synchronises.                                            */
+int prg_debug_sampler_step(float* x, const float* u, const float* img_cond, const uint64_t* seeds, const prg_step* step, int B,
+                           int HW, int reps, float* avg_us, void* stream);
+
 /* Wall-clock free timing hook for bench.py: average duration in milliseconds of the dominant kernel class
  * (implicit-GEMM convolution launches) measured with HIP events on the run's own stream during the last
  * prg_sampler_run when profiling was enabled with prg_sampler_set_profile(h, 1) (forces eager launches).
@@ -257,6 +265,7 @@ int prg_sampler_get_profile_executed(prg_sampler* h, double* conv_flops_executed
 typedef struct prg_profile_shape {
   int32_t cin, cout, k, stride, ups, hout, wout;   /* Conv2d(cin, cout, k, stride) on (hout, wout) outputs; ups: after nn.Upsample(x2) */
   int32_t two_source, prologue;                     /* virtual concat of two tensors (skip connection); fused GroupNorm+SiLU on the input */
+  int32_t mx;                                       /* 1: the launches ran on MX-fp8 operands (scale-MFMA); occupies the former padding */
   int64_t launches;
   double ms, flops, flops_executed;
 } prg_profile_shape;

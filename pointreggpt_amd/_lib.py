@@ -69,6 +69,7 @@ PROTOTYPES = {
     "prg_sampler_get_profile_bytes": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "prg_sampler_get_profile_executed": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "prg_sampler_get_profile_step": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
+    "prg_debug_sampler_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     "prg_sampler_get_profile_shapes": (C.c_int, [_P, _P, _I, C.POINTER(C.c_int32)]),
     "prg_host_crop_aabb": (C.c_int, [_P, _L, _P, _P, _P, C.POINTER(_L)]),
     "prg_host_voxel_down_sample": (C.c_int, [_P, _L, C.c_double, _P, C.POINTER(_L)]),

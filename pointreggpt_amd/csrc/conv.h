@@ -194,6 +194,7 @@ bool conv_supports_prologue(const ConvDesc& d);
 // executed / algorithmic MAC ratio of the calling thread's last launch_conv: 1, or 4 / 9 when an Upsample conv ran as four
 // 2 x 2-tap sub-pixel convolutions (conv_w256.hip MODE 2) — conv_flops() below is the ALGORITHMIC count (the reference's op)
 double conv_last_exec_scale();
+int conv_last_was_mx();
 
 inline double conv_flops(const ConvDesc& d) {
   return 2.0 * (double)d.B * d.Hout * d.Wout * d.Cout * (double)(d.C0 + d.C1) * d.KH * d.KW;

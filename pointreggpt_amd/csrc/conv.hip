@@ -789,6 +789,9 @@ int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* g
 // executed / algorithmic MAC ratio of this thread's last launch_conv (1 except for the sub-pixel Upsample form: 4 / 9)
 static thread_local double g_last_exec_scale = 1.0;
 double conv_last_exec_scale() { return g_last_exec_scale; }
+// 1 when this thread's last launch_conv ran on MX-fp8 operands (v_mfma_scale_f32_32x32x64_f8f6f4); bench.py configs4.mx_flop_fraction
+static thread_local int g_last_mx = 0;
+int conv_last_was_mx() { return g_last_mx; }
 
 // Consumers without the in-kernel GroupNorm fold (common.h, GnFold): fill the pro_a / pro_b tables from the accumulators
 // with one small launch, then run on the tables as before.
@@ -819,6 +822,7 @@ static int try_mx(ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int*
   }
   {
     const int r = try_launch_conv3x3_w256mx(L, s, gn_nsplit_out, acc_done);   // 256-pixel x 128-channel tiles with MX operands
+    if (r == 1) g_last_mx = 1;
     if (r != 0) return r;
   }
   // Shapes the 256-pixel MX kernel does not cover (the 64-channel convs, launches with few tiles): by default the bf16
@@ -838,6 +842,7 @@ static int try_mx(ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int*
   else if (hp.TH == 8 && hp.TW == 16 && hp.BN == 128) rc = launch_mx<8, 16, 128>(L, s, fuse, gn_nsplit_out);
   else if (hp.TH == 8 && hp.TW == 16 && hp.BN == 64) rc = launch_mx<8, 16, 64>(L, s, fuse, gn_nsplit_out);
   else return 0;
+  if (rc == PRG_OK) g_last_mx = 1;
   return rc == PRG_OK ? 1 : rc;
 }
 static int try_mx(ConvLaunch<float>&, hipStream_t, int*, int*) { return 0; }
@@ -903,6 +908,7 @@ bool conv_h16_pair_ok(const ConvLaunch<bf16_t>& L1in, const ConvLaunch<bf16_t>& 
 template <typename T>
 int launch_conv(const ConvLaunch<T>& Lin, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
   g_last_exec_scale = 1.0;
+  g_last_mx = 0;
   if (coef_done) *coef_done = 0;
   if (acc_done) *acc_done = 0;
   ConvLaunch<T> L = Lin;          // (materialize_prologue clears pro_fold once the coefficient tables are filled)

@@ -4,6 +4,8 @@
 // 1250-1251, 1280, 1369-1373) so that, given identical network outputs and noise, the state is bit-identical.
 #include "sampler.h"
 
+#include <vector>
+
 namespace prg {
 
 // ---- Philox4x32-10 (counter-based; key = per-scene seed, counter = (pixel quad, draw index)) ----
@@ -144,3 +146,40 @@ int launch_sampler_init(float* x, const float* noise, const uint64_t* seeds, int
 }
 
 }  // namespace prg
+
+using namespace prg;
+
+extern "C" int prg_debug_sampler_step(float* x, const float* u, const float* img_cond, const uint64_t* seeds, const prg_step* step, int B,
+                                      int HW, int reps, float* avg_us, void* stream) {
+  PRG_CHECK(x && u && seeds && step && B > 0 && HW > 0 && HW % 4 == 0 && reps > 0, "prg_debug_sampler_step: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  // a table of `reps` copies of the transition (+1 row so that no launch is the chain's last), the device step counter and the ticket
+  std::vector<prg_step> rows((size_t)reps + 1, *step);
+  char* scratch = nullptr;
+  const size_t tab = sizeof(prg_step) * rows.size();
+  PRG_HIP(hipMalloc(&scratch, tab + 2 * sizeof(int)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = PRG_OK;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess && rc == PRG_OK) { set_error(std::string("prg_debug_sampler_step: ") + hipGetErrorString(e)); rc = PRG_E_HIP; } };
+  fail(hipMemcpyAsync(scratch, rows.data(), tab, hipMemcpyHostToDevice, s));
+  fail(hipMemsetAsync(scratch + tab, 0, 2 * sizeof(int), s));
+  fail(hipEventCreate(&e0));
+  fail(hipEventCreate(&e1));
+  if (rc == PRG_OK) {
+    SamplerStepArgs a{};
+    a.x = x; a.u = u; a.cond = img_cond; a.noise = nullptr; a.steps = reinterpret_cast<const prg_step*>(scratch);
+    a.step_idx = reinterpret_cast<int*>(scratch + tab); a.ticket = a.step_idx + 1; a.seeds = seeds; a.final_out = x;
+    a.B = B; a.HW = HW; a.n_steps = reps + 1;
+    fail(hipEventRecord(e0, s));
+    for (int i = 0; i < reps && rc == PRG_OK; ++i) rc = launch_sampler_step(a, s);
+    fail(hipEventRecord(e1, s));
+    fail(hipStreamSynchronize(s));
+    float ms = 0.0f;
+    if (rc == PRG_OK) fail(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_us) *avg_us = ms * 1e3f / (float)reps;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
+  return rc;
+}

@@ -86,7 +86,8 @@ struct ProfileSink {  // per-launch conv timing (bench roofline)
   void add_shape(const Rec& r, double ms) {
     for (auto& sh : shapes)
       if (sh.cin == r.key.cin && sh.cout == r.key.cout && sh.k == r.key.k && sh.stride == r.key.stride && sh.ups == r.key.ups &&
-          sh.hout == r.key.hout && sh.wout == r.key.wout && sh.two_source == r.key.two_source && sh.prologue == r.key.prologue) {
+          sh.hout == r.key.hout && sh.wout == r.key.wout && sh.two_source == r.key.two_source && sh.prologue == r.key.prologue &&
+          sh.mx == r.key.mx) {
         sh.launches += 1; sh.ms += ms; sh.flops += r.flops; sh.flops_executed += r.flops_exec;
         return;
       }
@@ -421,6 +422,7 @@ struct UnetImpl : prg_unet {
         ProfileSink::Rec r{};
         r.key.cin = L.d.C0 + L.d.C1; r.key.cout = L.d.Cout; r.key.k = L.d.KH; r.key.stride = L.d.stride; r.key.ups = L.d.ups;
         r.key.hout = L.d.Hout; r.key.wout = L.d.Wout; r.key.two_source = L.d.C1 > 0; r.key.prologue = (L.pro_a != nullptr || L.pro_fold.acc != nullptr);
+        r.key.mx = conv_last_was_mx();
         r.flops = conv_flops(L.d); r.flops_exec = conv_flops(L.d) * conv_last_exec_scale();
         if (prof->recs.size() < prof->used) prof->recs.resize(prof->used);
         prof->recs[prof->used - 1] = r;

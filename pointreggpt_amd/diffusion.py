@@ -56,7 +56,7 @@ def ddim_times(total: int, steps: int) -> List[int]:
 class _ProfileShape(C.Structure):     # include/prg.h: prg_profile_shape
     _fields_ = [("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32),
                 ("hout", C.c_int32), ("wout", C.c_int32), ("two_source", C.c_int32), ("prologue", C.c_int32),
-                ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("flops_executed", C.c_double)]
+                ("mx", C.c_int32), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("flops_executed", C.c_double)]
 
 class GaussianDiffusion:
     """Sampling half of the reference class: same constructor keywords, ``sample(param_cond=, img_cond=)``."""

@@ -371,3 +371,29 @@ def test_pin_rank_cpus_in_a_subprocess():
     if len(before) >= 2:
         assert info["pinned"] and after == before[len(before) // 2 + (len(before) % 2 > 0 and 0):] or set(after) < set(before)
         assert len(after) == len(before) // 2
+
+
+def test_bench_contract_line_is_short_for_a_full_result():
+    """bench.py's stdout line is built key by key from the full result and stays under 4 KB (round 5's 22 KB line was not parsed by
+    the driver): fed with the full round-5 result of the driver's own command (profiles/r05_end_bench_driver_command.json) plus an
+    8-rank table, the line keeps every contract key, `roofline`, `cpu_baseline`, and names the sidecar."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05_end_bench_driver_command.json")).read().strip().splitlines()[-1])
+    full["per_rank"] = [{"rank": r, "setup_s": 40.0 + r, "warmup_s": 20.0, "timed_s": 86.0 + 0.1 * r, "device_bytes_in_use": 9 << 30,
+                         "pinned_cpus": 32, "numa_node": r // 4} for r in range(8)]
+    line = bench.contract_line(full, bench.SIDECAR)
+    assert len(line) < bench.LINE_LIMIT == 4096 and "\n" not in line
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity_mode", "configs4", "e2e_files", "full"):
+        assert k in c, k
+    assert c["value"] == full["value"] and c["roofline"]["frac"] == full["roofline"]["frac"] and abs(c["roofline"]["traffic"] / full["roofline"]["traffic"] - 1) < 1e-4
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-12
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+    assert "workload" in c["config"] and "model" not in c["config"]
+    assert c["per_rank_timed_s"] == {"min": 86.0, "max": 86.7}
+    # a pathological leg cannot break the contract: the optional objects are dropped before the limit is crossed
+    full["config"]["workload"] = "w" * 3000
+    assert len(bench.contract_line(full, bench.SIDECAR)) < 4096
