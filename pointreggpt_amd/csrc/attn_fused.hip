@@ -845,11 +845,11 @@ int launch_tail(const bf16_t* h, const float* A, const float* Bc, const bf16_t* 
                 const bf16_t* wres, const float* bres, bf16_t* out, int B, int N, hipStream_t s, const GnFold& fold,
                 const float* head_w = nullptr, const float* head_b = nullptr, float* head_out = nullptr, int head_sigmoid = 0) {
   const size_t lds = (size_t)kTP * (CIN + 8 + COUT + 8) * 2;
-  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
-  if (!attr) {
+  static DeviceOnce attr;   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
+  if (!attr.done()) {
     int rc = set_lds(&resblock_tail_fused_kernel<CIN, COUT>, lds);
     if (rc) return rc;
-    attr = true;
+    attr.mark();
   }
   resblock_tail_fused_kernel<CIN, COUT><<<dim3(tail_slabs(N), B), 256, lds, s>>>(h, A, Bc, s0, C0, s1, C1, wres, bres, out, N, head_w, head_b,
                                                                                  head_out, head_sigmoid, fold);
@@ -864,8 +864,8 @@ constexpr bool kPsumDefault = C >= 128;   // (measured: C = 64 58 against 70 us 
 template <int C>
 int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const float* bias, const float* out_g, bf16_t* out,
              float* ws, int B, int N, const float* kshift, hipStream_t s) {
-  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
-  if (!attr) {
+  static DeviceOnce attr;   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
+  if (!attr.done()) {
     int rc;
     if ((rc = set_lds(&la_kmax_fused_kernel<C>, lds_kmax<C>()))) return rc;
     if ((rc = set_lds(&la_ctx_fused_kernel<C, false, false>, lds_kmax<C>()))) return rc;
@@ -874,7 +874,7 @@ int launch_c(const bf16_t* x, const bf16_t* wqkv, const bf16_t* wout, const floa
     if ((rc = set_lds(&la_ctx_fused_kernel<C, true, true>, lds_kmax<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, false>, lds_out<C>()))) return rc;
     if ((rc = set_lds(&la_out_fused_kernel<C, true>, lds_out<C>()))) return rc;
-    attr = true;
+    attr.mark();
   }
   const int nslab = la_slabs(N);
   float* pmax = ws;
@@ -913,11 +913,11 @@ template <int NT, int QS>
 static int launch_attn_big(const bf16_t* qkv, bf16_t* out, int B, hipStream_t s) {
   constexpr int N = 32 * NT;
   constexpr size_t lds = ((size_t)N * 40 + (size_t)32 * (N + 8)) * 2;
-  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
-  if (!attr) {
+  static DeviceOnce attr;   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
+  if (!attr.done()) {
     int rc = set_lds(&full_attn_mfma_big_kernel<NT, QS>, lds);
     if (rc) return rc;
-    attr = true;
+    attr.mark();
   }
   full_attn_mfma_big_kernel<NT, QS><<<dim3(4, B, QS), 256, lds, s>>>(qkv, out);
   PRG_LAUNCH_CHECK();

@@ -491,10 +491,10 @@ constexpr size_t lds_out() {
 template <int C>
 int launch_c(const float* x, const uint16_t* wqkv_h, const uint16_t* wqkv_l, const uint16_t* wout_h, const uint16_t* wout_l,
              const float* bias, const float* out_g, float* out, float* ws, int B, int N, hipStream_t s) {
-  static std::atomic<bool> attr{false};
-  if (!attr) {
+  static DeviceOnce attr;
+  if (!attr.done()) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la_out_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out<C>()));
-    attr = true;
+    attr.mark();
   }
   const int ntiles = N / kTP, nslab = ceil_div(ntiles, sp_tpb(ntiles));
   float* ctxp = ws;
@@ -657,10 +657,10 @@ template <int NT, int QS>
 int launch_fa(const float* qkv, float* out, int B, hipStream_t s) {
   constexpr int N = 32 * NT, KB = N < 256 ? N : 256;
   constexpr size_t lds = (size_t)(2 * KB * 40 + 2 * 32 * (KB + 8)) * 2;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set.load(std::memory_order_acquire)) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(full_attn_split_kernel<NT, QS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set.store(true, std::memory_order_release);
+    attr_set.mark();
   }
   full_attn_split_kernel<NT, QS><<<dim3(4, B, QS), 256, lds, s>>>(qkv, out);
   PRG_LAUNCH_CHECK();

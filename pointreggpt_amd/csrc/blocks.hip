@@ -905,10 +905,10 @@ int launch_linear(const float* x, int ldx, int xoff, const float* W, int ldw, in
                   int ldy, int R, int I, int O, int act_in, int act_out, hipStream_t s) {
   PRG_CHECK(x && W && y && R > 0 && I > 0 && O > 0, "linear: bad arguments");
   const dim3 grid(ceil_div(O, 4 * kLinOutPerWave), ceil_div(R, kLinRows));
-  static std::atomic<bool> attr{false};   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
-  if (!attr) {
+  static DeviceOnce attr;   // one-time opt-in; atomic: lanes launch from several host threads (idempotent call)
+  if (!attr.done()) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinSmem));
-    attr = true;
+    attr.mark();
   }
   linear_kernel<<<grid, 256, kLinSmem, s>>>(x, ldx, xoff, W, ldw, woff, bias, y, ldy, R, I, O, act_in, act_out);
   PRG_LAUNCH_CHECK();

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <atomic>
 #include <string>
 
 #include "../../include/prg.h"
@@ -31,6 +33,23 @@ int fail(int code, const std::string& msg);
     hipError_t _e = hipGetLastError();                                                           \
     if (_e != hipSuccess) return ::prg::fail(PRG_E_HIP, std::string("launch: ") + hipGetErrorString(_e)); \
   } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// per-DEVICE one-time state: hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count belong to a device, not to the
+// process — a process that drives a second GPU must opt in there too.  One bit per device ordinal; atomic because
+// lanes launch from several host threads (the guarded calls are idempotent, a race is benign).
+// ---------------------------------------------------------------------------------------------
+struct DeviceOnce {
+  std::atomic<uint64_t> mask{0};
+  static uint64_t bit() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return (uint64_t)1 << (d & 63);
+  }
+  bool done() const { return (mask.load(std::memory_order_acquire) & bit()) != 0; }
+  void mark() { mask.fetch_or(bit(), std::memory_order_release); }
+};
+int device_cu_count();   // multiProcessorCount of the CURRENT device (cached per device ordinal); 0 on failure
 
 // ---------------------------------------------------------------------------------------------
 // bf16 storage type (raw 16 bits; conversions round-to-nearest-even, NaN preserved)

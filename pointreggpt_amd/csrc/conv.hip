@@ -1352,7 +1352,7 @@ void pack_stem_mfma_weights_split(const float* w /* [64][Cin][7][7] */, int Cin,
   for (int co = 0; co < 64; ++co) {
     float m = 0.0f;
     for (int i = 0; i < Cin * 49; ++i) m = std::fmax(m, std::fabs(w[(size_t)co * Cin * 49 + i]));
-    if (m > 0.0f && std::isfinite(m)) {
+    if (m >= 0x1p-100f && std::isfinite(m)) {   // (a dead / denormal channel stays unscaled: 2^k would overflow, pack_conv_weight_split)
       int e = 0;
       (void)std::frexp(m, &e);
       mul[co] = std::ldexp(1.0f, 10 - e);

@@ -545,13 +545,8 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   if ((size_t)d.B * d.Hin * d.Win * 128 + 4096 >= ((size_t)1 << 31)) return 0;
   const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH;
   const int total = tiles_x * tiles_y * d.B;
-  static int num_cus = 0;
-  if (!num_cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    num_cus = p.multiProcessorCount;
-  }
+  const int num_cus = device_cu_count();
+  if (num_cus <= 0) return 0;
   int grid = (total < num_cus ? total : num_cus) & ~7;       // multiple of 8: XCD-contiguous tile runs
   if (grid < 8) return 0;                                    // tiny launches stay on the generic kernels
   const int cpg = L.gn_groups > 0 ? 64 / L.gn_groups : 0;
@@ -559,7 +554,7 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
              tiles_x * tiles_y * 2 * split_n <= kGnMaxSplit;
   if (L.gn_partials && !fuse) return 0;
-  static std::atomic<bool> attr_done[5];     // zero-initialised; atomic: lanes launch from several host threads
+  static DeviceOnce attr_done[5];     // zero-initialised; atomic: lanes launch from several host threads
   const GnFold& pf = L.pro_fold;
   const bool fold_ok = pf.acc && pf.P && pf.Q && pf.G * pf.cpg == 64 && pf.cpg % 8 == 0;
   if (pf.acc && !fold_ok) return 0;
@@ -570,10 +565,10 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
   const void* const fns[5] = {reinterpret_cast<const void*>(&conv3x3_c64_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_c64_kernel<1, false>),
                               reinterpret_cast<const void*>(&conv3x3_c64_kernel<2, false>), reinterpret_cast<const void*>(&conv3x3_c64_kernel<3, false>),
                               reinterpret_cast<const void*>(&conv3x3_c64_kernel<0, true>)};
-  if (!attr_done[variant]) {
+  if (!attr_done[variant].done()) {
     hipError_t e = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_LDS);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(c64 conv): ") + hipGetErrorString(e));
-    attr_done[variant] = true;
+    attr_done[variant].mark();
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 * split_n : 0;
   // the image-completing workgroup folds the statistics into the coefficients itself (no gn_coeff launch)

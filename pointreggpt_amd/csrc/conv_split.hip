@@ -25,18 +25,7 @@
 
 #include "conv_epi.h"
 
-#ifndef PRG_SPLIT_MIX
-#define PRG_SPLIT_MIX 1       // 1: the lo half's v - hi as one v_fma_mix_f32 per element; 0: convert back + subtract (A/B builds)
-#endif
-#ifndef PRG_SPLIT_EPI
-#define PRG_SPLIT_EPI 1       // 1: direct-store epilogue of the symmetric kernel (no LDS stage); 0: the shared transposing epilogue
-#endif
-#ifndef PRG_SPLIT_ORDER
-#define PRG_SPLIT_ORDER 0     // 1: fragment loads + weight prefetch in front of the staging code (experiment)
-#endif
-#ifndef PRG_SPLIT_EXP
-#define PRG_SPLIT_EXP 0      // ablation builds (tools/split_ablate.sh): 1 no MFMAs, 2 no split arithmetic, 3 no epilogue, 4 no weight loads, 5 no halo staging in the loop
-#endif
+#include "conv_split_ablate.h"
 
 namespace prg {
 
@@ -45,7 +34,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // 8 consecutive channels -> their hi and lo halves as two 16-byte MFMA operand units
-template <bool MIX = (PRG_SPLIT_MIX != 0)>
+template <bool MIX = true>
 __device__ inline void split8(const float (&v)[8], uint4& hi, uint4& lo) {
   f16x8 h, l;
 #pragma unroll
@@ -75,27 +64,8 @@ __device__ inline void split8(const float (&v)[8], uint4& hi, uint4& lo) {
 }
 
 // SiLU of the fused prologue: hardware exp2 / reciprocal (1 ulp each) — ~2e-7 relative, the size of the contraction's own error
-#ifndef PRG_SPLIT_SILU
-#define PRG_SPLIT_SILU 0      // 0: hardware exp2 / rcp; 1: the parity mode's expf + IEEE divide; 2: compensated exponent + one Newton step
-#endif
 __device__ inline float silu_fast(float x) {
-#if PRG_SPLIT_SILU == 1
-  return x / (1.0f + expf(-x));
-#elif PRG_SPLIT_SILU == 2
-  // t = -x log2(e) to ~2^-48 relative: t_hi + t_lo with the constant split in two; exp2(t) = exp2(t_hi) (1 + t_lo ln 2)
-  const float c_hi = -1.4426950216293335f, c_lo = -1.9259629911e-8f;
-  float t_hi = x * c_hi;
-  const float t_lo = fmaf(x, c_hi, -t_hi) + x * c_lo;
-  t_hi = fminf(t_hi, 126.0f);
-  float e = __builtin_amdgcn_exp2f(t_hi);
-  e = fmaf(e * t_lo, 0.6931471805599453f, e);
-  const float dd = 1.0f + e;
-  float r = __builtin_amdgcn_rcpf(dd);
-  r = fmaf(fmaf(-dd, r, 1.0f), r, r);
-  return x * r;
-#else
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
-#endif
 }
 
 __device__ inline f16x8 ld_frag(const uint4* p) { return __builtin_bit_cast(f16x8, *p); }
@@ -158,14 +128,6 @@ __device__ inline void flush_acc(f32x16 (&acc)[TM][2], f32x16 (&tot)[TM][2]) {
 // MFMAs compiled out: MFMA 105 + LDS reads 53 + L1/TA 47 + split 21 + epilogue 48 us simply added up, identical workgroups
 // run in lockstep and overlap nothing; the first pipelined version 345 us at 8 VALU + 6 SALU instructions per MFMA
 // (rocprofv3 SQ_INSTS_*: address arithmetic and tap bookkeeping); this structure: DESIGN.md section 4.6.
-#if PRG_SPLIT_EXP == 6
-__device__ unsigned long long g_split_trace[16];   // per-phase cycle totals of workgroup 0 / wave 0 (tools/split_ablate.sh 6)
-#define TRACE_T(n) const long long tt##n = clock64()
-#define TRACE_ADD(i, a, b) if (trace_on) tr[i] += (unsigned long long)((b) - (a))
-#else
-#define TRACE_T(n)
-#define TRACE_ADD(i, a, b)
-#endif
 
 template <int N>
 struct IC {
@@ -288,12 +250,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int u = 0; u < 8; ++u) v[u] = 0.0f;
       }
       uint4 vh, vl;
-#if PRG_SPLIT_EXP == 2      // ablation: no split arithmetic
-      vh = __builtin_bit_cast(uint4, h0); vl = __builtin_bit_cast(uint4, h1);
-#else
       if (L.pro_a) split8<false>(v, vh, vl);
       else split8(v, vh, vl);
-#endif
       char* p = Ah + buf * HBYTES + w_lane[k];
       *reinterpret_cast<uint4*>(p) = vh;
       *reinterpret_cast<uint4*>(p + 64) = vl;
@@ -381,10 +339,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-#if PRG_SPLIT_EXP == 1      // ablation: no MFMAs (keep the fragment loads alive)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j][0] += (float)(fa[S][st][0][0] + fa[S][st][1][1] + fw[S][st][2 * j][2] + fw[S][st][2 * j + 1][3]);
-#else
       // term-major: back-to-back MFMAs never wait on the same accumulator; the two cross terms first (small), then hi * hi
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][st][1], fw[S][st][2 * j], acc[j], 0, 0, 0);
@@ -392,21 +346,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][st][0], fw[S][st][2 * j + 1], acc[j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][st][0], fw[S][st][2 * j], acc[j], 0, 0, 0);
-#endif
     }
   };
 
-#if PRG_SPLIT_EXP == 6
-  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool trace_on = blockIdx.x == 0 && tid == 0;
-  const long long t_begin = clock64();
-#endif
   // one tap of chunk c; P = parity of the chunk (register set of tap T = (T + P) & 1)
   auto body = [&](auto PAR, auto TAP, int c) {
     constexpr int P = decltype(PAR)::value, T = decltype(TAP)::value, S = (T + P) & 1;
     const int it = c * 9 + T;
     const bool more = c + 1 < nchunks;
-    TRACE_T(0);
     // (1) all but the newest weight prefetch (tile it + 2, issued by the previous body AFTER its halo pass) have landed — tile
     //     it + 1 in particular, and that halo pass; this wave's fragment loads of `it` and staging ds_writes are done.
     //     A RAW s_barrier: __syncthreads() makes hipcc drain vmcnt(0) in front of it while an LDS-DMA is in flight, i.e. a
@@ -417,18 +364,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (NS == 3 && (T + 2 < 9 || more)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // tile it + 1 is visible; nobody still reads tile it's ring slot or the previous chunk's halo
-    TRACE_T(1);
-#if PRG_SPLIT_ORDER == 1
-#if PRG_SPLIT_EXP != 4
-    // (3) weight tile it + NS into the slot tile `it` just vacated
-    if constexpr (T + NS < 9) gload_b(c, T + NS, NS == 3 ? T % 3 : it & 1);
-    else if (more) gload_b(c + 1, T + NS - 9, NS == 3 ? T % 3 : it & 1);
-#endif
-    // (4) fragments of the next tap into the other register set, (5) the MFMAs of this tap
-    if constexpr (T < 8) reads(IC<1 - S>(), IC<T + 1>(), c & 1, NS == 3 ? (T + 1) % 3 : (it + 1) & 1);
-    else if (more) reads(IC<1 - S>(), IC<0>(), (c + 1) & 1, NS == 3 ? 0 : (it + 1) & 1);
-    TRACE_T(2);
-#if PRG_SPLIT_EXP != 5
     if (more) {
       // (2) the next chunk's halo, one pass per tap: written one tap after its load, into the other halo buffer
       //     (loaded at taps 0 .. NH - 1, written DIST taps later: the loads come from HBM — ~2 us, two to four taps)
@@ -436,31 +371,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if constexpr (T >= DIST && T < DIST + NH) halo_write((c + 1) & 1, IC<T - DIST>());
       if constexpr (T < NH) halo_load(c + 1, IC<T>());
     }
-#endif
-#else
-#if PRG_SPLIT_EXP != 5
-    if (more) {
-      // (2) the next chunk's halo, one pass per tap: written one tap after its load, into the other halo buffer
-      //     (loaded at taps 0 .. NH - 1, written DIST taps later: the loads come from HBM — ~2 us, two to four taps)
-      if constexpr (T == 0) pro_load(c + 1);
-      if constexpr (T >= DIST && T < DIST + NH) halo_write((c + 1) & 1, IC<T - DIST>());
-      if constexpr (T < NH) halo_load(c + 1, IC<T>());
-    }
-#endif
-    TRACE_T(2);
-#if PRG_SPLIT_EXP != 4
     // (3) weight tile it + NS into the slot tile `it` just vacated
     if constexpr (T + NS < 9) gload_b(c, T + NS, NS == 3 ? T % 3 : it & 1);
     else if (more) gload_b(c + 1, T + NS - 9, NS == 3 ? T % 3 : it & 1);
-#endif
     // (4) fragments of the next tap into the other register set, (5) the MFMAs of this tap
     if constexpr (T < 8) reads(IC<1 - S>(), IC<T + 1>(), c & 1, NS == 3 ? (T + 1) % 3 : (it + 1) & 1);
     else if (more) reads(IC<1 - S>(), IC<0>(), (c + 1) & 1, NS == 3 ? 0 : (it + 1) & 1);
-#endif
-    TRACE_T(3);
     mfmas(IC<S>());
-    TRACE_T(4);
-    TRACE_ADD(0, tt0, tt1); TRACE_ADD(1, tt1, tt2); TRACE_ADD(2, tt2, tt3); TRACE_ADD(3, tt3, tt4);
     if constexpr (T == 8) {                    // the 288-term partial of this channel chunk
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -482,21 +399,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (c + 1 < nchunks) chunk_body(IC<1>(), c + 1);
   }
 
-#if PRG_SPLIT_EXP == 6
-  const long long t_loop = clock64();
-#endif
   double gs, gq;
   auto row_to_m = [&](int r) -> int64_t {
     const int p = wave * 32 + r;
     return ((int64_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
   };
-#if PRG_SPLIT_EXP == 3        // ablation: no epilogue (one store per lane keeps the accumulators alive)
-  float sum = 0;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) sum += tot[0][e] + tot[1][e];
-  L.out[(size_t)row_to_m(l31) * d.Cout + tn * BN + hi] = sum;
-  return;
-#endif
   if (L.split_scale) {                         // undo the packer's per-channel power-of-two weight scale (exact)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -505,15 +412,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int e = 0; e < 16; ++e) tot[j][e] *= sc;
     }
   }
-#if PRG_SPLIT_EPI == 0
-  f32x16 res[1][2] = {{tot[0], tot[1]}};
-  epilogue_store<float, 1, decltype(row_to_m), true>(L, res, stage + wave * 32 * 68, lane, tn * BN, row_to_m, gs, gq);
-  if (fuse_stats) {
-    const int nsplit = tiles_x * tiles_y;
-    float* dst = L.gn_partials + ((size_t)b * nsplit + ty * tiles_x + tx) * L.gn_groups * 2;
-    epilogue_stats<4, 1>(reinterpret_cast<double*>(stage + NW * 32 * 68), gs, gq, wave, lane, tn * BN, d.Cout, L.gn_groups, dst);
-  }
-#else
   // DIRECT epilogue: the accumulator layout already has lanes 0-31 = 32 consecutive channels of ONE pixel (register e of half hi
   // is pixel row (e & 3) + 8 (e >> 2) + 4 hi), so a dword store per register writes two full 128-byte lines per wave-instruction —
   // no LDS transpose, no barrier; the GroupNorm partial sums come from lane reductions (a group's channels are adjacent lanes).
@@ -576,15 +474,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
     }
   }
-#endif
-#if PRG_SPLIT_EXP == 6
-  if (trace_on) {
-    for (int i = 0; i < 4; ++i) g_split_trace[i] = tr[i];
-    g_split_trace[4] = (unsigned long long)(t_loop - t_begin);
-    g_split_trace[5] = (unsigned long long)(clock64() - t_loop);
-    g_split_trace[6] = (unsigned long long)niter;
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,14 +553,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       const int c = it / NT, tap = it - NT * c;
       const char* p = wtile + (size_t)(tap * L.split_kchunks + c) * wstep;
       char* dst = Bs + ((it & (NS - 1)) * BN + pw * WPW * 8) * 128;
-#if PRG_SPLIT_EXP != 25      // (timing ablations of this kernel: 21 no MFMAs, 23 no halo staging, 24 no fragment reads, 25 no weight DMA)
+      if constexpr (!ablate::ws_no_wdma) {
 #pragma unroll
-      for (int r = 0; r < WPW; ++r)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
-                                         (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
-#else
-      (void)p; (void)dst;
-#endif
+        for (int r = 0; r < WPW; ++r)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
+                                           (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
+      }
     };
     gload_b(0);
     if (niter > 1) gload_b(1);
@@ -712,16 +599,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       const bool first = c < d.C0;
       const float* base = first ? L.src0 : L.src1;
       const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
-#if PRG_SPLIT_EXP != 23
+      if constexpr (!ablate::ws_no_halo) {
 #pragma unroll
-      for (int k = 0; k < NHP; ++k) {
-        const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
-        g0[k] = p[0];
-        g1[k] = p[1];
+        for (int k = 0; k < NHP; ++k) {
+          const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
+          g0[k] = p[0];
+          g1[k] = p[1];
+        }
       }
-#else
-      (void)base; (void)Cs; (void)cc;
-#endif
     };
     float4 (&g0)[NHP] = gA0;
     float4 (&g1)[NHP] = gA1;
@@ -730,16 +615,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       const bool first = c < d.C0;
       const float* base = first ? L.src0 : L.src1;
       const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
-#if PRG_SPLIT_EXP != 23
+      if constexpr (!ablate::ws_no_halo) {
 #pragma unroll
-      for (int k = 0; k < NHP; ++k) {
-        const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
-        g0[k] = p[0];
-        g1[k] = p[1];
+        for (int k = 0; k < NHP; ++k) {
+          const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
+          g0[k] = p[0];
+          g1[k] = p[1];
+        }
       }
-#else
-      (void)base; (void)Cs; (void)cc;
-#endif
     };
     float pa[8], pb[8];
     auto pro_load = [&](int chunk) {
@@ -754,11 +637,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     auto write_pass_set = [&](int buf, auto K, const float4 (&h0)[NHP], const float4 (&h1)[NHP]) {
       constexpr int k = decltype(K)::value;
       const int hp = prow + k * 32;
-#if PRG_SPLIT_EXP == 23
-      if (false) {
-#else
-      if (hp < HALO) {
-#endif
+      if (!ablate::ws_no_halo && hp < HALO) {
         float v[8] = {h0[k].x, h0[k].y, h0[k].z, h0[k].w, h1[k].x, h1[k].y, h1[k].z, h1[k].w};
         if (L.pro_a) {
 #pragma unroll
@@ -865,12 +744,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     constexpr int toff = UP ? (T / 2) * RSTRIDE + (T % 2) * PITCH : (T / 3) * RSTRIDE + (T % 3) * PITCH;
     const char* A = Ah + cb * HBYTES + toff + st * 32 + pho;
     const char* Bb = Bs + slot * (BN * 128);
-#if PRG_SPLIT_EXP == 24
-    (void)A; (void)Bb;
+    if constexpr (ablate::ws_no_reads) {
+      (void)A; (void)Bb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[st][i])); asm volatile("" : "+v"(fw[st][i])); }   // (opaque values, no LDS read)
-    return;
-#endif
+      for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[st][i])); asm volatile("" : "+v"(fw[st][i])); }   // (opaque values, no LDS read)
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       fa[st][2 * i] = ld_frag(reinterpret_cast<const uint4*>(A + a_lane[i]));
@@ -884,11 +763,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
   };
   auto mfmas = [&](auto ST) {
     constexpr int st = decltype(ST)::value;
-#if PRG_SPLIT_EXP == 21
+    if constexpr (ablate::ws_no_mfma) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[st][i])); asm volatile("" ::"v"(fw[st][i])); }   // (keep the fragment loads alive)
-    return;
-#endif
+      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[st][i])); asm volatile("" ::"v"(fw[st][i])); }   // (keep the fragment loads alive)
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -902,10 +781,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j], acc[i][j], 0, 0, 0);
   };
-#if PRG_SPLIT_EXP == 6
-  unsigned long long ws_wait = 0;
-  const bool ws_trace = blockIdx.x == 0 && tid == 0;
-#endif
   auto body = [&](auto TAP, int c) {
     constexpr int T = decltype(TAP)::value;
     const int it = c * NT + T;
@@ -913,14 +788,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     // barrier #it (tap 0 runs straight after the prologue's barrier #0): weight tiles it, it + 1 are in LDS, tile it - 1's slot
     // is free for the producers, this chunk's halo is complete.  No wait: a consumer's outstanding fragment loads read only
     // images that stay valid for another tap.
-#if PRG_SPLIT_EXP == 6
-    const long long tb0 = clock64();
     if (T > 0 || c > 0) asm volatile("s_barrier" ::: "memory");
-    const long long tb1 = clock64();
-    if (ws_trace) { ws_wait += (unsigned long long)(tb1 - tb0); }
-#else
-    if (T > 0 || c > 0) asm volatile("s_barrier" ::: "memory");
-#endif
     reads(IC<1>(), TAP, c & 1, it & (NS - 1));
     __builtin_amdgcn_sched_barrier(0);
     mfmas(IC<0>());
@@ -938,13 +806,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
           for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
     }
   };
-#if PRG_SPLIT_EXP == 6
-  const long long tw0 = clock64();
-#endif
   asm volatile("s_barrier" ::: "memory");                // the producers' prologue: chunk 0's halo, weight tiles 0 and 1
-#if PRG_SPLIT_EXP == 6
-  const long long tw1 = clock64();
-#endif
   reads(IC<0>(), IC<0>(), 0, 0);
   for (int c = 0; c < nchunks; ++c) {
     body(IC<0>(), c); body(IC<1>(), c); body(IC<2>(), c); body(IC<3>(), c);
@@ -953,9 +815,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier(niter): every consumer is done with the LDS images
-#if PRG_SPLIT_EXP == 6
-  const long long tw2 = clock64();
-#endif
   // DIRECT epilogue (as in the symmetric kernel): register e of lane half hi is pixel row (e & 3) + 8 (e >> 2) + 4 hi, lanes 0-31
   // are 32 consecutive channels: a dword store per register writes two full 128-byte lines per wave-instruction; GroupNorm partial
   // sums by lane reductions (a group's channels are adjacent lanes), one slab per (tile, pixel half): no LDS, no barrier.
@@ -1025,15 +884,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
       }
     }
   }
-#if PRG_SPLIT_EXP == 6
-  if (ws_trace) {
-    g_split_trace[8] = ws_wait;
-    g_split_trace[9] = (unsigned long long)(tw1 - tw0);
-    g_split_trace[10] = (unsigned long long)(tw2 - tw1);
-    g_split_trace[11] = (unsigned long long)(clock64() - tw2);
-    g_split_trace[12] = (unsigned long long)niter;
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1055,14 +905,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
 // LDS = 2 x 50,688 (halos, 144-byte pixels, rows of 0 mod 16 slots) + 4 x 8,192 (weights) = 134,144 bytes.
 // The arithmetic is the symmetric kernel's, term for term (same MFMA sequence per accumulator, 288-term partials, same epilogue
 // expression): only the GroupNorm slab partition differs.
-// MERGED (round 5, second half): the four producer waves ALL stage the halo (a quarter each: six 64-pixel passes instead of eleven
-// 32-pixel ones on two waves) and ALL move weight tiles (two LDS-DMA instructions each instead of four on two waves).  Measured with
-// the timing ablations of this kernel (profiles/r05_p64_ablations.txt): the halo staging — loads, split arithmetic, LDS writes — costs
-// 53 of a level-0 launch's 248 us although its two waves only carry ~3 k VALU cycles per 13.8 k-cycle tile: on this part VALU work on
-// a SIMD adds to that SIMD's MFMA time, and the two halo waves sat on the SIMDs of consumers 0 and 1 while SIMDs 2 and 3
-// hosted the nearly idle weight movers.  One in-order vmcnt queue per wave now carries both kinds of load; the counted waits below
-// are written for the issue order  W(it + 3), [coefficients, halo loads of the next chunk at tap 0], ...
-template <int NS, bool MERGED>
+// (Round 5 also measured a MERGED-producer form — all four producer waves staging a quarter of the halo and a quarter of each weight
+// tile — at 2-3 % slower, profiles/r05_p64_ablations.txt; removed in round 6.)
+template <int NS>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLaunch<float> L, const int tiles_x, const int tiles_y,
                                                                    const int ntiles, const int fuse_stats) {
   constexpr int TH = 16, TW = 16, BN = 64, CH = 32, NT = 9;
@@ -1101,178 +946,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
   const int Hs = d.Hout, Ws = d.Wout;
   const int tiles_img = tiles_x * tiles_y;
 
-  if constexpr (MERGED) {
-    if (wave >= 4) {
-      // ------------------------------------- producers: halo quarter + weight quarter each -------------------------------------
-      constexpr int NHQ = (HALO * 4 + 255) / 256;          // halo staging passes of the 256 producer threads (6)
-      constexpr int WPQ = BN / 8 / 4;                      // global_load_lds instructions per producer wave and weight tile (2)
-      static_assert(NHQ == 6 && WPQ == 2, "passes");
-      const int pt = tid - 256, q = pt & 3, prow = pt >> 2;  // channels q * 8 .. + 7 of halo pixels prow + 64 k
-      const int pw = wave - 4;
-      int wsrc[WPQ];
-#pragma unroll
-      for (int r = 0; r < WPQ; ++r) {
-        const int n = (pw * WPQ + r) * 8 + (lane >> 3);
-        wsrc[r] = n * 128 + (((lane & 7) ^ ((n >> 1) & 7)) << 4);
-      }
-      const char* wtile = reinterpret_cast<const char*>(L.w_split);
-      int c_n = 0, tap_n = 0;                              // (chunk, tap) of the next weight tile: the sequence repeats per pixel tile
-      auto gload_next = [&](int it) {                      // (issued unconditionally: past the end it re-fetches tiles nobody reads)
-        const char* p = wtile + (size_t)(tap_n * L.split_kchunks + c_n) * wstep;
-        char* dst = Bs + ((it & (NS - 1)) * BN + pw * WPQ * 8) * 128;
-#if PRG_SPLIT_EXP != 15
-#pragma unroll
-        for (int r = 0; r < WPQ; ++r)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
-                                           (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
-#else
-        (void)p; (void)dst;
-#endif
-        if (++tap_n == NT) { tap_n = 0; if (++c_n == nchunks) c_n = 0; }
-      };
-      int hyx[NHQ], wl[NHQ];                               // tile-independent: halo coordinates and LDS address of pass k
-#pragma unroll
-      for (int k = 0; k < NHQ; ++k) {
-        const int hp = prow + k * 64;
-        const int hy = hp / HP, hx = hp - hy * HP;
-        hyx[k] = hp < HALO ? ((hy << 8) | hx) : -1;
-        wl[k] = hy * RSTRIDE + hx * PITCH + q * 16;
-      }
-      int hsrc[NHQ];
-      int img = 0;
-      auto set_tile = [&](int kt) {
-        int lin = t_first + kt * t_stride;
-        const int tx = lin % tiles_x; lin /= tiles_x;
-        const int ty = lin % tiles_y;
-        img = lin / tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
-#pragma unroll
-        for (int k = 0; k < NHQ; ++k) {
-          hsrc[k] = -1;
-          if (hyx[k] >= 0) {
-            int y = y0 - 1 + (hyx[k] >> 8), x = x0 - 1 + (hyx[k] & 255);
-            if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) {
-              if (d.ups) { y >>= 1; x >>= 1; }
-              hsrc[k] = (img * d.Hin + y) * d.Win + x;
-            }
-          }
-        }
-      };
-      float4 g0[NHQ], g1[NHQ];
-      auto load_chunk = [&](int chunk) {                   // 12 loads per thread, whatever the pass holds (uniform count for the waits)
-        const int c = chunk * CH + q * 8;
-        const bool first = c < d.C0;
-        const float* base = first ? L.src0 : L.src1;
-        const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
-#if PRG_SPLIT_EXP != 13
-#pragma unroll
-        for (int k = 0; k < NHQ; ++k) {
-          const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
-          g0[k] = p[0];
-          g1[k] = p[1];
-        }
-#else
-        (void)base; (void)Cs; (void)cc;
-#endif
-      };
-      float pa[8], pb[8];
-      auto pro_load = [&](int chunk) {
-        if (L.pro_a) {
-          const float4* a4 = reinterpret_cast<const float4*>(L.pro_a + (size_t)img * d.C0 + chunk * CH + q * 8);
-          const float4* b4 = reinterpret_cast<const float4*>(L.pro_b + (size_t)img * d.C0 + chunk * CH + q * 8);
-          const float4 a0 = a4[0], a1 = a4[1], b0 = b4[0], b1 = b4[1];
-          pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w; pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
-          pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
-        }
-      };
-      auto write_pass = [&](int buf, auto K) {
-        constexpr int k = decltype(K)::value;
-#if PRG_SPLIT_EXP == 13
-        if (false) {
-#else
-        if (hyx[k] >= 0) {
-#endif
-          float v[8] = {g0[k].x, g0[k].y, g0[k].z, g0[k].w, g1[k].x, g1[k].y, g1[k].z, g1[k].w};
-          if (L.pro_a) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = silu_fast(fmaf(v[u], pa[u], pb[u]));
-          }
-          if (hsrc[k] < 0) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = 0.0f;
-          }
-          uint4 vh, vl;
-          if (L.pro_a) split8<false>(v, vh, vl);
-          else split8(v, vh, vl);
-          char* p = Ah + buf * HBYTES + wl[k];
-          *reinterpret_cast<uint4*>(p) = vh;
-          *reinterpret_cast<uint4*>(p + 64) = vl;
-        }
-      };
-      // prologue: weight tiles 0 .. 2 in flight, tile 0's first halo staged
-      gload_next(0);
-      gload_next(1);
-      gload_next(2);                                       // (niter >= 18)
-      set_tile(0);
-      pro_load(0);
-      load_chunk(0);
-      write_pass(0, IC<0>()); write_pass(0, IC<1>()); write_pass(0, IC<2>()); write_pass(0, IC<3>()); write_pass(0, IC<4>()); write_pass(0, IC<5>());
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // -> barrier(0): weight tiles 0 .. 2 landed, halo 0 written
-      int kt = 0, c = 0, it = 0;
-      for (int g = 0; g < nchunks_total; ++g) {
-        const bool more = g + 1 < nchunks_total;
-        int c1 = c + 1, kt1 = kt;
-        if (c1 == nchunks) { c1 = 0; kt1 = kt + 1; }
-        const int nb = (g + 1) & 1;
-        // tap 0: weight tile it + 3 (into tile it - 1's slot, free since barrier(it)), then the next chunk's coordinates, coefficients
-        // and ALL its halo loads.  barrier(it + 1) needs weight tile it + 2 (issued a tap ago): everything issued since may stay in
-        // flight — 2 DMA + 12 halo loads (the 4 coefficient loads, when there are any, sit in front of the halo loads: a count of 14
-        // then waits for two of them as well, which is harmless).
-        gload_next(it + 3);
-        if (more) {
-          if (c1 == 0) set_tile(kt1);
-          pro_load(c1);
-          load_chunk(c1);
-          asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");           // -> barrier(9 g + 1)
-        } else {
-          asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-        }
-        // tap 1: weight tile it + 4.  barrier(it + 2) needs tile it + 3, issued BEFORE the halo loads: 12 + 2 younger operations
-        gload_next(it + 4);
-        if (more) asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");   // -> barrier(9 g + 2)
-        else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-        // taps 2 .. 7: weight tile it + 3 + T and one halo pass each, converted and written (the other halo buffer was last read during
-        // the previous chunk's tap 8); the wait for tile it + 2 + T — younger than the halo loads — also retires those (the in-order
-        // queue: they were issued two taps ago and the first pass needs them now anyway)
-        gload_next(it + 5);
-        if (more) write_pass(nb, IC<0>());
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // -> barrier(9 g + 3)
-        gload_next(it + 6);
-        if (more) write_pass(nb, IC<1>());
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        gload_next(it + 7);
-        if (more) write_pass(nb, IC<2>());
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        gload_next(it + 8);
-        if (more) write_pass(nb, IC<3>());
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        gload_next(it + 9);
-        if (more) write_pass(nb, IC<4>());
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        gload_next(it + 10);
-        if (more) write_pass(nb, IC<5>());
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // -> barrier(9 g + 8)
-        // tap 8: weight tile it + 11; nothing else — the consumers fetch the next chunk's first fragments during it
-        gload_next(it + 11);
-        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");              // -> barrier(9 g + 9)
-        it += NT;
-        c = c1;
-        kt = kt1;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the trailing DMA of tiles nobody reads must not outlive the workgroup's LDS)
-      return;
-    }
-  }
   if (wave >= 6) {
     // ------------------------------------------------ weight producers ------------------------------------------------
     const int pw = wave - 6;
@@ -1287,14 +960,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
     auto gload_next = [&](int it) {
       const char* p = wtile + (size_t)(tap_n * L.split_kchunks + c_n) * wstep;
       char* dst = Bs + ((it & (NS - 1)) * BN + pw * WPW * 8) * 128;
-#if PRG_SPLIT_EXP != 15      // (timing ablations of this kernel, tools/split_ablate.sh: 11 no MFMAs, 12 no epilogue, 13 no halo staging, 14 no fragment reads, 15 no weight DMA)
+      if constexpr (!ablate::p64_no_wdma) {
 #pragma unroll
-      for (int r = 0; r < WPW; ++r)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
-                                         (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
-#else
-      (void)p; (void)dst;
-#endif
+        for (int r = 0; r < WPW; ++r)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
+                                           (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
+      }
       if (++tap_n == NT) { tap_n = 0; if (++c_n == nchunks) c_n = 0; }
     };
     gload_next(0);
@@ -1348,16 +1019,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
       const bool first = c < d.C0;
       const float* base = first ? L.src0 : L.src1;
       const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
-#if PRG_SPLIT_EXP != 13
+      if constexpr (!ablate::p64_no_halo) {
 #pragma unroll
-      for (int k = 0; k < NHP; ++k) {
-        const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
-        g0[k] = p[0];
-        g1[k] = p[1];
+        for (int k = 0; k < NHP; ++k) {
+          const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k] >= 0 ? (size_t)hsrc[k] * Cs + cc : (size_t)0));
+          g0[k] = p[0];
+          g1[k] = p[1];
+        }
       }
-#else
-      (void)base; (void)Cs; (void)cc;
-#endif
     };
     float pa[8], pb[8];
     auto pro_load = [&](int chunk) {
@@ -1371,11 +1040,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
     };
     auto write_pass = [&](int buf, auto K) {
       constexpr int k = decltype(K)::value;
-#if PRG_SPLIT_EXP == 13
-      if (false) {
-#else
-      if (hyx[k] >= 0) {
-#endif
+      if (!ablate::p64_no_halo && hyx[k] >= 0) {
         float v[8] = {g0[k].x, g0[k].y, g0[k].z, g0[k].w, g1[k].x, g1[k].y, g1[k].z, g1[k].w};
         if (L.pro_a) {
 #pragma unroll
@@ -1459,12 +1124,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
   f16x8 fa[2][4], fw[2][4];                              // [k16 step][A: (hi, lo) x row tile | W: (hi, lo) x column tile]
   auto reads = [&](auto ST, auto TAP, int cb, int slot) {
     constexpr int st = decltype(ST)::value, T = decltype(TAP)::value;
-#if PRG_SPLIT_EXP == 14
-    (void)cb; (void)slot; (void)T;
+    if constexpr (ablate::p64_no_reads) {
+      (void)cb; (void)slot; (void)T;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[st][i])); asm volatile("" : "+v"(fw[st][i])); }   // (opaque values, no LDS read)
-    return;
-#endif
+      for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[st][i])); asm volatile("" : "+v"(fw[st][i])); }   // (opaque values, no LDS read)
+      return;
+    }
     constexpr int toff = (T / 3) * RSTRIDE + (T % 3) * PITCH;
     const char* A = Ah + cb * HBYTES + toff + st * 32;
     const char* Bb = Bs + slot * (BN * 128);
@@ -1481,11 +1146,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
   };
   auto mfmas = [&](auto ST) {
     constexpr int st = decltype(ST)::value;
-#if PRG_SPLIT_EXP == 11
+    if constexpr (ablate::p64_no_mfma) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[st][i])); asm volatile("" ::"v"(fw[st][i])); }   // (keep the fragment loads alive)
-    return;
-#endif
+      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[st][i])); asm volatile("" ::"v"(fw[st][i])); }   // (keep the fragment loads alive)
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1577,11 +1242,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
         for (int e = 0; e < 16; ++e) {
           // (sc is an exact power of two: the fused form rounds once, exactly where the product-then-sum form rounds — same bits)
           const float v = __builtin_fmaf(tot[i][j][e], sc, bv);
-#if PRG_SPLIT_EXP == 12
-          if (v == 1.2345e-30f) r0[0] = v;     // (keeps the accumulators alive, stores nothing)
-#else
-          ((e >> 3) ? r1 : r0)[((e & 3) + 8 * ((e >> 2) & 1)) * BN] = v;
-#endif
+          if constexpr (ablate::p64_no_store) {
+            if (v == 1.2345e-30f) r0[0] = v;     // (keeps the accumulators alive, stores nothing)
+          } else {
+            ((e >> 3) ? r1 : r0)[((e & 3) + 8 * ((e >> 2) & 1)) * BN] = v;
+          }
           s1 += v;
           q1 = fmaf(v, v, q1);
         }
@@ -1812,11 +1477,11 @@ static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse
   size_t lds = (size_t)2 * HB + NS * 8192 + 512;      // (+ the statistics scratch of the direct epilogue)
   if (lds < kEpilogueLds) lds = kEpilogueLds;
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y : 0;
-  static std::atomic<bool> attr_done{false};   // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race between lanes is benign)
-  if (!attr_done.load(std::memory_order_acquire)) {
+  static DeviceOnce attr_done;   // > 64 KB of dynamic LDS needs the opt-in (idempotent: a race between lanes is benign)
+  if (!attr_done.done()) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<TH, TW, NS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_done.store(true, std::memory_order_release);
+    attr_done.mark();
     if (std::getenv("PRG_SPLIT_DEBUG")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_split_kernel<TH, TW, NS>, 256, lds);
@@ -1825,16 +1490,6 @@ static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse
   }
   conv3x3_split_kernel<TH, TW, NS><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
   PRG_LAUNCH_CHECK();
-#if PRG_SPLIT_EXP == 6
-  {
-    unsigned long long h[16];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_split_trace), sizeof(h));
-    fprintf(stderr, "trace Cin %d Cout %d %dx%d: iterations %llu | per iteration: wait+barrier %.0f, staging(+floated MFMAs) %.0f, glds+reads %.0f, "
-            "mfma issue %.0f | loop total %llu, epilogue %llu cycles\n", d.C0 + d.C1, d.Cout, d.Hout, d.Wout, h[6], (double)h[0] / h[6], (double)h[1] / h[6],
-            (double)h[2] / h[6], (double)h[3] / h[6], h[4], h[5]);
-  }
-#endif
   return PRG_OK;
 }
 
@@ -1844,10 +1499,10 @@ static int launch_split_ws_up(const ConvLaunch<float>& L, hipStream_t s) {
   const ConvDesc& d = L.d;
   const int tiles_x = d.Win / 16, tiles_y = d.Hin / 8, tiles_n = d.Cout / 128;
   const size_t lds = (size_t)2 * HB + NS * 128 * 128;
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load(std::memory_order_acquire)) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_done.store(true, std::memory_order_release);
+    attr_done.mark();
   }
   conv3x3_split_ws_kernel<NS, true><<<dim3(tiles_x * tiles_y * tiles_n * d.B * 4), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
   PRG_LAUNCH_CHECK();
@@ -1860,22 +1515,13 @@ static int launch_split_ws(const ConvLaunch<float>& L, hipStream_t s, int fuse_s
   const int tiles_x = d.Wout / 16, tiles_y = d.Hout / 8, tiles_n = d.Cout / 128;
   const size_t lds = (size_t)2 * HB + NS * 128 * 128;
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * 2 : 0;
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load(std::memory_order_acquire)) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_ws_kernel<NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_done.store(true, std::memory_order_release);
+    attr_done.mark();
   }
   conv3x3_split_ws_kernel<NS, false><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, fuse_stats);
   PRG_LAUNCH_CHECK();
-#if PRG_SPLIT_EXP == 6
-  {
-    unsigned long long h[16];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_split_trace), sizeof(h));
-    fprintf(stderr, "ws trace Cin %d Cout %d %dx%d: taps %llu | prologue wait %llu | loop %llu cycles = %.0f per tap, of which at the barrier %.0f | "
-            "epilogue %llu\n", d.C0 + d.C1, d.Cout, d.Hout, d.Wout, h[12], h[9], h[10], (double)h[10] / h[12], (double)h[8] / h[12], h[11]);
-  }
-#endif
   return PRG_OK;
 }
 
@@ -1887,22 +1533,16 @@ static int launch_split_p64(const ConvLaunch<float>& L, hipStream_t s, int fuse_
   const int ntiles = tiles_x * tiles_y * d.B;
   const size_t lds = (size_t)2 * HB + NS * 64 * 128;
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * 4 : 0;
-  static std::atomic<int> num_cus{0};
-  if (!num_cus.load(std::memory_order_acquire)) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    PRG_HIP(hipGetDevice(&dev));
-    PRG_HIP(hipGetDeviceProperties(&p, dev));
-    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_p64_kernel<NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_p64_kernel<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    num_cus.store(p.multiProcessorCount, std::memory_order_release);
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_p64_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    attr_done.mark();
   }
-  int grid = ntiles < num_cus.load() ? ntiles : num_cus.load();
+  const int num_cus = device_cu_count();
+  PRG_CHECK(num_cus > 0, "conv3x3_split_p64: no device properties");
+  int grid = ntiles < num_cus ? ntiles : num_cus;
   if (grid >= 8) grid &= ~7;                             // multiple of 8: XCD-contiguous tile runs
-  // PRG_SPLIT_P64_MERGED=1: all four producer waves stage halo AND weights (measured 2-3 % SLOWER: see the kernel's header)
-  static const int merged = [] { const char* e = std::getenv("PRG_SPLIT_P64_MERGED"); return e ? std::atoi(e) : 0; }();
-  if (merged) conv3x3_split_p64_kernel<NS, true><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, ntiles, fuse_stats);
-  else conv3x3_split_p64_kernel<NS, false><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, ntiles, fuse_stats);
+  conv3x3_split_p64_kernel<NS><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, ntiles, fuse_stats);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }
@@ -1918,13 +1558,13 @@ static int launch_split_igemm(const ConvLaunch<float>& L, int M, hipStream_t s, 
   size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
   if (lds < kEpilogueLds) lds = kEpilogueLds;
   const bool one = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ups;
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_kernel<BM, BN, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_split_kernel<BM, BN, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_done = true;
+    attr_done.mark();
   }
   if (one) conv_igemm_split_kernel<BM, BN, true><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse);
   else conv_igemm_split_kernel<BM, BN, false><<<dim3(tiles_m * tiles_n), 256, lds, s>>>(L, M, tiles_m, tiles_n, fuse);
@@ -2027,10 +1667,12 @@ void pack_conv_weight_split(const float* w, int Cout, int Cin, int KH, int KW, s
     for (int n = 0; n < Cout; ++n) {
       float m = 0.0f;
       for (size_t i = 0; i < per; ++i) m = std::fmax(m, std::fabs(w[(size_t)n * per + i]));
-      if (m > 0.0f && std::isfinite(m)) {
+      // (m < 2^-100: a dead / denormal channel — 2^k would overflow to +inf and 0 * inf = NaN: left unscaled,
+      //  its halves flush to zero like the products they stand for)
+      if (m >= 0x1p-100f && std::isfinite(m)) {
         int e = 0;
         (void)std::frexp(m, &e);                 // m = f * 2^e, f in [0.5, 1)
-        const int k = 10 - e;                    // m * 2^k in [2^9, 2^10)
+        const int k = 10 - e;                    // m * 2^k in [2^9, 2^10); |k| <= 110
         mul[n] = std::ldexp(1.0f, k);
         (*oscale)[n] = std::ldexp(1.0f, -k);
       }
@@ -2055,3 +1697,4 @@ void pack_conv_weight_split(const float* w, int Cout, int Cin, int KH, int KW, s
 }
 
 }  // namespace prg
+

@@ -1135,13 +1135,8 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
   if (d.ups && ((H | W) & 1)) return 0;
   const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
   const long total = (long)tiles_x * tiles_y * tiles_n * d.B;
-  static int num_cus = 0;
-  if (!num_cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    num_cus = p.multiProcessorCount;
-  }
+  const int num_cus = device_cu_count();
+  if (num_cus <= 0) return 0;
   // fewer tiles than CUs: the 128-pixel tiles of conv_ws.hip fill the chip better
   static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
   const int grid = num_cus & ~7;
@@ -1164,11 +1159,11 @@ int try_launch_conv3x3_w256(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_
                            {reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 1, 0>),
                             reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 2, 0>), reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 3, 0>)}};
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
-  static std::atomic<bool> attr_done[2][4];   // zero-initialised; atomic: lanes launch from several host threads
-  if (!attr_done[tw == 32][pro]) {
+  static DeviceOnce attr_done[2][4];   // zero-initialised; atomic: lanes launch from several host threads
+  if (!attr_done[tw == 32][pro].done()) {
     hipError_t e = hipFuncSetAttribute(fns[tw == 32][pro], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 conv): ") + hipGetErrorString(e));
-    attr_done[tw == 32][pro] = true;
+    attr_done[tw == 32][pro].mark();
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
   if (acc_done) *acc_done = (fuse && L.gn_acc) ? 1 : 0;
@@ -1210,24 +1205,19 @@ int try_launch_conv3x3_up_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
   if ((size_t)d.B * d.Hin * d.Win * d.C0 * 2 >= ((size_t)1 << 31)) return 0;   // (32-bit halo offsets, as the other modes)
   const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
   const long total = (long)tiles_x * tiles_y * tiles_n * d.B * (d.Cout == 64 ? 2 : 4);   // (Cout = 64: two x-phases per tile)
-  static int num_cus = 0;
-  if (!num_cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    num_cus = p.multiProcessorCount;
-  }
+  const int num_cus = device_cu_count();
+  if (num_cus <= 0) return 0;
   const int grid = num_cus & ~7;
   static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
   if (grid < 8 || total < (min_fill > 0 ? min_fill : grid / 2)) return 0;
   const void* fn = tw == 32 ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 2>)
                             : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 2>);
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
-  static std::atomic<bool> attr_done[2];
-  if (!attr_done[tw == 32]) {
+  static DeviceOnce attr_done[2];
+  if (!attr_done[tw == 32].done()) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 upsample): ") + hipGetErrorString(e));
-    attr_done[tw == 32] = true;
+    attr_done[tw == 32].mark();
   }
   if (L.probe) return 1;
   if (tw == 32) conv3x3_w256_kernel<32, 0, 2><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
@@ -1258,13 +1248,8 @@ int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* g
   if (d.ups && ((H | W) & 1)) return 0;
   const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
   const long total = (long)tiles_x * tiles_y * tiles_n * d.B;
-  static int num_cus = 0;
-  if (!num_cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    num_cus = p.multiProcessorCount;
-  }
+  const int num_cus = device_cu_count();
+  if (num_cus <= 0) return 0;
   static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
   const int grid = num_cus & ~7;
   // Round 5: a launch with fewer tiles than CUs stays on the bf16 kernels (the network's level-3 convs: 128 tiles on 256 CUs — measured
@@ -1283,11 +1268,11 @@ int try_launch_conv3x3_w256mx(const ConvLaunch<bf16_t>& L, hipStream_t s, int* g
                            {reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 0>), reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 1>),
                             reinterpret_cast<const void*>(&conv3x3_w256mx_kernel<32, 2>)}};
   const size_t lds = tw == 32 ? W2MxGeom<32>::LDS : W2MxGeom<16>::LDS;
-  static std::atomic<bool> attr_done[2][3];   // zero-initialised; atomic: lanes launch from several host threads
-  if (!attr_done[tw == 32][pro]) {
+  static DeviceOnce attr_done[2][3];   // zero-initialised; atomic: lanes launch from several host threads
+  if (!attr_done[tw == 32][pro].done()) {
     hipError_t e = hipFuncSetAttribute(fns[tw == 32][pro], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 mx conv): ") + hipGetErrorString(e));
-    attr_done[tw == 32][pro] = true;
+    attr_done[tw == 32][pro].mark();
   }
   if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 : 0;
   if (acc_done) *acc_done = (fuse && L.gn_acc) ? 1 : 0;
@@ -1325,24 +1310,19 @@ int try_launch_conv4x4s2_w256(const ConvLaunch<bf16_t>& L, hipStream_t s) {
   else return 0;
   const int th = 256 / tw, tiles_x = W / tw, tiles_y = H / th;
   const long total = (long)tiles_x * tiles_y * tiles_n * d.B;
-  static int num_cus = 0;
-  if (!num_cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    num_cus = p.multiProcessorCount;
-  }
+  const int num_cus = device_cu_count();
+  if (num_cus <= 0) return 0;
   const int grid = num_cus & ~7;
   static const int min_fill = [] { const char* e = std::getenv("PRG_W256_MIN_TILES"); return e ? std::atoi(e) : 0; }();
   if (grid < 8 || total < (min_fill > 0 ? min_fill : grid / 2)) return 0;   // the generic kernel for tiny launches
   const void* fn = tw == 32 ? reinterpret_cast<const void*>(&conv3x3_w256_kernel<32, 0, 1>)
                             : reinterpret_cast<const void*>(&conv3x3_w256_kernel<16, 0, 1>);
   const size_t lds = tw == 32 ? W2Geom<32>::LDS : W2Geom<16>::LDS;
-  static std::atomic<bool> attr_done[2];
-  if (!attr_done[tw == 32]) {
+  static DeviceOnce attr_done[2];
+  if (!attr_done[tw == 32].done()) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(w256 downsample): ") + hipGetErrorString(e));
-    attr_done[tw == 32] = true;
+    attr_done[tw == 32].mark();
   }
   if (tw == 32) conv3x3_w256_kernel<32, 0, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);
   else conv3x3_w256_kernel<16, 0, 1><<<dim3(grid), 512, lds, s>>>(L, tiles_x, tiles_y, tiles_n, 0);

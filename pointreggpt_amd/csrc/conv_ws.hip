@@ -886,12 +886,12 @@ int launch_ws_cfg2(const ConvLaunch<bf16_t>& L, hipStream_t s, int fuse_stats, i
   if (grid > total) grid = total;
   if (grid >= 8) grid &= ~7;                     // multiple of 8: XCD-contiguous runs inside a round
   if (tiles_n > 1 && (grid & 7) != 0) return kWsUnsupported;   // a workgroup must own one channel tile (bias in LDS)
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<TH, TW, BN, PRO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(ws conv): ") + hipGetErrorString(e));
-    attr_done = true;
+    attr_done.mark();
   }
   if (nsplit) *nsplit = fuse_stats ? tiles_x * tiles_y * G::WAVES_M : 0;
   if (L.probe) return PRG_OK;
@@ -947,13 +947,8 @@ int try_launch_conv3x3_ws(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_ns
     const int tn128 = d.Cout % 128 == 0 ? d.Cout / 128 : d.Cout / 64;   // Cout tiles of the configuration chosen below
     if (tn128 != 1 && tn128 != 2 && tn128 != 4 && tn128 != 8) return 0;  // every workgroup must own ONE channel tile
   }
-  static int num_cus = 0;
-  if (!num_cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    num_cus = p.multiProcessorCount;
-  }
+  const int num_cus = device_cu_count();
+  if (num_cus <= 0) return 0;
   const int H = d.Hout, W = d.Wout;
   const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
   const bool want = L.gn_partials != nullptr;

@@ -25,6 +25,20 @@ namespace prg {
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
+int device_cu_count() {
+  static std::atomic<int> cus[64];          // zero-initialised; per device ordinal
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::atomic<int>& c = cus[dev & 63];
+  int n = c.load(std::memory_order_acquire);
+  if (n <= 0) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    n = p.multiProcessorCount;
+    c.store(n, std::memory_order_release);
+  }
+  return n;
+}
 int fail(int code, const std::string& m) {
   g_err = m;
   return code;

@@ -226,14 +226,16 @@ def native_write_ply(path: str, pts) -> None:
 
 
 def rank_cpu_budget() -> int:
-    """CPUs this rank may count on: the affinity mask when the process is pinned (sharding.pin_rank_cpus), otherwise the host's
-    CPUs divided by the ranks of the job (WORLD_SIZE; LOCAL_WORLD_SIZE when the launcher exports it)."""
+    """CPUs this rank may count on: the affinity mask when sharding.pin_rank_cpus narrowed it to this rank's private share (it
+    leaves the marker PRG_PINNED_CPUS), otherwise the CPUs the process may use — the whole host, or a container cpuset / job-wide
+    taskset that EVERY rank shares — divided by the ranks of the job (LOCAL_WORLD_SIZE, else WORLD_SIZE)."""
     total = os.cpu_count() or 4
     mine = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total
-    if mine < total:
+    pinned = os.environ.get("PRG_PINNED_CPUS", "")
+    if pinned.isdigit() and int(pinned) == mine:
         return max(1, mine)
     ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return max(1, total // max(1, ranks))
+    return max(1, mine // max(1, ranks))
 
 
 class WriterPool:

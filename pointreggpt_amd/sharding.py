@@ -142,7 +142,7 @@ def rank_cpu_set(local_rank: int, local_world: int, allowed: List[int], gpu_cpus
 
 
 def pin_rank_cpus(local_rank: int, local_world: int, device_index: int | None = None) -> dict:
-    """Pin THIS process (and every thread it starts afterwards: the lane threads, the C++ writer pool) to its share of the host:
+    """Pin THIS process (its existing threads and every thread it starts afterwards: the lane threads, the C++ writer pool) to its share of the host:
     the cores of the NUMA node its GPU is attached to, divided among the ranks on that node.  One rank issues ~1000 graph
     launches per batch from each lane thread and runs cpu_count / world / 2 writer threads; unpinned, eight ranks' threads
     migrate across both sockets of a 2-socket host.  `PRG_NO_AFFINITY=1` opts out; a single rank is left alone.
@@ -169,7 +169,29 @@ def pin_rank_cpus(local_rank: int, local_world: int, device_index: int | None = 
             peers = idx = None
     cpus = rank_cpu_set(local_rank, local_world, allowed, gpu_cpus, peers, idx)
     if cpus:
+        # Reading the GPU's PCI address initialised the HIP runtime, whose helper threads already exist, and sched_setaffinity(0)
+        # only moves the CALLING thread: every thread of the process is moved, then torch's intra-op pool is
+        # sized for the share (it was sized for the whole host at import).
+        threads = 0
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            tids = []
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, cpus)
+                threads += 1
+            except OSError:        # a thread that exited meanwhile
+                pass
         os.sched_setaffinity(0, cpus)
-        info.update(pinned=True, cpus=len(cpus), first_cpu=cpus[0], last_cpu=cpus[-1], numa_node=node,
+        try:
+            import torch
+            torch.set_num_threads(max(1, len(cpus)))
+        except Exception:      # noqa: BLE001
+            pass
+        # rank_cpu_budget() tells a mask THIS function narrowed (the rank's private share) from one a container / taskset narrowed
+        # (shared by every rank of the job) by this marker; exported so that worker processes started later see it too
+        os.environ["PRG_PINNED_CPUS"] = str(len(cpus))
+        info.update(pinned=True, cpus=len(cpus), first_cpu=cpus[0], last_cpu=cpus[-1], numa_node=node, threads_moved=threads,
                     source="sysfs local_cpulist" if peers else "even split of the allowed CPUs")
     return info

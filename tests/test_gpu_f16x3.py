@@ -397,3 +397,24 @@ def test_split_conv_small_unstandardised_weights(hip):
         print(f"\nsmall-weight split conv {Cin}->{Cout} {K}x{K}/{stride}: per-channel relative rms error max {float(e.max()):.3e} "
               f"(torch-CPU fp32 {float(c.max()):.3e}), max|w| {float(w.abs().max()):.3e}")
         assert float(e.max()) <= 4.0 * float(c.max()) + 2e-7, (float(e.max()), float(c.max()))
+
+
+def test_split_conv_dead_channel_stays_finite(hip):
+    """an output channel whose weights are all below ~2^-117 (dead / denormal) made the packer's power-of-two scale
+    2^(10 - e) overflow to +inf: every weight of the channel became inf, zero weights NaN (0 * inf), and GroupNorm spread the NaN.
+    Such a channel is now left unscaled: its output is finite (zero to within float32 rounding of ~1e-38 products) and the other
+    channels are what they are without it."""
+    for (B, Cin, Cout, H, Wd, K, stride) in [(1, 64, 64, 16, 16, 3, 1), (1, 128, 64, 16, 16, 1, 1)]:
+        g = torch.Generator().manual_seed(99 + K)
+        x = torch.randn((B, Cin, H, Wd), generator=g)
+        w = torch.randn((Cout, Cin, K, K), generator=g) * (1.0 / (Cin * K * K)) ** 0.5
+        w[5] = 0.0
+        w[5, ::2] = 1e-38                                  # max|w| = 1e-38 < 2^-117, zeros in between
+        w[9] = 0.0                                         # an all-zero channel (was already skipped: m > 0)
+        bias = torch.zeros((Cout,))
+        got = _conv(hip, x, w, bias, hip.lib.PRG_F16X3, K, stride)
+        assert bool(torch.isfinite(got).all())
+        assert float(got[:, 5].abs().max()) <= 1e-30 and float(got[:, 9].abs().max()) == 0.0
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=stride, padding=0 if K == 1 else 1)
+        keep = [c for c in range(Cout) if c not in (5, 9)]
+        assert float((got.double() - ref)[:, keep].abs().max()) <= 2e-5

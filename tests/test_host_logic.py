@@ -397,3 +397,22 @@ def test_bench_contract_line_is_short_for_a_full_result():
     # a pathological leg cannot break the contract: the optional objects are dropped before the limit is crossed
     full["config"]["workload"] = "w" * 3000
     assert len(bench.contract_line(full, bench.SIDECAR)) < 4096
+
+
+def test_rank_cpu_budget_divides_a_shared_mask_but_not_a_pinned_one():
+    """a mask narrower than the host that pin_rank_cpus did NOT set (container cpuset, job-wide taskset,
+    PRG_NO_AFFINITY) is shared by every rank and must be divided by the rank count; a mask pin_rank_cpus set is the rank's own."""
+    import json
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("needs >= 4 CPUs")
+    code = ("import os, sys, json; sys.path.insert(0, %r); from pointreggpt_amd import postprocess as PP, sharding as S; "
+            "os.sched_setaffinity(0, %r); a = PP.rank_cpu_budget(); i = S.pin_rank_cpus(1, 2); b = PP.rank_cpu_budget(); "
+            "print(json.dumps([a, b, i, len(os.sched_getaffinity(0))]))" % (ROOT, allowed[:4]))
+    env = {k: v for k, v in os.environ.items() if k not in ("PRG_NO_AFFINITY", "PRG_PINNED_CPUS")}
+    env.update(WORLD_SIZE="2", LOCAL_WORLD_SIZE="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    shared, own, info, n_after = json.loads(r.stdout.strip().splitlines()[-1])
+    assert shared == 2                       # 4 shared CPUs / 2 ranks (the old code returned 4 per rank)
+    assert info["pinned"] and n_after == 2 and own == 2 and info["threads_moved"] >= 1

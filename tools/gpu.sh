@@ -25,9 +25,10 @@ for ST in "$@"; do
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $O/${T}_smoke.log;;
     bench|benchq)
       A="--gpus 1 --steps 20 --warmup 5"; [ $ST = benchq ] && A="--gpus 1 --steps 4 --warmup 2"
-      /usr/bin/time -v python bench.py $A > $O/${T}_bench_line.json 2> $O/${T}_bench.err
+      T0=$(date +%s)
+      python bench.py $A > $O/${T}_bench_line.json 2> $O/${T}_bench.err; echo "bench rc=$? wall $(( $(date +%s) - T0 )) s"
       cp bench_full.json $O/${T}_bench_full.json 2>/dev/null
-      wc -c $O/${T}_bench_line.json; cat $O/${T}_bench_line.json; grep -E "Elapsed|Maximum resident" $O/${T}_bench.err;;
+      wc -c $O/${T}_bench_line.json; cat $O/${T}_bench_line.json; tail -c 600 $O/${T}_bench.err | grep -v '^{' ;;
     prof:*)
       DT=${ST#prof:}
       if [ $DT = bf16 ] || [ $DT = mxfp8 ]; then
