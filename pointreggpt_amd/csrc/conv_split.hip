@@ -129,6 +129,17 @@ __device__ inline void flush_acc(f32x16 (&acc)[TM][2], f32x16 (&tot)[TM][2]) {
 // run in lockstep and overlap nothing; the first pipelined version 345 us at 8 VALU + 6 SALU instructions per MFMA
 // (rocprofv3 SQ_INSTS_*: address arithmetic and tap bookkeeping); this structure: DESIGN.md section 4.6.
 
+// scheduling pipeline of one k16 step of a consumer wave: (MFMA, ds_read) x 8, then 4 MFMAs  (sched_group_barrier masks: 0x008 = MFMA,
+// 0x100 = DS read); placed behind the twelve MFMAs and the eight fragment reads of the OTHER register set it orders
+__device__ inline void interleave_8_reads_12_mfmas() {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+}
+
 template <int N>
 struct IC {
   static constexpr int value = N;
@@ -789,14 +800,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
     // is free for the producers, this chunk's halo is complete.  No wait: a consumer's outstanding fragment loads read only
     // images that stay valid for another tap.
     if (T > 0 || c > 0) asm volatile("s_barrier" ::: "memory");
-    reads(IC<1>(), TAP, c & 1, it & (NS - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(IC<0>());
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), c & 1, (it + 1) & (NS - 1));
-    else if (more) reads(IC<0>(), IC<0>(), (c + 1) & 1, (it + 1) & (NS - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(IC<1>());
+    if constexpr (ablate::kInterleave) {
+      // one fragment read in each of the first eight MFMA shadows instead of eight reads in a row behind the twelfth MFMA: the four
+      // consumers are barrier-aligned, so a burst is 32 ds_read_b128 at once on the CU's LDS port (4 cycles each) against one
+      // 32-cycle MFMA of cover
+      __builtin_amdgcn_sched_barrier(0);
+      reads(IC<1>(), TAP, c & 1, it & (NS - 1));
+      mfmas(IC<0>());
+      interleave_8_reads_12_mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), c & 1, (it + 1) & (NS - 1));
+      else if (more) reads(IC<0>(), IC<0>(), (c + 1) & 1, (it + 1) & (NS - 1));
+      mfmas(IC<1>());
+      interleave_8_reads_12_mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      reads(IC<1>(), TAP, c & 1, it & (NS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<0>());
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), c & 1, (it + 1) & (NS - 1));
+      else if (more) reads(IC<0>(), IC<0>(), (c + 1) & 1, (it + 1) & (NS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<1>());
+    }
     if constexpr (T == NT - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -1172,14 +1199,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
     // it - 1's slot is free for the producers, this chunk's halo is complete.  No wait: a consumer's outstanding fragment loads
     // read only images that stay valid for another tap.
     if (it > 0) asm volatile("s_barrier" ::: "memory");
-    reads(IC<1>(), TAP, g & 1, it & (NS - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(IC<0>());
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), g & 1, (it + 1) & (NS - 1));
-    else if (more) reads(IC<0>(), IC<0>(), (g + 1) & 1, (it + 1) & (NS - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(IC<1>());
+    if constexpr (ablate::kInterleave) {
+      __builtin_amdgcn_sched_barrier(0);
+      reads(IC<1>(), TAP, g & 1, it & (NS - 1));
+      mfmas(IC<0>());
+      interleave_8_reads_12_mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), g & 1, (it + 1) & (NS - 1));
+      else if (more) reads(IC<0>(), IC<0>(), (g + 1) & 1, (it + 1) & (NS - 1));
+      mfmas(IC<1>());
+      interleave_8_reads_12_mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      reads(IC<1>(), TAP, g & 1, it & (NS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<0>());
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (T < NT - 1) reads(IC<0>(), IC<(T + 1) % NT>(), g & 1, (it + 1) & (NS - 1));
+      else if (more) reads(IC<0>(), IC<0>(), (g + 1) & 1, (it + 1) & (NS - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(IC<1>());
+    }
     if constexpr (T == NT - 1) {                         // the 288-term partial of this channel chunk
       // (a tile's FIRST partial is assigned, not added to a zeroed total: 0 + x = x, and the epilogue no longer zeroes 64 registers)
       if (first) {

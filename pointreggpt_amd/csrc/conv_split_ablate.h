@@ -22,5 +22,10 @@ constexpr bool ws_no_mfma = kWhich == 21;
 constexpr bool ws_no_halo = kWhich == 23;
 constexpr bool ws_no_reads = kWhich == 24;
 constexpr bool ws_no_wdma = kWhich == 25;
+// EXPERIMENT switches (a variant build sets them; the default is what ships)
+#ifndef PRG_SPLIT_ILV
+#define PRG_SPLIT_ILV 0
+#endif
+constexpr bool kInterleave = PRG_SPLIT_ILV != 0;   // consumer fragment reads interleaved with the MFMAs (round 6)
 }  // namespace ablate
 }  // namespace prg

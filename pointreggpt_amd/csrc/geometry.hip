@@ -163,6 +163,14 @@ __global__ void unproject_f64_kernel(const float* __restrict__ depth, const floa
 }
 
 // ---- DepthAugment (dc:577-604) -------------------------------------------------------------------
+// min over the valid (non-zero) neighbours of the 3x3 window, or over all in-frame neighbours when none is valid (the pool pads
+// with -inf of -x: out-of-frame positions never win).  fminf is exact and order-independent on the finite inputs of this path, so
+// the window may be walked in any order: a thread owns FOUR consecutive pixels of a row (round 6: three float4 row loads + six
+// edge scalars instead of 36 scalar loads, three float4 stores; 16 Mpx: 2.3 -> see profiles/r06_*), W % 4 == 0, else one pixel.
+__device__ inline void aug_min(float v, float& mv, float& mr) {
+  mr = fminf(mr, v);
+  if (v != 0.0f) mv = fminf(mv, v);
+}
 __global__ void depth_augment_kernel(const float* __restrict__ depth, float* __restrict__ out, int H, int W) {
   int b = blockIdx.y;
   int HW = H * W;
@@ -178,9 +186,7 @@ __global__ void depth_augment_kernel(const float* __restrict__ depth, float* __r
       for (int dx = -1; dx <= 1; ++dx) {
         int cc = col + dx;
         if (cc < 0 || cc >= W) continue;
-        float v = d[rr * W + cc];
-        mr = fminf(mr, v);
-        if (v != 0.0f) mv = fminf(mv, v);
+        aug_min(d[rr * W + cc], mv, mr);
       }
     }
     float m = (mv == inf) ? mr : mv;
@@ -188,6 +194,43 @@ __global__ void depth_augment_kernel(const float* __restrict__ depth, float* __r
     o[i] = c0;
     o[HW + i] = m;
     o[2 * HW + i] = m - c0;
+  }
+}
+__global__ __launch_bounds__(256) void depth_augment4_kernel(const float* __restrict__ depth, float* __restrict__ out, int H, int W) {
+  const int b = blockIdx.y;
+  const int HW = H * W, W4 = W >> 2, Q = HW >> 2;
+  const float* d = depth + (size_t)b * HW;
+  float* o = out + (size_t)b * 3 * HW;
+  const float inf = __uint_as_float(0x7f800000u);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+    const int r = q / W4, c4 = (q - r * W4) << 2;
+    float mv[4] = {inf, inf, inf, inf}, mr[4] = {inf, inf, inf, inf};
+    float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int rr = r + dy;
+      if (rr < 0 || rr >= H) continue;
+      const float* row = d + (size_t)rr * W + c4;
+      const float4 v = *reinterpret_cast<const float4*>(row);
+      if (dy == 0) ctr = v;
+      const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        aug_min(x[k], mv[k], mr[k]);
+        if (k > 0) aug_min(x[k - 1], mv[k], mr[k]);
+        if (k < 3) aug_min(x[k + 1], mv[k], mr[k]);
+      }
+      if (c4 > 0) aug_min(row[-1], mv[0], mr[0]);
+      if (c4 + 4 < W) aug_min(row[4], mv[3], mr[3]);
+    }
+    const float c[4] = {ctr.x, ctr.y, ctr.z, ctr.w};
+    float m[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = (mv[k] == inf) ? mr[k] : mv[k];
+    const size_t i = (size_t)q << 2;
+    *reinterpret_cast<float4*>(o + i) = ctr;
+    *reinterpret_cast<float4*>(o + HW + i) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(o + 2 * (size_t)HW + i) = make_float4(m[0] - c[0], m[1] - c[1], m[2] - c[2], m[3] - c[3]);
   }
 }
 
@@ -362,7 +405,10 @@ int prg_unproject_f64(const float* depth, const float* K, const float* pose, dou
 int prg_depth_augment(const float* depth, float* out, int B, int H, int W, void* stream) {
   PRG_CHECK(depth && out, "prg_depth_augment: null pointer");
   PRG_CHECK(B > 0 && H > 0 && W > 0, "prg_depth_augment: bad shape");
-  depth_augment_kernel<<<grid_for(H * W, B), 256, 0, (hipStream_t)stream>>>(depth, out, H, W);
+  if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    depth_augment4_kernel<<<grid_for(H * W / 4, B), 256, 0, (hipStream_t)stream>>>(depth, out, H, W);
+  else
+    depth_augment_kernel<<<grid_for(H * W, B), 256, 0, (hipStream_t)stream>>>(depth, out, H, W);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }

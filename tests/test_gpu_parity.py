@@ -124,6 +124,22 @@ def test_augment_and_mask_bit_exact(hip, golden):
     assert np.array_equal(cond.cpu().numpy(), g["img_cond"])
 
 
+def test_depth_augment_vector_and_scalar_forms_against_oracle(hip):
+    """Round 6: DepthAugment (dc:577-604) runs four pixels per thread when W % 4 == 0 and one pixel per thread otherwise; both
+    forms against the oracle's max-pool restatement, bit for bit, on images with holes, all-zero windows, borders and a
+    constant-zero image (the `no valid neighbour` branch)."""
+    from oracle import unet as OU
+    g = torch.Generator().manual_seed(4)
+    for (B, H, W) in [(3, 32, 32), (2, 30, 30), (1, 8, 4), (2, 5, 7), (1, 128, 128)]:
+        d = torch.rand((B, 1, H, W), generator=g) * 3
+        d[torch.rand((B, 1, H, W), generator=g) < 0.4] = 0.0
+        d[0, 0, : H // 2, : W // 2] = 0.0                 # a hole larger than the window
+        if B > 1:
+            d[1] = 0.0
+        got = hip.G.depth_augment(d.cuda()).cpu()
+        assert torch.equal(got, OU.depth_augment(d)), (B, H, W)
+
+
 def test_geometry_properties_full_size(hip):
     """BASELINE size (B=64, 128x128): identity pose round-trips the clipped depth bit-exactly; the z-buffer keeps
     the minimum; project(unproject(d)) with any pose never invents depth outside the source range."""

@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--ranks", type=int, default=8)
-    p.add_argument("--batches", type=int, default=5, help="batches per rank in the replay")
+    p.add_argument("--batches", type=int, default=20, help="batches per rank in the replay")
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--size", type=int, default=128)
     p.add_argument("--lanes", type=int, default=2)
