@@ -833,6 +833,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_ws_kernel(const ConvLaun
           for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
     }
   };
+  if constexpr (ablate::kConsumerPrio > 0) __builtin_amdgcn_s_setprio(ablate::kConsumerPrio);
   asm volatile("s_barrier" ::: "memory");                // the producers' prologue: chunk 0's halo, weight tiles 0 and 1
   reads(IC<0>(), IC<0>(), 0, 0);
   for (int c = 0; c < nchunks; ++c) {
@@ -1239,6 +1240,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_p64_kernel(const ConvLau
       }
     }
   };
+  if constexpr (ablate::kConsumerPrio > 0) __builtin_amdgcn_s_setprio(ablate::kConsumerPrio);
   asm volatile("s_barrier" ::: "memory");                // barrier(0): the producers' prologue — tile 0's first halo, weight tiles 0 and 1
   reads(IC<0>(), IC<0>(), 0, 0);
   const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 64;          // 8, 16, 32 or 64 when the statistics are fused

@@ -22,10 +22,16 @@ constexpr bool ws_no_mfma = kWhich == 21;
 constexpr bool ws_no_halo = kWhich == 23;
 constexpr bool ws_no_reads = kWhich == 24;
 constexpr bool ws_no_wdma = kWhich == 25;
-// EXPERIMENT switches (a variant build sets them; the default is what ships)
+// A/B switches (a variant build flips them; the default is what ships)
 #ifndef PRG_SPLIT_ILV
-#define PRG_SPLIT_ILV 0
+#define PRG_SPLIT_ILV 1
 #endif
-constexpr bool kInterleave = PRG_SPLIT_ILV != 0;   // consumer fragment reads interleaved with the MFMAs (round 6)
+#ifndef PRG_SPLIT_PRIO
+#define PRG_SPLIT_PRIO 0
+#endif
+// consumer fragment reads interleaved one per MFMA shadow (round 6: -3 ... -5.6 % per launch, same bits; 0 = eight reads in a row
+// behind the twelfth MFMA, the round-5 order; profiles/r06_ab_split_interleaved_reads.txt)
+constexpr bool kInterleave = PRG_SPLIT_ILV != 0;
+constexpr int kConsumerPrio = PRG_SPLIT_PRIO;      // s_setprio of the consumer waves before their main loop (experiment)
 }  // namespace ablate
 }  // namespace prg
