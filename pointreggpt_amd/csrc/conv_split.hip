@@ -23,52 +23,9 @@
 #include <cstring>
 #include <type_traits>
 
-#include "conv_epi.h"
-
-#include "conv_split_ablate.h"
+#include "conv_split_common.h"
 
 namespace prg {
-
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-
-// 8 consecutive channels -> their hi and lo halves as two 16-byte MFMA operand units
-template <bool MIX = true>
-__device__ inline void split8(const float (&v)[8], uint4& hi, uint4& lo) {
-  f16x8 h, l;
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    const f32x2 p = {v[i], v[i + 1]};
-    const f16x2 ph = __builtin_convertvector(p, f16x2);          // v_cvt_pk_f16_f32, round to nearest even
-    // v - hi, exact in float32.  MIX (round 5): ONE mixed-precision fma per element — v_fma_mix_f32 reads the f16 half directly —
-    // instead of a conversion back to float32 and a (packed, two-slot) subtraction: 16 instead of 24 issue slots per eight elements,
-    // the same bits.  hipcc folds fma(float(h), -1, v) back into convert + subtract, hence two lines of inline asm (op_sel picks the
-    // half).  Same-box A/B (profiles/r05_ab_split8_fma_mix.txt): the persistent 64-channel kernel 248-255 -> 229 us per level-0
-    // launch (K = 1152: 460-470 -> 424); the launches with a fused GroupNorm + SiLU prologue got 3-4 % SLOWER with it (the asm
-    // statements pin the schedule around the two transcendentals), so those keep the plain form (split8<false>).
-    f32x2 r;
-    if constexpr (MIX) {
-      const uint32_t phw = __builtin_bit_cast(uint32_t, ph);
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(phw), "v"(p[0]));
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(phw), "v"(p[1]));
-    } else {
-      r = p - __builtin_convertvector(ph, f32x2);
-    }
-    const f16x2 pl = __builtin_convertvector(r, f16x2);
-    h[i] = ph[0]; h[i + 1] = ph[1];
-    l[i] = pl[0]; l[i + 1] = pl[1];
-  }
-  hi = __builtin_bit_cast(uint4, h);
-  lo = __builtin_bit_cast(uint4, l);
-}
-
-// SiLU of the fused prologue: hardware exp2 / reciprocal (1 ulp each) — ~2e-7 relative, the size of the contraction's own error
-__device__ inline float silu_fast(float x) {
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
-}
-
-__device__ inline f16x8 ld_frag(const uint4* p) { return __builtin_bit_cast(f16x8, *p); }
 
 // acc += a * w with split operands: the two cross terms first (small), then the leading term
 __device__ inline void mma3(const f16x8& ah, const f16x8& al, const f16x8& wh, const f16x8& wl, f32x16& c) {
@@ -128,22 +85,6 @@ __device__ inline void flush_acc(f32x16 (&acc)[TM][2], f32x16 (&tot)[TM][2]) {
 // MFMAs compiled out: MFMA 105 + LDS reads 53 + L1/TA 47 + split 21 + epilogue 48 us simply added up, identical workgroups
 // run in lockstep and overlap nothing; the first pipelined version 345 us at 8 VALU + 6 SALU instructions per MFMA
 // (rocprofv3 SQ_INSTS_*: address arithmetic and tap bookkeeping); this structure: DESIGN.md section 4.6.
-
-// scheduling pipeline of one k16 step of a consumer wave: (MFMA, ds_read) x 8, then 4 MFMAs  (sched_group_barrier masks: 0x008 = MFMA,
-// 0x100 = DS read); placed behind the twelve MFMAs and the eight fragment reads of the OTHER register set it orders
-__device__ inline void interleave_8_reads_12_mfmas() {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-  }
-  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-}
-
-template <int N>
-struct IC {
-  static constexpr int value = N;
-};
 
 template <int TH, int TW, int NS>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(
@@ -1614,6 +1555,8 @@ static int launch_split_igemm(const ConvLaunch<float>& L, int M, hipStream_t s, 
   return PRG_OK;
 }
 
+int try_launch_conv3x3_split_w512(const ConvLaunch<float>& L, hipStream_t s, int want_stats, int* gn_nsplit_out);   // conv_split512.hip
+
 // 1 = launched, 0 = shape not covered (the exact-f32 kernels of conv.hip run it), < 0 = error
 int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsplit_out) {
   if (!L.w_split) return 0;
@@ -1656,6 +1599,11 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
         d.Wout == 2 * d.Win && !L.residual && !L.pro_a && !want_stats) {
       rc = launch_split_ws_up(L, s);
       return rc ? rc : 1;
+    }
+    {
+      // EXPERIMENT (PRG_SPLIT_W512=1, conv_split512.hip): one wave per SIMD, 128 x 64 wave tiles; bit-identical to the kernel below
+      const int r = try_launch_conv3x3_split_w512(L, s, want_stats, gn_nsplit_out);
+      if (r != 0) return r;
     }
     if (ws_on && d.Cout % 128 == 0 && W % 16 == 0 && H % 8 == 0 && !L.residual) {
       const int tiles = (W / 16) * (H / 8) * 2;

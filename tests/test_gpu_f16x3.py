@@ -17,6 +17,8 @@ import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from pointreggpt_amd import weights as W
 from test_gpu_parity import (D, NORTH_STAR, _run_long_chain, _tap_report, golden_unet, hip, maxerr)  # noqa: F401 (hip: fixture)
 
@@ -418,3 +420,46 @@ def test_split_conv_dead_channel_stays_finite(hip):
         ref = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=stride, padding=0 if K == 1 else 1)
         keep = [c for c in range(Cout) if c not in (5, 9)]
         assert float((got.double() - ref)[:, keep].abs().max()) <= 2e-5
+
+
+def test_f16x3_one_wave_per_simd_kernel(tmp_path):
+    """Round 6 experiment (PRG_SPLIT_W512=1, conv_split512.hip): the one-wave-per-SIMD 512-register form of the f16x3 3x3 convolution
+    (128 x 64 wave tiles, no producer waves) performs conv3x3_split_ws_kernel's arithmetic term for term — single convolutions
+    (plain, two-source-free, K = 128 ... 4608) and the whole dim-64 U-Net (fused prologues, fused GroupNorm statistics, all slab
+    partitions) give the SAME BITS with it switched on and off."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from pointreggpt_amd import _lib, weights as W
+from pointreggpt_amd.unet import Unet
+lib = _lib.load()
+out = {}
+g = torch.Generator().manual_seed(5)
+for (B, Cin, Cout, H, Wd) in [(2, 128, 128, 32, 32), (1, 512, 256, 16, 16), (3, 64, 128, 16, 48)]:
+    x = torch.randn((B, Cin, H, Wd), generator=g).cuda()
+    w = np.ascontiguousarray((torch.randn((Cout, Cin, 3, 3), generator=g) * (1.0 / (9 * Cin)) ** 0.5).numpy())
+    bias = np.ascontiguousarray(torch.randn((Cout,), generator=g).numpy())
+    o = torch.empty((B, Cout, H, Wd), dtype=torch.float32, device="cuda")
+    _lib.check(lib.prg_debug_conv(_lib.ptr(x), w.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), _lib.ptr(o), B, Cin, Cout, H, Wd,
+                                  _lib.PRG_F16X3, 3, 1, _lib.stream_ptr()))
+    out["conv_%%d_%%d_%%d" %% (Cin, Cout, H)] = o.cpu().numpy()
+net = Unet(64, dtype="f16x3").load_state_dict(W.synth_state_dict(W.unet_config(64), 13))
+x = torch.randn((4, 1, 128, 128), generator=g).cuda()
+t = torch.tensor([3, 500, 998, 42], dtype=torch.int64).cuda()
+pc = torch.tensor([[151.5, 152.1, 64.5, 64.0]] * 4).cuda()
+out["unet"] = net(x, t, pc).cpu().numpy()
+net.close()
+np.savez(sys.argv[1], **out)
+''' % ROOT
+    res = {}
+    for on in ("0", "1"):
+        path = tmp_path / f"w512_{on}.npz"
+        env = dict(os.environ, PRG_SPLIT_W512=on)
+        r = subprocess.run([sys.executable, "-c", code, str(path)], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[on] = np.load(path)
+    for k in res["0"].files:
+        assert np.isfinite(res["1"][k]).all(), k
+        assert np.array_equal(res["0"][k], res["1"][k]), (k, float(np.abs(res["0"][k] - res["1"][k]).max()))
