@@ -22,7 +22,7 @@
 
 namespace prg {
 
-template <int NS>
+template <int NS, bool PRO>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_split_w512_kernel(
     const ConvLaunch<float> L, const int tiles_x, const int tiles_y, const int tiles_n, const int fuse_stats) {
   constexpr int TH = 16, TW = 16, BN = 128, CH = 32, NT = 9;
@@ -78,25 +78,26 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       w_lane[k] = hy * RSTRIDE + hx * PITCH + q * 16;
     }
   }
+  // passes [K0, K0 + 3) of a chunk are loaded together (taps 0 and 3) and share ONE set of three staging register pairs
   float4 hh0[3], hh1[3];
-  // passes [K0, K0 + 3) of a chunk: 6 loads per thread whatever the passes hold (the counted waits need a fixed number); the two
-  // halves of a chunk's halo are loaded at taps 0 and 3 and share ONE set of three staging register pairs
-  auto halo_load = [&](int chunk, auto K0) {
-    constexpr int k0 = decltype(K0)::value;
+  const float* hbase = nullptr;                          // source tensor / row pitch / channel offset of the chunk being staged
+  int hCs = 0, hcc = 0;
+  auto halo_chunk = [&](int chunk) {
     const int c = chunk * CH + q * 8;
     const bool first = c < d.C0;
-    const float* base = first ? L.src0 : L.src1;
-    const int Cs = first ? d.C0 : d.C1, cc = first ? c : c - d.C0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float4* p = reinterpret_cast<const float4*>(base + (hsrc[k0 + k] >= 0 ? (size_t)hsrc[k0 + k] * Cs + cc : (size_t)0));
-      hh0[k] = p[0];
-      hh1[k] = p[1];
-    }
+    hbase = first ? L.src0 : L.src1;
+    hCs = first ? d.C0 : d.C1;
+    hcc = first ? c : c - d.C0;
+  };
+  auto halo_load1 = [&](auto K) {                        // always issued (padding lanes read the tensor's first bytes and are zeroed
+    constexpr int k = decltype(K)::value, r = k % 3;     // when written): the counted waits need a fixed number of loads
+    const float4* p = reinterpret_cast<const float4*>(hbase + (hsrc[k] >= 0 ? (size_t)hsrc[k] * hCs + hcc : (size_t)0));
+    hh0[r] = p[0];
+    hh1[r] = p[1];
   };
   float pa[8], pb[8];
   auto pro_load = [&](int chunk) {
-    if (L.pro_a) {
+    if constexpr (PRO) {
       const float4* a4 = reinterpret_cast<const float4*>(L.pro_a + (size_t)b * d.C0 + chunk * CH + q * 8);
       const float4* b4 = reinterpret_cast<const float4*>(L.pro_b + (size_t)b * d.C0 + chunk * CH + q * 8);
       const float4 a0 = a4[0], a1 = a4[1], b0 = b4[0], b1 = b4[1];
@@ -104,26 +105,30 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
     }
   };
-  auto halo_write = [&](int buf, auto K) {
-    constexpr int k = decltype(K)::value;
-    if (k * 64 + 63 < HALO || prow + k * 64 < HALO) {
-      constexpr int r = k % 3;
-      float v[8] = {hh0[r].x, hh0[r].y, hh0[r].z, hh0[r].w, hh1[r].x, hh1[r].y, hh1[r].z, hh1[r].w};
-      if (L.pro_a) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = silu_fast(fmaf(v[u], pa[u], pb[u]));
+  // one pass = four pair slices (prologue + split of two channels) and a write slice: five MFMA shadows
+  uint32_t hp2[4], lp2[4];
+  auto stage_slice = [&](int buf, auto K, auto P) {
+    constexpr int k = decltype(K)::value, p = decltype(P)::value, r = k % 3;
+    if constexpr (p < 4) {
+      float v0 = p == 0 ? hh0[r].x : p == 1 ? hh0[r].z : p == 2 ? hh1[r].x : hh1[r].z;
+      float v1 = p == 0 ? hh0[r].y : p == 1 ? hh0[r].w : p == 2 ? hh1[r].y : hh1[r].w;
+      if constexpr (PRO) {
+        v0 = silu_fast(fmaf(v0, pa[2 * p], pb[2 * p]));
+        v1 = silu_fast(fmaf(v1, pa[2 * p + 1], pb[2 * p + 1]));
       }
-      if (hsrc[k] < 0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = 0.0f;
+      if (hsrc[k] < 0) { v0 = 0.0f; v1 = 0.0f; }
+      split2<!PRO>(v0, v1, hp2[p], lp2[p]);
+    } else {
+      if (k * 64 + 63 < HALO || prow + k * 64 < HALO) {
+        char* dst = Ah + buf * HBYTES + w_lane[k];
+        *reinterpret_cast<uint4*>(dst) = make_uint4(hp2[0], hp2[1], hp2[2], hp2[3]);
+        *reinterpret_cast<uint4*>(dst + 64) = make_uint4(lp2[0], lp2[1], lp2[2], lp2[3]);
       }
-      uint4 vh, vl;
-      if (L.pro_a) split8<false>(v, vh, vl);
-      else split8(v, vh, vl);
-      char* p = Ah + buf * HBYTES + w_lane[k];
-      *reinterpret_cast<uint4*>(p) = vh;
-      *reinterpret_cast<uint4*>(p + 64) = vl;
     }
+  };
+  auto stage_pass = [&](int buf, auto K) {
+    stage_slice(buf, K, IC<0>()); stage_slice(buf, K, IC<1>()); stage_slice(buf, K, IC<2>()); stage_slice(buf, K, IC<3>());
+    stage_slice(buf, K, IC<4>());
   };
 
   // ---- weight tiles: LDS-DMA, lane-linear destination, the XOR swizzle on the per-lane source address ----
@@ -133,13 +138,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int n = (wave * WPW + r) * 8 + (lane >> 3);
     wsrc[r] = n * 128 + (((lane & 7) ^ ((n >> 1) & 7)) << 4);
   }
-  auto gload_b = [&](int chunk, int tap, int slot) {
+  auto dma_piece = [&](int chunk, int tap, int slot, auto R) {
+    constexpr int r = decltype(R)::value;
     const char* p = wtile + (size_t)(tap * L.split_kchunks + chunk) * wstep;
     char* dst = Bs + (slot * BN + wave * WPW * 8) * 128;
-#pragma unroll
-    for (int r = 0; r < WPW; ++r)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
-                                       (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + wsrc[r]),
+                                     (__attribute__((address_space(3))) void*)(dst + r * 1024), 16, 0, 0);
   };
 
   // ---- fragments ----
@@ -159,110 +163,75 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }
   f16x8 fa[2][8], fw[2][4];                              // [k16 step][A: (hi, lo) x row tile | W: (hi, lo) x column tile]
-  auto reads = [&](auto ST, auto TAP, int cb) {
-    constexpr int st = decltype(ST)::value, T = decltype(TAP)::value;
+  // fragment R (0 .. 7: A rows, 8 .. 11: weight columns) of k16 step ST of tap TAP
+  auto read_slot = [&](auto ST, auto TAP, auto R, int cb) {
+    constexpr int st = decltype(ST)::value, T = decltype(TAP)::value, r = decltype(R)::value;
     constexpr int toff = (T / 3) * RSTRIDE + (T % 3) * PITCH;
-    const char* A = Ah + cb * HBYTES + toff + st * 32 + a_lane;
-    const char* Bb = Bs + (T % NS) * (BN * 128);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[st][2 * i] = ld_frag(reinterpret_cast<const uint4*>(A + i * 2 * RSTRIDE));
-      fa[st][2 * i + 1] = ld_frag(reinterpret_cast<const uint4*>(A + i * 2 * RSTRIDE + 64));
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      fw[st][2 * j] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][0] + j * 4096));
-      fw[st][2 * j + 1] = ld_frag(reinterpret_cast<const uint4*>(Bb + b_lane[st][1] + j * 4096));
+    if constexpr (r < 8) {
+      fa[st][r] = ld_frag(reinterpret_cast<const uint4*>(Ah + cb * HBYTES + toff + st * 32 + a_lane + (r >> 1) * 2 * RSTRIDE + (r & 1) * 64));
+    } else {
+      constexpr int j = (r - 8) >> 1, h = (r - 8) & 1;
+      fw[st][2 * j + h] = ld_frag(reinterpret_cast<const uint4*>(Bs + (T % NS) * (BN * 128) + b_lane[st][h] + j * 4096));
     }
   };
-  auto mfmas = [&](auto ST) {                            // term-major: back-to-back MFMAs never wait on the same accumulator
-    constexpr int st = decltype(ST)::value;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i + 1], fw[st][2 * j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j + 1], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][2 * i], fw[st][2 * j], acc[i][j], 0, 0, 0);
+  auto reads = [&](auto ST, auto TAP, int cb) {
+    static_for<12>([&](auto R) { read_slot(ST, TAP, R, cb); });
   };
-  // scheduling pipelines of the two k16 steps of a tap (sched_group_barrier masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM
-  // read, 0x002 VALU): 24 MFMAs each, the 12 fragment reads of the OTHER register set one per MFMA shadow, and the tap's producer work —
-  // four LDS-DMA pieces in the first half; the staging VALU, the halo's global loads and the two LDS writes in the second
-  auto pipeline_a = [&]() {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-  };
-  auto pipeline_b = [&]() {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    }
+  // MFMA M (0 .. 23) of k16 step ST: term-major over the 4 x 2 tiles (a lo x w hi, a hi x w lo, a hi x w hi), so that back-to-back
+  // MFMAs never wait on the same accumulator: per accumulator the sequence is conv3x3_split_ws_kernel's
+  auto mfma_slot = [&](auto ST, auto M) {
+    constexpr int st = decltype(ST)::value, m = decltype(M)::value, term = m / 8, idx = m % 8, i = idx >> 1, j = idx & 1;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][term == 0 ? 2 * i + 1 : 2 * i], fw[st][term == 1 ? 2 * j + 1 : 2 * j], acc[i][j], 0, 0, 0);
   };
 
-  // one tap of chunk c.  Invariant at its barrier: weight tiles it and it + 1 are in LDS (tile it + 1 was issued a tap ago), tile
-  // it - 1's slot is free, this chunk's halo is complete; the other halo buffer was last read before the previous barrier.
-  auto body = [&](auto TAP, int c) {
+  // One tap of chunk c, as 48 pinned issue slots: MFMA m, the slot's side work, a scheduling fence (hipcc otherwise re-orders the
+  // MFMAs into dependent chains and bunches the side work: the first form of this kernel, profiles/r06_ab_split_w512.txt).
+  // Invariant at the tap's barrier: weight tiles it and it + 1 are in LDS (tile it + 1 was issued a tap ago), tile it - 1's slot is
+  // free, this chunk's halo is complete; the other halo buffer was last read before the previous barrier.
+  //   first half  (step 0's MFMAs): slots 0-11 the fragments of step 1, slots 12-15 the four LDS-DMA pieces of tile it + 2;
+  //   second half (step 1's MFMAs): slots 0-11 the next tap's step-0 fragments, slots 12-23 the next chunk's staging —
+  //     tap 0: coefficients + passes 0-2 loaded;  tap 2: passes 0, 1 converted and written;  tap 3: pass 2, then passes 3-5 loaded
+  //     into the freed registers;  taps 5, 6, 7: passes 3, 4, 5;  tap 8: nothing (the buffer is handed over at the next barrier).
+  auto body = [&](auto TAP, auto MORE, int c) {
     constexpr int T = decltype(TAP)::value;
-    const int it = c * NT + T;
-    const bool more = c + 1 < nchunks;
+    constexpr bool more = decltype(MORE)::value != 0;
+    constexpr bool dma = T + 2 < NT || more;
     // the in-order VMEM queue behind the DMA of tile it + 1: only the halo (and coefficient) loads the previous tap issued
-    // (taps 0 and 3: six loads, four more at tap 0 when the launch has a fused prologue)
-    if (T == 1 && more) {
-      if (L.pro_a) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else if (T == 4 && more) {
-      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    // first half: the DMA of tile it + 2 (into tile it - 1's slot), the fragments of step 1, the MFMAs of step 0.  Its own scheduling
-    // region, so that the DMA stays IN FRONT of the second half's halo loads in the in-order VMEM queue (the counted wait above)
+    if constexpr (T == 1 && more && PRO) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr ((T == 1 || T == 4) && more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (T + 2 < NT) { gload_b(c, T + 2, (T + 2) % NS); }
-    else if (more) gload_b(c + 1, T + 2 - NT, (T + 2) % NS);
-    reads(IC<1>(), TAP, c & 1);
-    mfmas(IC<0>());
-    pipeline_a();
-    __builtin_amdgcn_sched_barrier(0);
-    // second half: the next chunk's staging (loads at tap 0, one converted pass at taps 2-7), the next tap's first fragments, step 1
-    if (more) {
-      // passes 0-2: loaded at tap 0 (a tap and a half = ~3000 cycles before their first use), written at taps 2 (two passes) and 3;
-      // the set is then free for passes 3-5: loaded at tap 3 behind that write, written at taps 5, 6, 7; tap 8 hands the buffer over
-      if constexpr (T == 0) { pro_load(c + 1); halo_load(c + 1, IC<0>()); }
-      if constexpr (T == 2) { halo_write((c + 1) & 1, IC<0>()); halo_write((c + 1) & 1, IC<1>()); }
-      if constexpr (T == 3) { halo_write((c + 1) & 1, IC<2>()); halo_load(c + 1, IC<3>()); }
-      if constexpr (T == 5) halo_write((c + 1) & 1, IC<3>());
-      if constexpr (T == 6) halo_write((c + 1) & 1, IC<4>());
-      if constexpr (T == 7) halo_write((c + 1) & 1, IC<5>());
-    }
-    if constexpr (T < NT - 1) reads(IC<0>(), IC<T + 1>(), c & 1);
-    else if (more) reads(IC<0>(), IC<0>(), (c + 1) & 1);
-    mfmas(IC<1>());
-    pipeline_b();
-    __builtin_amdgcn_sched_barrier(0);
+    const int nc = T + 2 < NT ? c : c + 1;               // chunk of tile it + 2
+    static_for<24>([&](auto M) {
+      constexpr int m = decltype(M)::value;
+      mfma_slot(IC<0>(), M);
+      if constexpr (m < 12) read_slot(IC<1>(), TAP, M, c & 1);
+      else if constexpr (m < 16 && dma) dma_piece(nc, (T + 2) % NT, (T + 2) % NS, IC<m - 12>());
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    const int nb = (c + 1) & 1;
+    static_for<24>([&](auto M) {
+      constexpr int m = decltype(M)::value, sl = m - 12;
+      mfma_slot(IC<1>(), M);
+      if constexpr (m < 12) {
+        if constexpr (T < NT - 1) read_slot(IC<0>(), IC<(T + 1) % NT>(), M, c & 1);
+        else if constexpr (more) read_slot(IC<0>(), IC<0>(), M, nb);
+      } else if constexpr (more) {
+        if constexpr (T == 0) {
+          if constexpr (sl == 0) { halo_chunk(c + 1); pro_load(c + 1); }
+          if constexpr (sl >= 1 && sl <= 3) halo_load1(IC<sl - 1>());
+        } else if constexpr (T == 2) {
+          if constexpr (sl < 5) stage_slice(nb, IC<0>(), IC<sl < 5 ? sl : 0>());
+          else if constexpr (sl < 10) stage_slice(nb, IC<1>(), IC<sl < 10 ? sl - 5 : 0>());
+        } else if constexpr (T == 3) {
+          if constexpr (sl < 5) stage_slice(nb, IC<2>(), IC<sl < 5 ? sl : 0>());
+          else if constexpr (sl < 8) halo_load1(IC<sl < 8 ? sl - 2 : 3>());
+        } else if constexpr (T >= 5 && T <= 7) {
+          if constexpr (sl < 5) stage_slice(nb, IC<T - 2>(), IC<sl < 5 ? sl : 0>());
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
     if constexpr (T == NT - 1) {                         // the 288-term partial of this channel chunk
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -272,21 +241,24 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
           for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
     }
   };
+  auto chunk_taps = [&](auto MORE, int c) {
+    body(IC<0>(), MORE, c); body(IC<1>(), MORE, c); body(IC<2>(), MORE, c); body(IC<3>(), MORE, c); body(IC<4>(), MORE, c);
+    body(IC<5>(), MORE, c); body(IC<6>(), MORE, c); body(IC<7>(), MORE, c); body(IC<8>(), MORE, c);
+  };
 
   // ---- prologue: weight tiles 0 and 1, chunk 0's halo ----
-  gload_b(0, 0, 0);
-  if (niter > 1) gload_b(0, 1, 1);
+  static_for<WPW>([&](auto R) { dma_piece(0, 0, 0, R); });
+  static_for<WPW>([&](auto R) { dma_piece(0, 1, 1, R); });
+  halo_chunk(0);
   pro_load(0);
-  halo_load(0, IC<0>());
-  halo_write(0, IC<0>()); halo_write(0, IC<1>()); halo_write(0, IC<2>());
-  halo_load(0, IC<3>());
-  halo_write(0, IC<3>()); halo_write(0, IC<4>()); halo_write(0, IC<5>());
+  halo_load1(IC<0>()); halo_load1(IC<1>()); halo_load1(IC<2>());
+  stage_pass(0, IC<0>()); stage_pass(0, IC<1>()); stage_pass(0, IC<2>());
+  halo_load1(IC<3>()); halo_load1(IC<4>()); halo_load1(IC<5>());
+  stage_pass(0, IC<3>()); stage_pass(0, IC<4>()); stage_pass(0, IC<5>());
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   reads(IC<0>(), IC<0>(), 0);
-  for (int c = 0; c < nchunks; ++c) {
-    body(IC<0>(), c); body(IC<1>(), c); body(IC<2>(), c); body(IC<3>(), c); body(IC<4>(), c);
-    body(IC<5>(), c); body(IC<6>(), c); body(IC<7>(), c); body(IC<8>(), c);
-  }
+  for (int c = 0; c + 1 < nchunks; ++c) chunk_taps(IC<1>(), c);
+  chunk_taps(IC<0>(), nchunks - 1);
 
   // ---- direct epilogue (conv3x3_split_ws_kernel's, per 8 x 16 pixel half): register e of lane half hi is pixel row
   //      (e & 3) + 8 (e >> 2) + 4 hi of a 32-pixel row tile, lanes 0-31 are 32 consecutive channels ----
@@ -374,10 +346,13 @@ int try_launch_conv3x3_split_w512(const ConvLaunch<float>& L, hipStream_t s, int
   if (gn_nsplit_out) *gn_nsplit_out = f ? slabs : 0;
   static DeviceOnce attr_done;
   if (!attr_done.done()) {
-    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_w512_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_w512_kernel<NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_w512_kernel<NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     attr_done.mark();
   }
-  conv3x3_split_w512_kernel<NS><<<dim3(tiles_x * tiles_y * tiles_n * d.B), 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, f);
+  const dim3 grid(tiles_x * tiles_y * tiles_n * d.B);
+  if (L.pro_a) conv3x3_split_w512_kernel<NS, true><<<grid, 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, f);
+  else conv3x3_split_w512_kernel<NS, false><<<grid, 256, lds, s>>>(L, tiles_x, tiles_y, tiles_n, f);
   PRG_LAUNCH_CHECK();
   return 1;
 }

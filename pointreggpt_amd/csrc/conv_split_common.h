@@ -64,4 +64,31 @@ struct IC {
   static constexpr int value = N;
 };
 
+// f(IC<0>()), f(IC<1>()), ... f(IC<N - 1>()): a loop whose index is a compile-time constant in the body
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IC<I>());
+    static_for<N, I + 1>(f);
+  }
+}
+
+// two consecutive channels -> packed hi and lo halves (one pair of split8: the same instructions, the same bits)
+template <bool MIX>
+__device__ inline void split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+  const f32x2 p = {v0, v1};
+  const f16x2 ph = __builtin_convertvector(p, f16x2);
+  f32x2 r;
+  if constexpr (MIX) {
+    const uint32_t phw = __builtin_bit_cast(uint32_t, ph);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(phw), "v"(p[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(phw), "v"(p[1]));
+  } else {
+    r = p - __builtin_convertvector(ph, f32x2);
+  }
+  const f16x2 pl = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(uint32_t, ph);
+  lo = __builtin_bit_cast(uint32_t, pl);
+}
+
 }  // namespace prg
