@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; tot[i][j][e] = 0.0f; }   // (acc: dead store, every chunk starts from the constant)
   f16x8 fa[2][8], fw[2][4];                              // [k16 step][A: (hi, lo) x row tile | W: (hi, lo) x column tile]
   // fragment R (0 .. 7: A rows, 8 .. 11: weight columns) of k16 step ST of tap TAP
   auto read_slot = [&](auto ST, auto TAP, auto R, int cb) {
@@ -179,9 +179,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   };
   // MFMA M (0 .. 23) of k16 step ST: term-major over the 4 x 2 tiles (a lo x w hi, a hi x w lo, a hi x w hi), so that back-to-back
   // MFMAs never wait on the same accumulator: per accumulator the sequence is conv3x3_split_ws_kernel's
-  auto mfma_slot = [&](auto ST, auto M) {
+  // FIRST: the chunk's first MFMA on this accumulator takes the instruction's constant 0 as its C operand instead of a zeroed register
+  // tuple (0 + x: the same bits) — the flush then only adds, it does not clear 128 registers
+  auto mfma_slot = [&](auto ST, auto M, auto FIRST) {
     constexpr int st = decltype(ST)::value, m = decltype(M)::value, term = m / 8, idx = m % 8, i = idx >> 1, j = idx & 1;
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][term == 0 ? 2 * i + 1 : 2 * i], fw[st][term == 1 ? 2 * j + 1 : 2 * j], acc[i][j], 0, 0, 0);
+    const f16x8& a = fa[st][term == 0 ? 2 * i + 1 : 2 * i];
+    const f16x8& w = fw[st][term == 1 ? 2 * j + 1 : 2 * j];
+    if constexpr (decltype(FIRST)::value != 0 && term == 0) {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, zero, 0, 0, 0);
+    } else {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, acc[i][j], 0, 0, 0);
+    }
   };
 
   // One tap of chunk c, as 48 pinned issue slots: MFMA m, the slot's side work, a scheduling fence (hipcc otherwise re-orders the
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int nc = T + 2 < NT ? c : c + 1;               // chunk of tile it + 2
     static_for<24>([&](auto M) {
       constexpr int m = decltype(M)::value;
-      mfma_slot(IC<0>(), M);
+      mfma_slot(IC<0>(), M, IC<(T == 0)>());
       if constexpr (m < 12) read_slot(IC<1>(), TAP, M, c & 1);
       else if constexpr (m < 16 && dma) dma_piece(nc, (T + 2) % NT, (T + 2) % NS, IC<m - 12>());
       __builtin_amdgcn_sched_barrier(0);
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int nb = (c + 1) & 1;
     static_for<24>([&](auto M) {
       constexpr int m = decltype(M)::value, sl = m - 12;
-      mfma_slot(IC<1>(), M);
+      mfma_slot(IC<1>(), M, IC<0>());
       if constexpr (m < 12) {
         if constexpr (T < NT - 1) read_slot(IC<0>(), IC<(T + 1) % NT>(), M, c & 1);
         else if constexpr (more) read_slot(IC<0>(), IC<0>(), M, nb);
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) { tot[i][j][e] += acc[i][j][e]; acc[i][j][e] = 0.0f; }
+          for (int e = 0; e < 16; ++e) tot[i][j][e] += acc[i][j][e];
     }
   };
   auto chunk_taps = [&](auto MORE, int c) {
