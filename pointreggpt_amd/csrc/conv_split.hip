@@ -1601,7 +1601,8 @@ int try_launch_conv_split(const ConvLaunch<float>& L, hipStream_t s, int* gn_nsp
       return rc ? rc : 1;
     }
     {
-      // EXPERIMENT (PRG_SPLIT_W512=1, conv_split512.hip): one wave per SIMD, 128 x 64 wave tiles; bit-identical to the kernel below
+      // conv_split512.hip (round 6): one wave per SIMD, 128 x 64 wave tiles, for launches with a 256-pixel tile per CU; bit-identical to
+      // the kernel below (PRG_SPLIT_W512=0: off)
       const int r = try_launch_conv3x3_split_w512(L, s, want_stats, gn_nsplit_out);
       if (r != 0) return r;
     }

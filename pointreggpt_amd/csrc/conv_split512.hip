@@ -13,7 +13,7 @@
 //     stream — one s_barrier per tap for four waves.
 // The arithmetic is conv3x3_split_ws_kernel's term for term (same MFMA sequence per accumulator, 288-term partials, same epilogue
 // expression, same GroupNorm slab partition: a wave's 128 pixels are one 8 x 16 tile of that kernel), so the two are bit-identical
-// (tests/test_gpu_f16x3.py::test_f16x3_one_wave_per_simd_kernel).  Selected by PRG_SPLIT_W512=1; the same-box A/B is
+// (tests/test_gpu_f16x3.py::test_f16x3_one_wave_per_simd_kernel).  Dispatch: try_launch_conv3x3_split_w512 below; the same-box A/B is
 // profiles/r06_ab_split_w512.txt.
 #include <atomic>
 #include <cstdlib>
@@ -337,9 +337,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   }
 }
 
-// 1 = launched, 0 = not this kernel's shape / not enabled, < 0 = error.  PRG_SPLIT_W512=1 enables it (experiment: see the header).
+// 1 = launched, 0 = not this kernel's shape / switched off, < 0 = error.  Default ON for launches with at least one 256-pixel x
+// 128-channel tile per CU (same-box A/B, profiles/r06_ab_split_w512.txt: -3 ... -5 % per launch against conv3x3_split_ws_kernel, the
+// whole f16x3 pipeline +2.4 %; with half as many workgroups as the 128-pixel kernel a launch below that size leaves CUs idle:
+// 256 -> 256 @16x16 at B = 64 ran 83 us against 52).  PRG_SPLIT_W512=0: never; =2: every shape it covers (tests).
 int try_launch_conv3x3_split_w512(const ConvLaunch<float>& L, hipStream_t s, int want_stats, int* gn_nsplit_out) {
-  static const int on = [] { const char* e = std::getenv("PRG_SPLIT_W512"); return e ? std::atoi(e) : 0; }();
+  static const int on = [] { const char* e = std::getenv("PRG_SPLIT_W512"); return e ? std::atoi(e) : 1; }();
   if (!on) return 0;
   const ConvDesc& d = L.d;
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Cout % 128 == 0 && d.Wout % 16 == 0 && d.Hout % 16 == 0 && !L.residual &&
@@ -347,6 +350,7 @@ int try_launch_conv3x3_split_w512(const ConvLaunch<float>& L, hipStream_t s, int
     return 0;
   constexpr int NS = 3, HB = 18 * ((18 * 144 + 255) / 256 * 256);
   const int tiles_x = d.Wout / 16, tiles_y = d.Hout / 16, tiles_n = d.Cout / 128;
+  if (on != 2 && tiles_x * tiles_y * tiles_n * d.B < device_cu_count()) return 0;
   const int cpg = L.gn_groups > 0 ? d.Cout / L.gn_groups : 0;
   const int slabs = tiles_x * tiles_y * 4;
   const int f = want_stats && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 && slabs <= kGnMaxSplit;
