@@ -3,7 +3,7 @@
 
   python tools/chain_run.py G21b_ddim250_256 f16x3 [batch]
 
-The library reads its PRG_* switches once per process, so precision / dispatch experiments (tools/gpu_r5_precision.sh) run this
+The library reads its PRG_* switches once per process, so precision / dispatch experiments (tools/gpu_precision_budget.sh) run this
 script once per variant.  Same code path as tests/test_gpu_f16x3.py::test_long_chain_f16x3_north_star (it calls its helper)."""
 import json
 import os

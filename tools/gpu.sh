@@ -52,7 +52,7 @@ for ST in "$@"; do
       bash tools/gpu_split_bench.sh f16x3 > $O/${T}_split_conv_bench.txt 2>&1; tail -30 $O/${T}_split_conv_bench.txt
       bash tools/gpu_split_pmc.sh > $O/${T}_split_conv_pmc.txt 2>&1; tail -20 $O/${T}_split_conv_pmc.txt;;
     hostsat) python tools/host_saturation.py --out $O/${T}_host_saturation_8x.json 2>&1 | tail -30;;
-    power) bash tools/gpu_r5_power_modes.sh > $O/${T}_power_modes.log 2>&1; tail -25 $O/${T}_power_modes.log;;
+    power) bash tools/gpu_power_modes.sh > $O/${T}_power_modes.log 2>&1; cp $O/power_modes.json $O/${T}_power_clock_mfma_busy_per_mode.json; tail -25 $O/${T}_power_modes.log;;
     sh:*) bash tools/${ST#sh:} 2>&1 | tail -60;;
     *) echo "unknown stage $ST";;
   esac

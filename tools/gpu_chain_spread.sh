@@ -2,7 +2,7 @@
 # round 5: how much the point-XYZ L-infinity of the long chains moves between EQUAL-PRECISION variants of the f16x3 arithmetic
 # (kernel choices that only re-order float32 sums): the spread the literal 1e-4 m assertion has to live with.
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r5_spread.txt
+O=gpurun_out/chain_spread.txt
 : > $O
 run() {  # fixture batch env...
   local fx=$1 nb=$2; shift 2
@@ -21,7 +21,7 @@ for FX in G21b_ddim250_256 G20_ddim250_128 G22_chain1000_ancestral_128; do
 done
 python - <<'PY'
 import json
-for l in open("gpurun_out/r5_spread.txt"):
+for l in open("gpurun_out/chain_spread.txt"):
     if l.startswith("CHAIN "):
         r = json.loads(l[6:])
         print(f"{r['fixture']:30s} {str(r['env']):60s} xyz {r.get('xyz_linf_m', float('nan')):.3e} mean {r['depth_mean_m']:.3e} same_mask {r['same_valid_mask']} {r['seconds']} s")

@@ -1,16 +1,16 @@
 #!/bin/bash
-# round 5: one box, back to back — socket power, shader clock (rocm-smi every 0.5 s inside the timed loop),
+# tools/gpu_power_modes.sh (round 5; round 6: fp32 counter pass added): one box, back to back — socket power, shader clock (rocm-smi every 0.5 s inside the timed loop),
 # pairs/s and pairs per joule of the three throughput-relevant modes at the headline shape (B = 64, 128 x 128, ancestral DDNM, two
 # lanes), and the MFMA-busy fraction of each mode's kernels from one SQ counter pass (separate run, --pmc with --kernel-trace only).
-#   bash tools/gpu_r5_power_modes.sh  ->  gpurun_out/r5_power_modes.json
+#   bash tools/gpu_power_modes.sh  ->  gpurun_out/power_modes.json
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 COMMON="--streams 2 --no-cpu-baseline --no-e2e-files --no-drift --no-configs4 --no-roofline --no-parity-mode"
 run_mode() {  # dtype timesteps steps warmup
   local DT=$1 TS=$2 ST=$3 WU=$4
-  ( for i in $(seq 1 400); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Package Power|sclk" | tr '\n' ' '; echo; sleep 0.5; done ) > $O/r5_power_trace_$DT.txt &
+  ( for i in $(seq 1 400); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Package Power|sclk" | tr '\n' ' '; echo; sleep 0.5; done ) > $O/power_trace_$DT.txt &
   local SAMP=$!
-  python bench.py --dtype $DT --timesteps $TS --steps $ST --warmup $WU $COMMON > $O/r5_power_bench_$DT.json 2> $O/r5_power_bench_$DT.err
+  python bench.py --dtype $DT --timesteps $TS --steps $ST --warmup $WU $COMMON > $O/power_bench_$DT.json 2> $O/power_bench_$DT.err
   kill $SAMP 2>/dev/null; wait $SAMP 2>/dev/null
 }
 run_mode bf16 1000 6 2
@@ -18,14 +18,14 @@ run_mode mxfp8 1000 6 2
 run_mode f16x3 300 6 2
 run_mode fp32 60 4 2
 cd /tmp && export TMPDIR=/tmp
-for DT in bf16 mxfp8 f16x3; do
-  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/r5_power_pmc_$DT -o r -- \
-    python $GRAFT_REPO_ROOT/bench.py --dtype $DT --steps 1 --warmup 0 --streams 1 --sampling-steps 2 --no-cpu-baseline --no-roofline --no-e2e-files --no-drift --no-configs4 --no-parity-mode > $GRAFT_REPO_ROOT/$O/r5_power_pmc_$DT.log 2>&1 || true
+for DT in bf16 mxfp8 f16x3 fp32; do      # (round 5 left fp32 out of this loop: its row had a pmc_error)
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/power_pmc_$DT -o r -- \
+    python $GRAFT_REPO_ROOT/bench.py --dtype $DT --steps 1 --warmup 0 --streams 1 --sampling-steps 2 --no-cpu-baseline --no-roofline --no-e2e-files --no-drift --no-configs4 --no-parity-mode > $GRAFT_REPO_ROOT/$O/power_pmc_$DT.log 2>&1 || true
 done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv, json, re, collections
-out = {"what": "one box, back to back (tools/gpu_r5_power_modes.sh): rocm-smi socket power / shader clock every 0.5 s during bench.py --streams 2 "
+out = {"what": "one box, back to back (tools/gpu_power_modes.sh): rocm-smi socket power / shader clock every 0.5 s during bench.py --streams 2 "
                "(B = 64, 128x128, ancestral DDNM; bf16 / mxfp8 1000 transitions x 6 timed batches, f16x3 300 x 6, fp32 60 x 4: pairs/s scaled to 1000 transitions "
                "by bench.py's own accounting); samples above 600 W = inside the timed loop; MFMA-busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (32 x sum SQ_BUSY_CYCLES) over "
                "every kernel of two transitions + two MaskUnet evaluations (one --pmc pass per mode, --kernel-trace only)", "modes": {}}
@@ -34,12 +34,12 @@ MFMA_PER_ALG = {"bf16": 1.0, "mxfp8": 1.0, "f16x3": 3.0, "fp32": 1.0}
 for dt in ("bf16", "mxfp8", "f16x3", "fp32"):
     try:
         pw, ck = [], []
-        for line in open(f"gpurun_out/r5_power_trace_{dt}.txt"):
+        for line in open(f"gpurun_out/power_trace_{dt}.txt"):
             m = re.search(r"Power \(W\):\s*([0-9.]+)", line); c = re.search(r"sclk[^()]*\(([0-9]+)Mhz\)", line)
             if m and c:
                 pw.append(float(m.group(1))); ck.append(float(c.group(1)))
         busy = [(p, c) for p, c in zip(pw, ck) if p > 600]
-        b = json.load(open(f"gpurun_out/r5_power_bench_{dt}.json"))
+        b = json.load(open(f"gpurun_out/power_bench_{dt}.json"))
         n_tr = b["config"].get("transitions", 1000)
         pairs = b["value"] * n_tr / 1000.0          # pairs/s at the 1000-transition workload
         mp = sum(p for p, _ in busy) / max(1, len(busy)); mc = sum(c for _, c in busy) / max(1, len(busy))
@@ -48,7 +48,7 @@ for dt in ("bf16", "mxfp8", "f16x3", "fp32"):
              "algorithmic_TFLOPs_end_to_end": pairs * 59.094, "end_to_end_frac_of_nominal_peak": pairs * 59.094 * MFMA_PER_ALG[dt] / PEAK[dt]}
         try:
             tot = collections.defaultdict(float)
-            for row in csv.DictReader(open(f"gpurun_out/r5_power_pmc_{dt}/r_counter_collection.csv")):
+            for row in csv.DictReader(open(f"gpurun_out/power_pmc_{dt}/r_counter_collection.csv")):
                 tot[row["Counter_Name"]] += float(row["Counter_Value"])
             r["mfma_busy_all_kernels"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * tot["SQ_BUSY_CYCLES"]) if tot.get("SQ_BUSY_CYCLES") else None
             # achieved matrix-pipe rate implied by clock x busy: nominal peak x (clock / 2400 MHz) x busy
@@ -60,7 +60,7 @@ for dt in ("bf16", "mxfp8", "f16x3", "fp32"):
         out["modes"][dt] = r
     except Exception as e:
         out["modes"][dt] = {"error": str(e)}
-json.dump(out, open("gpurun_out/r5_power_modes.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/power_modes.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-rm -rf $O/r5_power_pmc_bf16 $O/r5_power_pmc_mxfp8 $O/r5_power_pmc_f16x3
+rm -rf $O/power_pmc_bf16 $O/power_pmc_mxfp8 $O/power_pmc_f16x3

@@ -2,7 +2,7 @@
 # round 5: which contraction class of the f16x3 mode needs more than 22 bits on the 256x256 chain (G21b), and what the
 # per-channel power-of-two weight scale (PRG_SPLIT_WSCALE, conv_split.hip) buys.  Runs on the GPU box through gpurun.
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r5_precision.txt
+O=gpurun_out/precision_budget.txt
 : > $O
 run() {  # fixture batch env...
   local fx=$1 nb=$2; shift 2
@@ -23,7 +23,7 @@ run G22_chain1000_ancestral_128 1 PRG_SPLIT_WSCALE=1
 run G19_chain1000_ancestral_64 1 PRG_SPLIT_WSCALE=1
 python - <<'PY'
 import json
-for l in open("gpurun_out/r5_precision.txt"):
+for l in open("gpurun_out/precision_budget.txt"):
     if l.startswith("CHAIN "):
         r = json.loads(l[6:])
         print(f"{r['fixture']:30s} {str(r['env']):70s} xyz {r.get('xyz_linf_m', float('nan')):.3e} mean {r['depth_mean_m']:.3e} same_mask {r['same_valid_mask']} {r['seconds']} s")
