@@ -27,7 +27,7 @@ int launch_gn_coeff_acc(const GnFold& f, float* A, float* Bc, int B, int C, hipS
 // entries [n] of (ss_off, C, gamma offset, beta offset into `flat`); pq [B][ss_total]: P at ss_off, Q at ss_off + C.
 struct CondFoldEntry { int ss_off, C; long long gamma_off, beta_off; };
 int launch_cond_fold(const CondFoldEntry* entries, int n, const float* flat, const GnApply& ss, float* pq, int64_t pq_stride,
-                     int B, hipStream_t s);
+                     int B, hipStream_t s, long long* zero = nullptr, int64_t zero_words = 0);
 // y = silu(x * A + B) + residual with the coefficients folded per block from the accumulators (one image per block row)
 int launch_affine_silu_fold(const bf16_t* x, const GnFold& f, const bf16_t* residual, bf16_t* out, int B, int HW, int C,
                             hipStream_t s);

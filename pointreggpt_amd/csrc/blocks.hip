@@ -365,10 +365,17 @@ int launch_gn_coeff_acc(const GnFold& f, float* A, float* Bc, int B, int C, hipS
 }
 
 // grid (entries, B): P = gamma (scale + 1), Q = beta (scale + 1) + shift of every conditioned GroupNorm of one forward
+// `zero` (may be null): the evaluation's fixed-point GroupNorm accumulators, cleared here instead of by a separate memset launch
+// (round 6: one launch fewer per evaluation; every later kernel of the forward is behind this one on the stream)
 __global__ __launch_bounds__(256) void cond_fold_kernel(const CondFoldEntry* __restrict__ entries, const float* __restrict__ flat,
-                                                        GnApply ss, float* __restrict__ pq, int64_t pq_stride) {
+                                                        GnApply ss, float* __restrict__ pq, int64_t pq_stride,
+                                                        long long* __restrict__ zero, int64_t zero_words) {
   const CondFoldEntry e = entries[blockIdx.x];
   const int b = blockIdx.y;
+  if (zero) {
+    const int64_t nthr = (int64_t)gridDim.x * gridDim.y * 256;
+    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_words; i += nthr) zero[i] = 0;
+  }
   const float* ssa = ss.ss_a + (size_t)b * ss.ss_a_stride + e.ss_off;
   if (ss.ss_a_row) ssa += (size_t)(*ss.ss_a_row) * ss.ss_a_row_stride;
   const float* ssb = ss.ss_b ? ss.ss_b + (size_t)b * ss.ss_b_stride + e.ss_off : nullptr;
@@ -384,9 +391,9 @@ __global__ __launch_bounds__(256) void cond_fold_kernel(const CondFoldEntry* __r
 }
 
 int launch_cond_fold(const CondFoldEntry* entries, int n, const float* flat, const GnApply& ss, float* pq, int64_t pq_stride,
-                     int B, hipStream_t s) {
+                     int B, hipStream_t s, long long* zero, int64_t zero_words) {
   PRG_CHECK(entries && n > 0 && flat && ss.ss_a && pq, "cond_fold: bad arguments");
-  cond_fold_kernel<<<dim3(n, B), 256, 0, s>>>(entries, flat, ss, pq, pq_stride);
+  cond_fold_kernel<<<dim3(n, B), 256, 0, s>>>(entries, flat, ss, pq, pq_stride, zero, zero_words);
   PRG_LAUNCH_CHECK();
   return PRG_OK;
 }

@@ -714,7 +714,9 @@ struct UnetImpl : prg_unet {
     gn_slot = 0;
     pq_dyn = nullptr;
     if (std::is_same<T, bf16_t>::value && gn_acc_enabled()) {
-      if (acc_on() && !arena.dry) PRG_HIP(hipMemsetAsync(d_gnacc, 0, gnacc_bytes, s));
+      // (the conditioned network clears the accumulators inside its cond_fold launch below: one launch fewer per evaluation)
+      const bool fold_clears = acc_on() && !arena.dry && L.cfg.conditional && n_cond_entries > 0 && cs && cs->ss_a;
+      if (acc_on() && !arena.dry && !fold_clears) PRG_HIP(hipMemsetAsync(d_gnacc, 0, gnacc_bytes, s));
       if (L.cfg.conditional && n_cond_entries > 0) {
         float* pq = alloc<float>((size_t)B * L.ss_total);
         PRG_CHECK(arena.dry || pq, "workspace exhausted (conditioning fold)");
@@ -722,7 +724,7 @@ struct UnetImpl : prg_unet {
           GnApply ss{};
           ss.ss_a = cs->ss_a; ss.ss_a_stride = cs->ss_a_stride; ss.ss_b = cs->ss_b; ss.ss_b_stride = cs->ss_b_stride;
           ss.ss_a_row = cs->row; ss.ss_a_row_stride = cs->row_stride;
-          if ((rc = launch_cond_fold(d_cond_entries, n_cond_entries, d_flat, ss, pq, L.ss_total, B, s))) return rc;
+          if ((rc = launch_cond_fold(d_cond_entries, n_cond_entries, d_flat, ss, pq, L.ss_total, B, s, d_gnacc, (int64_t)(gnacc_bytes / sizeof(long long))))) return rc;
           pq_dyn = pq;
         }
       }
