@@ -8,6 +8,7 @@
 #   benchq           the same with --steps 4 --warmup 2 (quick)
 #   prof:<dtype>     rocprofv3 --kernel-trace --stats of 20 DDIM transitions (bf16 / mxfp8) or 10 ancestral ones (fp32 / f16x3), one lane
 #   pmc              the three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*) + conv_hbm_traffic.json
+#   splitpmc         SQ counters of the f16x3 conv micro-bench, wave-specialised kernel vs the one-wave-per-SIMD kernel
 #   split            tools/split_bench.py (f16x3 conv micro-bench) + its counters
 #   hostsat          tools/host_saturation.py (8-rank host-side replay, GPU idle)
 #   power            power / clock / MFMA-busy per precision mode
@@ -47,7 +48,11 @@ for ST in "$@"; do
       bash tools/pmc.sh ${T}_pmc > /dev/null 2>&1
       cd $GRAFT_REPO_ROOT
       rm -rf $O/${T}_pmc_FETCH_SIZE $O/${T}_pmc_WRITE_SIZE $O/${T}_pmc_SQ
+      cp $O/${T}_pmc_conv_hbm_traffic.json profiles/conv_hbm_traffic.json      # (a later `bench` stage of this call reads it; commit the same file)
       cat $O/${T}_pmc_conv_hbm_traffic.json | head -c 600; echo;;
+    splitpmc)
+      PRG_SPLIT_W512=0 bash tools/gpu_split_pmc.sh > $O/${T}_split_conv_pmc_ws.txt 2>&1; grep -E "ws_kernel|p64_kernel|Kernel|kernel" $O/${T}_split_conv_pmc_ws.txt | head -30
+      PRG_SPLIT_W512=2 bash tools/gpu_split_pmc.sh > $O/${T}_split_conv_pmc_w512.txt 2>&1; grep -E "w512_kernel|p64_kernel" $O/${T}_split_conv_pmc_w512.txt | head -30;;
     split)
       bash tools/gpu_split_bench.sh f16x3 > $O/${T}_split_conv_bench.txt 2>&1; tail -30 $O/${T}_split_conv_bench.txt
       bash tools/gpu_split_pmc.sh > $O/${T}_split_conv_pmc.txt 2>&1; tail -20 $O/${T}_split_conv_pmc.txt;;
