@@ -154,6 +154,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=2, help="untimed batches per rank")
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--streams", type=int, default=2, help="independent pipelines (HIP stream + host thread each) sharing the GPU")
+    p.add_argument("--static-lanes", action="store_true", help="deal the timed batches round-robin to the lanes (rounds 3-5) instead of from a shared counter")
     p.add_argument("--size", type=int, default=128)
     p.add_argument("--timesteps", type=int, default=1000)
     p.add_argument("--sampling-steps", type=int, default=None, help="< timesteps selects DDIM (default: ancestral DDNM)")
@@ -791,7 +792,7 @@ def main():
 
     last = {}
 
-    def run_batches(lo, hi):
+    def run_batches(lo, hi, dynamic=False):
         if len(pipes) == 1:
             for i in range(lo, hi):
                 one_batch(batches[i])
@@ -799,12 +800,28 @@ def main():
         import threading
         errs = []
 
+        # `dynamic`: the lanes pull the next batch from one shared counter instead of owning every n-th batch — with a batch count
+        # that is not a multiple of the lane count (the driver's 20 steps on 3 lanes) no lane idles through a whole last round
+        nxt, lock = [lo], threading.Lock()
+
+        def take():
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            return i if i < hi else None
+
         def worker(k):
             try:
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(pipes[k]["stream"]):
-                    for i in range(lo + k, hi, len(pipes)):
-                        one_batch(batches[i], pipes[k])
+                    if dynamic:
+                        i = take()
+                        while i is not None:
+                            one_batch(batches[i], pipes[k])
+                            i = take()
+                    else:
+                        for i in range(lo + k, hi, len(pipes)):
+                            one_batch(batches[i], pipes[k])
             except BaseException as e:      # noqa: BLE001 — re-raised on the main thread
                 errs.append(e)
 
@@ -836,7 +853,7 @@ def main():
     warmup_s = time.perf_counter() - t_w0
     barrier()
     t0 = time.perf_counter()
-    run_batches(a.warmup, total_batches)
+    run_batches(a.warmup, total_batches, dynamic=not a.static_lanes)
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0              # this rank's own time (before the closing barrier)
     barrier()
