@@ -154,7 +154,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=2, help="untimed batches per rank")
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--streams", type=int, default=2, help="independent pipelines (HIP stream + host thread each) sharing the GPU")
-    p.add_argument("--static-lanes", action="store_true", help="deal the timed batches round-robin to the lanes (rounds 3-5) instead of from a shared counter")
+    p.add_argument("--dynamic-lanes", action="store_true", help="lanes pull the timed batches from a shared counter instead of owning every n-th batch (for "
+                   "lane counts that do not divide the step count; measured equal within noise at 2 / 3 / 4 lanes: profiles/r06_lanes_sweep_bf16.txt)")
     p.add_argument("--size", type=int, default=128)
     p.add_argument("--timesteps", type=int, default=1000)
     p.add_argument("--sampling-steps", type=int, default=None, help="< timesteps selects DDIM (default: ancestral DDNM)")
@@ -853,7 +854,7 @@ def main():
     warmup_s = time.perf_counter() - t_w0
     barrier()
     t0 = time.perf_counter()
-    run_batches(a.warmup, total_batches, dynamic=not a.static_lanes)
+    run_batches(a.warmup, total_batches, dynamic=a.dynamic_lanes)
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0              # this rank's own time (before the closing barrier)
     barrier()
