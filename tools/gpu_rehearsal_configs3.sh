@@ -1,7 +1,7 @@
 #!/bin/bash
 # BASELINE configs[3] rehearsal on ONE GPU: one rank's share of the 10k-pair job (-start 0 -stop 1250, B = 64, 128x128,
 # 1000-step DDNM, bf16, synthetic scenes and weights) through the two CLIs, wall time per stage.  Usage (GPU box):
-#   bash tools/gpu_r3_rehearsal.sh <tag> [stop]     -> gpurun_out/<tag>.json
+#   bash tools/gpu_rehearsal_configs3.sh <tag> [stop]     -> gpurun_out/<tag>.json
 TAG=$1; STOP=${2:-1250}
 ROOT=$GRAFT_REPO_ROOT
 WORK=$(mktemp -d /tmp/prg_rehearsal_XXXX)
