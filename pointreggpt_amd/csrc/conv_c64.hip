@@ -39,7 +39,7 @@ namespace {
 
 // Timing experiments only (results become garbage): -DPRG_C64_EXP=1 consumers skip fragment reads + MFMAs, 2 producers skip
 // the halo loads / writes, 4 no epilogue, 8 no priority raise, 32 producers skip only the prologue arithmetic, 256 SiLU
-// without transcendentals.
+// without transcendentals, 512 consumers issue half their fragment reads (upper bound of a 0.5-reads-per-MFMA form).
 #ifndef PRG_C64_EXP
 #define PRG_C64_EXP 0
 #endif
@@ -242,6 +242,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
               for (int pt = 0; pt < 4; ++pt) {
                 fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
                 acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
+              }
+            } else if constexpr ((PRG_C64_EXP & 512) != 0) { // timing experiment: HALF the fragment reads (0.5 per MFMA; garbage results)
+#pragma unroll
+              for (int pt = 0; pt < 4; ++pt) {
+                if ((pt & 1) == 0) fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+                acc[pt] = mma(wf[tap][c], fx[cur][pt & ~1], acc[pt]);
+                __builtin_amdgcn_sched_barrier(0);
               }
             } else {
 #pragma unroll
@@ -527,6 +534,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
 
 }  // namespace
 
+int try_launch_conv3x3_c64w(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done);   // conv_c64w.hip
+
 // Returns 1 when it launched, 0 when the shape is not covered (caller falls back), negative on error.
 int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
   static const int enabled = [] {
@@ -534,6 +543,12 @@ int try_launch_conv3x3_c64(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_n
     return e ? std::atoi(e) : 1;
   }();
   if (!enabled) return 0;
+  {
+    // round 6: the one-wave-per-SIMD form (conv_c64w.hip: 64 channels of weights per wave, 0.5 fragment reads per MFMA) takes the
+    // launches it covers — probe calls included, so that conv_h16_pair_ok sees the dispatch that will run
+    const int r = try_launch_conv3x3_c64w(L, s, gn_nsplit_out, coef_done, acc_done);
+    if (r != 0) return r;
+  }
   const ConvDesc& d = L.d;
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
   if (d.C0 != 64 || d.C1 != 0 || d.Cout != 64 || d.CoutPad != 64 || d.kchunks != 2) return 0;

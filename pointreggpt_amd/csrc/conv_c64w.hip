@@ -1,0 +1,388 @@
+// conv_c64w.hip — the weights-stationary 64 -> 64 3x3 convolution (bf16 throughput path) with ONE WAVE PER SIMD (round 6).
+//
+// conv3x3_c64_kernel (conv_c64.hip) gives a consumer wave 32 output channels: their 9 x 64 weights fill 144 of its 256 registers, so
+// every pixel fragment it reads from LDS feeds ONE MFMA — 1.0 ds_read_b128 per MFMA, and the two channel-half waves read the same
+// pixels twice.  A timing experiment (-DPRG_C64_EXP=512: half the fragment reads, garbage results; profiles/r06_c64_half_reads_bound.txt)
+// runs the level-0 launch in 54.5 us instead of 73.0: the kernel is bound by its LDS operand traffic, not by the matrix pipe.
+// Here a 256-thread workgroup owns a CU with one 512-register wave per SIMD:
+//   * a wave keeps the weights of ALL 64 output channels (72 A fragments, 288 registers: hipcc places them across the VGPR and
+//     AccVGPR halves of the unified file) and owns 64 pixels (two rows of the 8 x 32 tile): every pixel fragment feeds TWO MFMAs
+//     (0.5 reads per MFMA), nobody reads a pixel twice;
+//   * no producer waves: each thread stages its 11 halo units of the NEXT tile inside the MFMA stream (one unit per three k-steps:
+//     transform + ds_write of halo s+1, then the buffer load of the same unit of halo s+2 into the freed registers), written as
+//     pinned issue slots (MFMA, side operation, sched_barrier) like conv_split512.hip;
+//   * one barrier per tile for four waves, between the MFMAs and the epilogue, as before.
+// Per accumulator the MFMA sequence is conv3x3_c64_kernel's (bias first, taps and k-steps in order), the epilogue expression too:
+// outputs are bit-identical; the GroupNorm statistics are per-wave float totals added into the fixed-point accumulators, and a
+// wave now covers 64 pixels x 64 channels instead of 128 x 32, so the statistics differ in the last bits (as between any two of the
+// bf16 kernels).  Only the accumulator form of the statistics (ConvLaunch::gn_acc) is implemented; other launches keep conv_c64.
+#include <atomic>
+#include <cstdlib>
+
+#include "conv.h"
+#include "conv_split_ablate.h"
+
+namespace prg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 c64w_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float c64w_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int c64w_u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 c64w_f16x8;
+
+namespace {
+
+template <int N>
+struct WI {
+  static constexpr int value = N;
+};
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void w_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(WI<I>());
+    w_static_for<N, I + 1>(f);
+  }
+}
+
+constexpr int TH = 8, TW = 32, HP = TW + 2, HALO = (TH + 2) * HP;   // 340 halo rows
+constexpr int ROWB = 144;                                              // padded LDS row (64 bf16 = 128 B + 16)
+constexpr int NPT = 256;                                               // every thread stages
+constexpr int RPP = NPT / 8;                                           // halo rows per pass
+constexpr int KU = (HALO + RPP - 1) / RPP;                             // 11 units per thread
+constexpr size_t AH_BYTES = (size_t)KU * RPP * ROWB;                   // 352 rows: the units past the halo end land in spare rows
+constexpr size_t C64W_LDS = 2 * AH_BYTES + 64 * sizeof(float);         // + the bias
+
+__device__ inline uint32_t c64w_pack(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+template <int CTRL>
+__device__ inline float c64w_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int XOR>
+__device__ inline float c64w_swz(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (XOR << 10) | 0x1F));
+}
+__device__ inline void c64w_tile(int t, int tiles_x, int tiles_y, int& b, int& y0, int& x0) {
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  b = t / tiles_y;
+  y0 = ty * TH;
+  x0 = tx * TW;
+}
+// one LDS-visibility point: this wave's LDS operations are done, then the workgroup barrier.  Never waits for VMEM: the halo loads
+// and the epilogue's stores stay in flight across it.
+__device__ __forceinline__ void c64w_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// PRO 0: no prologue; 3: coefficients folded here from pro_fold on an f16 input with f16 weights (the h16 format, conv.h).
+// O16: f16 output.
+template <int PRO, bool O16>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_c64w_kernel(
+    const ConvLaunch<bf16_t> L, const int tiles_x, const int tiles_y, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int fuse_stats = flags & 1;
+  const ConvDesc& d = L.d;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int total = tiles_x * tiles_y * d.B;
+  // XCD-contiguous tile runs (gridDim.x is a multiple of 8), workgroups of an XCD interleaved inside its run (conv_c64.hip)
+  const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int per = (total + 7) / 8;
+  const int lo_t = min(xcd * per, total), hi_t = min((xcd + 1) * per, total);
+  const int nx = hi_t - lo_t;
+  const int first = lo_t + widx;
+  const int nsteps = widx < nx ? (nx - widx + wpx - 1) / wpx : 0;
+  const int stride = wpx;
+  if (nsteps == 0) return;
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  // ---- weights of channels h2 * 32 + l31: 9 taps x 4 k-steps; lane half hi takes k = 16 c + 8 hi .. + 7 ----
+  c64w_bf16x8 wf[2][9][4];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16_t* const wsrc = PRO == 3 ? reinterpret_cast<const bf16_t*>(L.w_f16) : L.w;
+        const bf16_t* p = wsrc + ((size_t)(tap * d.kchunks + (c >> 1)) * d.CoutPad + h2 * 32 + l31) * 32 + (c & 1) * 16 + hi * 8;
+        wf[h2][tap][c] = *reinterpret_cast<const c64w_bf16x8*>(p);
+      }
+  float* const bias_lds = reinterpret_cast<float*>(smem + 2 * AH_BYTES);
+  if (tid < 64) bias_lds[tid] = L.bias[tid];               // visible after the prologue barrier
+  const int gn_per = fuse_stats ? (64 / L.gn_groups) >> 3 : 1;   // 8-channel chunks per group (1, 2, 4 or 8)
+  // LDS byte offset of pixel (row 2 wave + pt, column l31), tap (0,0), k-step 0: rows are HP * ROWB apart
+  const unsigned x0off = (unsigned)(((wave * 2) * HP + l31) * ROWB + hi * 16);
+  auto mma = [](const c64w_bf16x8& a, const c64w_bf16x8& b, const c64w_f32x16& c) -> c64w_f32x16 {
+    if constexpr (PRO == 3)
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c64w_f16x8, a), __builtin_bit_cast(c64w_f16x8, b), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  };
+
+  // ---- halo staging: thread = (16-byte unit `slot` of a 128-byte pixel row, halo rows row + 32 k); geometry as conv_c64.hip ----
+  const int slot = tid & 7, row = tid >> 3;
+  char* const ah = smem + row * ROWB + slot * 16;
+  const int Hl = d.Hout, Wl = d.Wout;
+  int voffk[KU];
+  unsigned m_valid = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
+#pragma unroll
+  for (int k = 0; k < KU; ++k) {
+    const int hp = k * RPP + row;
+    const int hy = hp / HP, hx = hp - hy * HP;
+    const bool valid = hp < HALO;
+    const int dy = (hy - 1) >> d.ups, dx = (hx - 1) >> d.ups;
+    voffk[k] = ((dy + 1) * d.Win + dx + 1) * 128 + slot * 16;
+    m_valid |= (valid ? 1u : 0u) << k;
+    m_top |= (valid && hy == 0 ? 1u : 0u) << k;
+    m_bot |= (valid && hy == TH + 1 ? 1u : 0u) << k;
+    m_left |= (valid && hx == 0 ? 1u : 0u) << k;
+    m_right |= (valid && hx == HP - 1 ? 1u : 0u) << k;
+  }
+  const unsigned pad_bytes = (unsigned)(d.Win + 1) * 128u;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(L.src0)) - pad_bytes, 0,
+      (int)((size_t)d.B * d.Hin * d.Win * 128 + pad_bytes), 0x00020000);
+  // ONE register set: unit k of halo s+1 is transformed and written during tile s, then the same registers take unit k of halo s+2
+  c64w_u32x4 h[KU];
+  unsigned okmask = 0, okmask_nxt = 0;
+  int soff_nxt = 0;
+  float4 ca_n[2], cb_n[2];
+  h16x2 ah2[4], bh2[4];                                    // PRO == 3: the coefficients as packed f16 channel pairs
+  longlong2 fs_n = make_longlong2(0, 0);
+  // coordinates, padding mask and (PRO) coefficient loads of halo s (clamped to the last tile: harmless reloads)
+  auto issue_head = [&](int s) {
+    int b, y0, x0;
+    c64w_tile(first + min(s, nsteps - 1) * stride, tiles_x, tiles_y, b, y0, x0);
+    okmask_nxt = m_valid & ~((y0 == 0 ? m_top : 0u) | (y0 + TH == Hl ? m_bot : 0u) | (x0 == 0 ? m_left : 0u) |
+                             (x0 + TW == Wl ? m_right : 0u));
+    soff_nxt = __builtin_amdgcn_readfirstlane((((b * d.Hin + (y0 >> d.ups)) * d.Win) + (x0 >> d.ups)) * 128);
+    if constexpr (PRO == 3) {
+      const GnFold& f = L.pro_fold;
+      fs_n = *reinterpret_cast<const longlong2*>(f.acc + ((size_t)b * f.G + (slot * 8) / f.cpg) * 2);
+      const float* pp = f.P + (size_t)b * f.pq_stride + slot * 8;
+      const float* pq = f.Q + (size_t)b * f.pq_stride + slot * 8;
+      ca_n[0] = *reinterpret_cast<const float4*>(pp);
+      ca_n[1] = *reinterpret_cast<const float4*>(pp + 4);
+      cb_n[0] = *reinterpret_cast<const float4*>(pq);
+      cb_n[1] = *reinterpret_cast<const float4*>(pq + 4);
+    }
+  };
+  auto issue_unit = [&](auto K) {
+    constexpr int k = decltype(K)::value;
+    h[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((okmask_nxt >> k) & 1u) ? voffk[k] : -1, soff_nxt, 0);
+  };
+  auto adopt = [&]() {                                     // the validity mask and coefficients of the halo about to be written
+    okmask = okmask_nxt;
+    if constexpr (PRO == 3) {                              // A = rstd P, B = Q - mean A
+      float mean, rstd;
+      gn_fold_stats_raw(fs_n.x, fs_n.y, L.pro_fold.inv_n, mean, rstd);
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const float4 a = make_float4(rstd * ca_n[h2].x, rstd * ca_n[h2].y, rstd * ca_n[h2].z, rstd * ca_n[h2].w);
+        const float4 bq = make_float4(fmaf(-mean, a.x, cb_n[h2].x), fmaf(-mean, a.y, cb_n[h2].y), fmaf(-mean, a.z, cb_n[h2].z),
+                                      fmaf(-mean, a.w, cb_n[h2].w));
+        ah2[2 * h2] = __builtin_convertvector((f32x2){a.x, a.y}, h16x2);
+        ah2[2 * h2 + 1] = __builtin_convertvector((f32x2){a.z, a.w}, h16x2);
+        bh2[2 * h2] = __builtin_convertvector((f32x2){bq.x, bq.y}, h16x2);
+        bh2[2 * h2 + 1] = __builtin_convertvector((f32x2){bq.z, bq.w}, h16x2);
+      }
+    }
+  };
+  auto write_unit = [&](int buf, auto K) {                 // unit k of the adopted halo -> LDS buffer `buf`
+    constexpr int k = decltype(K)::value;
+    c64w_u32x4 v = h[k];
+    if constexpr (PRO == 3) {
+      v = h16_silu8(v, ah2, bh2);
+      if (!((okmask >> k) & 1u)) v = c64w_u32x4{0u, 0u, 0u, 0u};   // (PRO == 0: the padding units arrived as zeros)
+    }
+    *reinterpret_cast<c64w_u32x4*>(ah + (size_t)buf * AH_BYTES + k * RPP * ROWB) = v;
+  };
+
+  // ---- prologue: halo 0 written, halo 1 in flight ----
+  issue_head(0);
+  w_static_for<KU>([&](auto K) { issue_unit(K); });
+  adopt();
+  w_static_for<KU>([&](auto K) { write_unit(0, K); });
+  issue_head(1);
+  w_static_for<KU>([&](auto K) { issue_unit(K); });
+  c64w_barrier();                                          // halo 0 and the bias are in LDS
+
+  c64w_bf16x8 fx[2][2];                                    // [k-step parity][pixel row]
+  {
+    const char* const xb0 = smem + x0off;
+    fx[0][0] = *reinterpret_cast<const c64w_bf16x8*>(xb0);
+    fx[0][1] = *reinterpret_cast<const c64w_bf16x8*>(xb0 + HP * ROWB);
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
+    const int nbuf = (s + 1) & 1;
+    adopt();                                               // halo s+1: loaded during tile s-1 (prologue), written during this tile
+    issue_head(s + 2);
+    // the accumulators START at the bias (conv_c64.hip, round 5)
+    c64w_f32x16 acc[2][2];                                 // [pixel row][channel half]
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const float* const biasp = bias_lds + h2 * 32 + 4 * hi;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) { acc[pt][h2][4 * q] = b4.x; acc[pt][h2][4 * q + 1] = b4.y; acc[pt][h2][4 * q + 2] = b4.z; acc[pt][h2][4 * q + 3] = b4.w; }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 36 k-steps x 4 pinned slots: (MFMA row 0 / half 0, next fragment of row 0) (row 0 / half 1, next fragment of row 1)
+    // (row 1 / half 0, staging: transform + write unit ks / 3 of halo s+1 at ks % 3 == 0) (row 1 / half 1, staging: reload that unit
+    // for halo s+2 at ks % 3 == 1)
+    w_static_for<36>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value, tap = ks >> 2, c = ks & 3, cur = ks & 1, nxt = cur ^ 1;
+      constexpr int nks = ks + 1, ntap = nks >> 2, nc = nks & 3;
+      constexpr int toff = ((ntap / 3) * HP + (ntap % 3)) * ROWB + nc * 32;
+      acc[0][0] = mma(wf[0][tap][c], fx[cur][0], acc[0][0]);
+      if constexpr (nks < 36) fx[nxt][0] = *reinterpret_cast<const c64w_bf16x8*>(xb + toff);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][1] = mma(wf[1][tap][c], fx[cur][0], acc[0][1]);
+      if constexpr (nks < 36) fx[nxt][1] = *reinterpret_cast<const c64w_bf16x8*>(xb + HP * ROWB + toff);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][0] = mma(wf[0][tap][c], fx[cur][1], acc[1][0]);
+      if constexpr (ks % 3 == 0 && ks / 3 < KU) write_unit(nbuf, WI<(ks / 3 < KU ? ks / 3 : 0)>());
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][1] = mma(wf[1][tap][c], fx[cur][1], acc[1][1]);
+      if constexpr (ks % 3 == 1 && ks / 3 < KU) issue_unit(WI<(ks / 3 < KU ? ks / 3 : 0)>());
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    int tb, ty0, tx0;
+    c64w_tile(first + s * stride, tiles_x, tiles_y, tb, ty0, tx0);
+    c64w_barrier();                                        // halo s+1 is written; nobody reads buffer s & 1 any more
+    if (s + 1 < nsteps) {                                  // the next tile's first fragments, behind the epilogue's arithmetic
+      const char* const xn = smem + (size_t)nbuf * AH_BYTES + x0off;
+      fx[0][0] = *reinterpret_cast<const c64w_bf16x8*>(xn);
+      fx[0][1] = *reinterpret_cast<const c64w_bf16x8*>(xn + HP * ROWB);
+    }
+    // ---- epilogue (conv3x3_c64_kernel's, per channel half): lane holds pixel (row 2 wave + pt, col l31), channels
+    //      h2 * 32 + 8 q + 4 hi + {0..3} ----
+    const size_t orow = (size_t)d.Wout * 128;              // output bytes per image row
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      float V[8];                                          // [sum | sumsq][q]
+#pragma unroll
+      for (int q = 0; q < 8; ++q) V[q] = 0.0f;
+      char* const obase = reinterpret_cast<char*>(L.out) +
+                          ((((size_t)tb * d.Hout + ty0 + wave * 2) * d.Wout + tx0 + l31) * 64 + h2 * 32 + 8 * hi) * 2;
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[pt][h2][4 * q + r];
+            V[q] += v[r];
+            V[4 + q] = fmaf(v[r], v[r], V[4 + q]);
+          }
+          pk[2 * q] = O16 ? h16_pack(v[0], v[1]) : c64w_pack(v[0], v[1]);
+          pk[2 * q + 1] = O16 ? h16_pack(v[2], v[3]) : c64w_pack(v[2], v[3]);
+        }
+        // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: after the swap lane half 0 has all 8
+        // channels of chunk 2m, half 1 those of chunk 2m+1: one 16-byte store each
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * m], pk[4 * m + 2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * m + 1], pk[4 * m + 3], false, false);
+          const c64w_u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+          *reinterpret_cast<c64w_u32x4*>(obase + pt * orow + m * 32) = o;
+        }
+      }
+      if (fuse_stats) {
+        // 8 full-wave sums with a halving butterfly (conv_c64.hip): fixed order, deterministic
+        const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+        float A4[4], B2[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A4[j] = (b0 ? V[4 + j] : V[j]) + c64w_dpp<0xB1>(b0 ? V[j] : V[4 + j]);        // lane ^ 1
+#pragma unroll
+        for (int j = 0; j < 2; ++j) B2[j] = (b1 ? A4[2 + j] : A4[j]) + c64w_dpp<0x4E>(b1 ? A4[j] : A4[2 + j]);    // lane ^ 2
+        float D = (b2 ? B2[1] : B2[0]) + c64w_swz<4>(b2 ? B2[0] : B2[1]);
+        D += c64w_swz<8>(D);
+        D += c64w_swz<16>(D);
+        D += __shfl_xor(D, 32, 64);
+        // lane (< 8) holds the wave total of value i = 4 b0 + 2 b1 + b2 = [sq][q]: 8-channel chunk q of this channel half.
+        // Fold the chunks of one group (per = cpg / 8 <= 4 inside a half; 8 = both halves: each half adds its own total).
+        const int per = gn_per > 4 ? 4 : gn_per;
+        if (per >= 2) D += c64w_swz<4>(D);                 // q ^ 1  (lane bit 2)
+        if (per >= 4) D += c64w_dpp<0x4E>(D);              // q ^ 2  (lane bit 1)
+        const int i = (lane & 1) * 4 + (lane & 2) + ((lane >> 2) & 1);
+        const int q = i & 3;
+        if (lane < 8 && (q & (per - 1)) == 0) {
+          const int grp = (h2 * 4 + q) / gn_per;
+          int which = i >> 2;
+          asm volatile("" : "+v"(which));
+          gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, which, D);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Returns 1 when it launched, 0 when the shape / mode is not covered (the caller goes on to conv3x3_c64_kernel), negative on error.
+// PRG_CONV_C64W: 1 (default) on, 0 off.
+int try_launch_conv3x3_c64w(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
+  static const int enabled = [] { const char* e = std::getenv("PRG_CONV_C64W"); return e ? std::atoi(e) : 1; }();
+  if (!enabled) return 0;
+  const ConvDesc& d = L.d;
+  if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;
+  if (d.C0 != 64 || d.C1 != 0 || d.Cout != 64 || d.CoutPad != 64 || d.kchunks != 2) return 0;
+  if (L.residual || !L.bias || d.ups) return 0;
+  if (d.Wout % TW || d.Hout % TH) return 0;
+  if ((size_t)d.B * d.Hin * d.Win * 128 + 4096 >= ((size_t)1 << 31)) return 0;
+  const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH;
+  const int total = tiles_x * tiles_y * d.B;
+  const int num_cus = device_cu_count();
+  if (num_cus <= 0 || total < 2 * num_cus) return 0;         // (at least two tiles per CU: the staging pipeline needs a next tile)
+  const int grid = num_cus & ~7;
+  const int cpg = L.gn_groups > 0 ? 64 / L.gn_groups : 0;
+  const int split_n = cpg > 32 ? 2 : 1;
+  const int fuse = L.gn_partials != nullptr && cpg % 8 == 0 && cpg <= 64 && (cpg & (cpg - 1)) == 0 &&
+                   tiles_x * tiles_y * 2 * split_n <= kGnMaxSplit;
+  if (L.gn_partials && !(fuse && L.gn_acc)) return 0;        // statistics: the fixed-point accumulator form only
+  const GnFold& pf = L.pro_fold;
+  const bool fold_ok = pf.acc && pf.P && pf.Q && pf.G * pf.cpg == 64 && pf.cpg % 8 == 0;
+  if (pf.acc && !fold_ok) return 0;
+  if (L.pro_a && !fold_ok) return 0;                         // coefficient-table prologues stay on conv3x3_c64_kernel<1>
+  if (fold_ok && !(L.in_f16 && L.w_f16)) return 0;           // the folded prologue: in its h16 form only
+  if (L.in_f16 && !fold_ok) return 0;
+  const int pro = L.in_f16 ? 3 : 0;
+  if (L.out_f16 && pro != 0) return 0;
+  static const int pro3_on = [] { const char* e = std::getenv("PRG_CONV_C64W_PRO"); return e ? std::atoi(e) : 1; }();
+  if (pro == 3 && !pro3_on) return 0;
+  const int variant = L.out_f16 ? 2 : (pro == 3 ? 1 : 0);
+  const void* const fns[3] = {reinterpret_cast<const void*>(&conv3x3_c64w_kernel<0, false>), reinterpret_cast<const void*>(&conv3x3_c64w_kernel<3, false>),
+                              reinterpret_cast<const void*>(&conv3x3_c64w_kernel<0, true>)};
+  static DeviceOnce attr_done[3];
+  if (!attr_done[variant].done()) {
+    hipError_t e = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64W_LDS);
+    if (e != hipSuccess) return fail(PRG_E_HIP, std::string("hipFuncSetAttribute(c64w conv): ") + hipGetErrorString(e));
+    attr_done[variant].mark();
+  }
+  if (gn_nsplit_out) *gn_nsplit_out = fuse ? tiles_x * tiles_y * 2 * split_n : 0;   // (what conv3x3_c64_kernel reports: the caller's "statistics taken" flag)
+  if (coef_done) *coef_done = 0;
+  if (acc_done) *acc_done = fuse ? 1 : 0;
+  if (L.probe) return 1;
+  const int flags = fuse ? 1 : 0;
+  if (variant == 2) conv3x3_c64w_kernel<0, true><<<dim3(grid), 256, C64W_LDS, s>>>(L, tiles_x, tiles_y, flags);
+  else if (variant == 1) conv3x3_c64w_kernel<3, false><<<dim3(grid), 256, C64W_LDS, s>>>(L, tiles_x, tiles_y, flags);
+  else conv3x3_c64w_kernel<0, false><<<dim3(grid), 256, C64W_LDS, s>>>(L, tiles_x, tiles_y, flags);
+  PRG_LAUNCH_CHECK();
+  return 1;
+}
+
+}  // namespace prg

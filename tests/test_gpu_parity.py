@@ -1020,6 +1020,7 @@ def test_upsample_conv_subpixel_form(hip, B, Cin, Cout, H, Wd):
 
 # (B, Cin, C, H, W): conv1 / conv2 kernels of the pair
 PAIR_SHAPES = [(4, 64, 64, 64, 64),      # c64 -> c64 (down levels 0-1)
+               (8, 64, 64, 128, 128),    # ... at two tiles per CU: the one-wave-per-SIMD c64w kernel on both sides (round 6)
                (4, 128, 64, 64, 64),     # wave-specialised 8x32x64 (Cin = 128) -> c64 (up level 3, final block)
                (64, 128, 128, 32, 32),   # 256-pixel kernel on both sides, 8x32 tiles, one channel tile (level 2)
                (128, 256, 256, 16, 16)]  # ... 16x16 tiles, two channel tiles (256 workgroups): every input pixel transformed twice
@@ -1060,6 +1061,57 @@ def test_block_pair_h16_against_float64(hip, B, Cin, C, H, Wd):
           f"(|ref| max {scale:.2f})")
     assert errs[1][1] <= errs[0][1], errs                       # the f16 form is the more accurate one on average ...
     assert errs[1][0] <= 2.0 ** -7 * scale and errs[0][0] <= 2.0 ** -6 * scale, (errs, scale)   # ... both inside their rounding budgets
+
+
+def test_c64w_kernel_matches_the_c64_kernel(tmp_path):
+    """Round 6: conv3x3_c64w_kernel (one 512-register wave per SIMD holding the weights of all 64 output channels: 0.5 fragment reads
+    per MFMA) runs conv3x3_c64_kernel's MFMA sequence per accumulator — the plain 64 -> 64 convolution must give the SAME BITS with
+    the kernel on (default) and off (PRG_CONV_C64W=0) at a shape that selects it (two 8 x 32 tiles per CU), on images with every
+    kind of border tile; the ResnetBlock pair (f16 tensor in between, statistics in the epilogue, folded prologue) agrees to the
+    last-bit differences of the GroupNorm statistics (a wave totals 64 pixels x 64 channels instead of 128 x 32)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from pointreggpt_amd import _lib
+lib = _lib.load()
+out = {}
+g = torch.Generator().manual_seed(11)
+for (B, H, Wd) in [(8, 128, 128), (16, 64, 128)]:
+    x = torch.randn((B, 64, H, Wd), generator=g).cuda()
+    w = np.ascontiguousarray((torch.randn((64, 64, 3, 3), generator=g) / 24.0).numpy())
+    bias = np.ascontiguousarray(torch.randn((64,), generator=g).numpy())
+    o = torch.empty((B, 64, H, Wd), dtype=torch.float32, device="cuda")
+    _lib.check(lib.prg_debug_conv3x3(_lib.ptr(x), w.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), _lib.ptr(o), B, 64, 64, H, Wd,
+                                     _lib.PRG_BF16, _lib.stream_ptr()))
+    out["conv_%%d_%%d" %% (B, H)] = o.cpu().numpy()
+B, H = 8, 128
+x = torch.randn((B, 64, H, H), generator=g).cuda()
+w1 = (torch.randn((64, 64, 3, 3), generator=g) / 24.0); w2 = (torch.randn((64, 64, 3, 3), generator=g) / 24.0)
+b1, b2 = torch.randn((64,), generator=g), torch.randn((64,), generator=g)
+gamma, beta = 1.0 + 0.3 * torch.randn((64,), generator=g), 0.3 * torch.randn((64,), generator=g)
+arrs = [np.ascontiguousarray(t.numpy(), dtype=np.float32) for t in (w1, b1, gamma, beta, w2, b2)]
+o = torch.empty((B, 64, H, H), dtype=torch.float32, device="cuda")
+_lib.check(lib.prg_debug_block_pair(_lib.ptr(x), *[a.ctypes.data_as(C.c_void_p) for a in arrs], _lib.ptr(o), B, 64, 64, H, H, 8, 1, _lib.stream_ptr()))
+out["pair"] = o.cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % root
+    res = {}
+    for on in ("0", "1"):
+        path = tmp_path / f"c64w_{on}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(path)], capture_output=True, text=True, timeout=900, env=dict(os.environ, PRG_CONV_C64W=on))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[on] = np.load(path)
+    for k in res["0"].files:
+        assert np.isfinite(res["1"][k]).all(), k
+        if k.startswith("conv"):
+            assert np.array_equal(res["0"][k], res["1"][k]), (k, float(np.abs(res["0"][k] - res["1"][k]).max()))
+        else:
+            d = np.abs(res["0"][k].astype(np.float64) - res["1"][k])
+            print(f"block pair through c64w vs c64: max |diff| {d.max():.3e} on |y| <= {np.abs(res['0'][k]).max():.2f}, differing elements {float((d > 0).mean()):.4f}")
+            assert d.max() <= 2.0 ** -7 * np.abs(res["0"][k]).max() and float((d > 0).mean()) < 0.05
 
 
 def test_block_pair_h16_overflow_is_visible(hip):
