@@ -148,9 +148,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(L.src0)) - pad_bytes, 0,
       (int)((size_t)d.B * d.Hin * d.Win * 128 + pad_bytes), 0x00020000);
-  // ONE register set: unit k of halo s+1 is transformed and written during tile s, then the same registers take unit k of halo s+2
-  c64w_u32x4 h[KU];
-  unsigned okmask = 0, okmask_nxt = 0;
+  // NSET register sets, halo x in set x % NSET: unit k of halo s+1 is transformed and written during tile s, then the same registers
+  // take unit k of halo s+1+NSET.  Two sets (the plain forms) keep TWO halos = 90 KB per CU in flight like conv3x3_c64_kernel's
+  // producers — with one, a CU's 45 KB could not cover the ~4500 cycles a halo takes at the ~10 B/cycle/CU HBM rate, and here a late
+  // load stalls the wave's own MFMA stream; the h16 prologue form has no registers for a second set.
+  constexpr int NSET = PRO == 0 ? 2 : 1;
+  c64w_u32x4 h[NSET][KU];
+  unsigned okmask = 0, okmask_nxt = 0, okq[NSET];
   int soff_nxt = 0;
   float4 ca_n[2], cb_n[2];
   h16x2 ah2[4], bh2[4];                                    // PRO == 3: the coefficients as packed f16 channel pairs
@@ -173,12 +177,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       cb_n[1] = *reinterpret_cast<const float4*>(pq + 4);
     }
   };
-  auto issue_unit = [&](auto K) {
-    constexpr int k = decltype(K)::value;
-    h[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((okmask_nxt >> k) & 1u) ? voffk[k] : -1, soff_nxt, 0);
+  auto issue_unit = [&](auto SET, auto K) {
+    constexpr int k = decltype(K)::value, st = decltype(SET)::value;
+    h[st][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((okmask_nxt >> k) & 1u) ? voffk[k] : -1, soff_nxt, 0);
   };
   auto adopt = [&]() {                                     // the validity mask and coefficients of the halo about to be written
-    okmask = okmask_nxt;
+    okmask = okq[0];
+    if constexpr (NSET == 2) okq[0] = okq[1];
     if constexpr (PRO == 3) {                              // A = rstd P, B = Q - mean A
       float mean, rstd;
       gn_fold_stats_raw(fs_n.x, fs_n.y, L.pro_fold.inv_n, mean, rstd);
@@ -195,9 +200,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       }
     }
   };
-  auto write_unit = [&](int buf, auto K) {                 // unit k of the adopted halo -> LDS buffer `buf`
-    constexpr int k = decltype(K)::value;
-    c64w_u32x4 v = h[k];
+  auto write_unit = [&](int buf, auto SET, auto K) {       // unit k of the adopted halo -> LDS buffer `buf`
+    constexpr int k = decltype(K)::value, st = decltype(SET)::value;
+    c64w_u32x4 v = h[st][k];
     if constexpr (PRO == 3) {
       v = h16_silu8(v, ah2, bh2);
       if (!((okmask >> k) & 1u)) v = c64w_u32x4{0u, 0u, 0u, 0u};   // (PRO == 0: the padding units arrived as zeros)
@@ -205,13 +210,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     *reinterpret_cast<c64w_u32x4*>(ah + (size_t)buf * AH_BYTES + k * RPP * ROWB) = v;
   };
 
-  // ---- prologue: halo 0 written, halo 1 in flight ----
+  // ---- prologue: halo 0 written, halos 1 .. NSET in flight ----
   issue_head(0);
-  w_static_for<KU>([&](auto K) { issue_unit(K); });
+  w_static_for<KU>([&](auto K) { issue_unit(WI<0>(), K); });
+  okq[0] = okmask_nxt;
   adopt();
-  w_static_for<KU>([&](auto K) { write_unit(0, K); });
+  w_static_for<KU>([&](auto K) { write_unit(0, WI<0>(), K); });
   issue_head(1);
-  w_static_for<KU>([&](auto K) { issue_unit(K); });
+  w_static_for<KU>([&](auto K) { issue_unit(WI<(NSET == 2 ? 1 : 0)>(), K); });
+  okq[0] = okmask_nxt;
+  if constexpr (NSET == 2) {
+    issue_head(2);
+    w_static_for<KU>([&](auto K) { issue_unit(WI<0>(), K); });
+    okq[1] = okmask_nxt;
+  }
   c64w_barrier();                                          // halo 0 and the bias are in LDS
 
   c64w_bf16x8 fx[2][2];                                    // [k-step parity][pixel row]
@@ -220,11 +232,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     fx[0][0] = *reinterpret_cast<const c64w_bf16x8*>(xb0);
     fx[0][1] = *reinterpret_cast<const c64w_bf16x8*>(xb0 + HP * ROWB);
   }
-  for (int s = 0; s < nsteps; ++s) {
+  auto tile = [&](int s, auto SETW) {                      // halo s+1 lives in register set SETW
     const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
     const int nbuf = (s + 1) & 1;
-    adopt();                                               // halo s+1: loaded during tile s-1 (prologue), written during this tile
-    issue_head(s + 2);
+    adopt();                                               // halo s+1: loaded NSET tiles ago, written during this tile
+    issue_head(s + 1 + NSET);
     // the accumulators START at the bias (conv_c64.hip, round 5)
     c64w_f32x16 acc[2][2];                                 // [pixel row][channel half]
 #pragma unroll
@@ -252,10 +264,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       if constexpr (nks < 36) fx[nxt][1] = *reinterpret_cast<const c64w_bf16x8*>(xb + HP * ROWB + toff);
       __builtin_amdgcn_sched_barrier(0);
       acc[1][0] = mma(wf[0][tap][c], fx[cur][1], acc[1][0]);
-      if constexpr (ks % 3 == 0 && ks / 3 < KU) write_unit(nbuf, WI<(ks / 3 < KU ? ks / 3 : 0)>());
+      if constexpr (ks % 3 == 0 && ks / 3 < KU) write_unit(nbuf, SETW, WI<(ks / 3 < KU ? ks / 3 : 0)>());
       __builtin_amdgcn_sched_barrier(0);
       acc[1][1] = mma(wf[1][tap][c], fx[cur][1], acc[1][1]);
-      if constexpr (ks % 3 == 1 && ks / 3 < KU) issue_unit(WI<(ks / 3 < KU ? ks / 3 : 0)>());
+      if constexpr (ks % 3 == 1 && ks / 3 < KU) issue_unit(SETW, WI<(ks / 3 < KU ? ks / 3 : 0)>());
       __builtin_amdgcn_sched_barrier(0);
     });
     int tb, ty0, tx0;
@@ -328,6 +340,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
       }
     }
+    if constexpr (NSET == 2) okq[1] = okmask_nxt; else okq[0] = okmask_nxt;
+  };
+  if constexpr (NSET == 2) {
+    for (int s = 0; s < nsteps; s += 2) {
+      tile(s, WI<1>());
+      if (s + 1 < nsteps) tile(s + 1, WI<0>());
+    }
+  } else {
+    for (int s = 0; s < nsteps; ++s) tile(s, WI<0>());
   }
 }
 

@@ -1069,6 +1069,7 @@ def test_c64w_kernel_matches_the_c64_kernel(tmp_path):
     the kernel on (default) and off (PRG_CONV_C64W=0) at a shape that selects it (two 8 x 32 tiles per CU), on images with every
     kind of border tile; the ResnetBlock pair (f16 tensor in between, statistics in the epilogue, folded prologue) agrees to the
     last-bit differences of the GroupNorm statistics (a wave totals 64 pixels x 64 channels instead of 128 x 32)."""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
