@@ -226,12 +226,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   }
   c64w_barrier();                                          // halo 0 and the bias are in LDS
 
-  c64w_bf16x8 fx[2][2];                                    // [k-step parity][pixel row]
-  {
-    const char* const xb0 = smem + x0off;
-    fx[0][0] = *reinterpret_cast<const c64w_bf16x8*>(xb0);
-    fx[0][1] = *reinterpret_cast<const c64w_bf16x8*>(xb0 + HP * ROWB);
-  }
+  // pixel fragments: a ring of FD + 1 k-steps, read FD k-steps (4 FD MFMAs = 128 FD cycles) ahead of their use — at one k-step the
+  // LDS latency under load (> 128 cycles beside the staging writes) stalled every k-step's first MFMA
+  constexpr int FD = 2, FR = FD + 1;
+  c64w_bf16x8 fx[FR][2];                                   // [k-step % FR][pixel row]
+  auto frag_off = [](int ks) { const int tap = ks >> 2, c = ks & 3; return ((tap / 3) * HP + (tap % 3)) * ROWB + c * 32; };
+  auto first_frags = [&](const char* xb0) {
+#pragma unroll
+    for (int j = 0; j < FD; ++j) {
+      fx[j][0] = *reinterpret_cast<const c64w_bf16x8*>(xb0 + frag_off(j));
+      fx[j][1] = *reinterpret_cast<const c64w_bf16x8*>(xb0 + HP * ROWB + frag_off(j));
+    }
+  };
+  first_frags(smem + x0off);
   auto tile = [&](int s, auto SETW) {                      // halo s+1 lives in register set SETW
     const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
     const int nbuf = (s + 1) & 1;
@@ -254,8 +261,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // (row 1 / half 0, staging: transform + write unit ks / 3 of halo s+1 at ks % 3 == 0) (row 1 / half 1, staging: reload that unit
     // for halo s+2 at ks % 3 == 1)
     w_static_for<36>([&](auto KS) {
-      constexpr int ks = decltype(KS)::value, tap = ks >> 2, c = ks & 3, cur = ks & 1, nxt = cur ^ 1;
-      constexpr int nks = ks + 1, ntap = nks >> 2, nc = nks & 3;
+      constexpr int ks = decltype(KS)::value, tap = ks >> 2, c = ks & 3, cur = ks % FR, nks = ks + FD, nxt = nks % FR;
+      constexpr int ntap = (nks < 36 ? nks : 0) >> 2, nc = nks & 3;
       constexpr int toff = ((ntap / 3) * HP + (ntap % 3)) * ROWB + nc * 32;
       acc[0][0] = mma(wf[0][tap][c], fx[cur][0], acc[0][0]);
       if constexpr (nks < 36) fx[nxt][0] = *reinterpret_cast<const c64w_bf16x8*>(xb + toff);
@@ -273,11 +280,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     int tb, ty0, tx0;
     c64w_tile(first + s * stride, tiles_x, tiles_y, tb, ty0, tx0);
     c64w_barrier();                                        // halo s+1 is written; nobody reads buffer s & 1 any more
-    if (s + 1 < nsteps) {                                  // the next tile's first fragments, behind the epilogue's arithmetic
-      const char* const xn = smem + (size_t)nbuf * AH_BYTES + x0off;
-      fx[0][0] = *reinterpret_cast<const c64w_bf16x8*>(xn);
-      fx[0][1] = *reinterpret_cast<const c64w_bf16x8*>(xn + HP * ROWB);
-    }
+    if (s + 1 < nsteps) first_frags(smem + (size_t)nbuf * AH_BYTES + x0off);   // the next tile's first fragments, behind the epilogue
     // ---- epilogue (conv3x3_c64_kernel's, per channel half): lane holds pixel (row 2 wave + pt, col l31), channels
     //      h2 * 32 + 8 q + 4 hi + {0..3} ----
     const size_t orow = (size_t)d.Wout * 128;              // output bytes per image row
