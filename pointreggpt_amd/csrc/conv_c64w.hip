@@ -31,6 +31,12 @@ typedef __attribute__((ext_vector_type(8))) _Float16 c64w_f16x8;
 
 namespace {
 
+// Timing experiments only (results become garbage; tools/gpu_c64w_exp.sh): -DPRG_C64W_EXP=1 no MFMAs, 2 no staging (halo loads /
+// transforms / LDS writes inside the loop), 4 no epilogue (stores, statistics), 8 no fragment reads
+#ifndef PRG_C64W_EXP
+#define PRG_C64W_EXP 0
+#endif
+
 template <int N>
 struct WI {
   static constexpr int value = N;
@@ -119,6 +125,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // LDS byte offset of pixel (row 2 wave + pt, column l31), tap (0,0), k-step 0: rows are HP * ROWB apart
   const unsigned x0off = (unsigned)(((wave * 2) * HP + l31) * ROWB + hi * 16);
   auto mma = [](const c64w_bf16x8& a, const c64w_bf16x8& b, const c64w_f32x16& c) -> c64w_f32x16 {
+    if constexpr ((PRG_C64W_EXP & 1) != 0) {
+      asm volatile("" ::"v"(a), "v"(b));
+      return c;
+    }
     if constexpr (PRO == 3)
       return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c64w_f16x8, a), __builtin_bit_cast(c64w_f16x8, b), c, 0, 0, 0);
     else
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // take unit k of halo s+1+NSET.  Two sets (the plain forms) keep TWO halos = 90 KB per CU in flight like conv3x3_c64_kernel's
   // producers — with one, a CU's 45 KB could not cover the ~4500 cycles a halo takes at the ~10 B/cycle/CU HBM rate, and here a late
   // load stalls the wave's own MFMA stream; the h16 prologue form has no registers for a second set.
-  constexpr int NSET = PRO == 0 ? 2 : 1;
+  constexpr int NSET = 1;   // (two sets were measured equal on the first form of the kernel: profiles/r06_c64w_ablations.txt)
   c64w_u32x4 h[NSET][KU];
   unsigned okmask = 0, okmask_nxt = 0, okq[NSET];
   int soff_nxt = 0;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   h16x2 ah2[4], bh2[4];                                    // PRO == 3: the coefficients as packed f16 channel pairs
   longlong2 fs_n = make_longlong2(0, 0);
   // coordinates, padding mask and (PRO) coefficient loads of halo s (clamped to the last tile: harmless reloads)
-  auto issue_head = [&](int s) {
+  auto issue_head = [&](int s) __attribute__((always_inline)) {
     int b, y0, x0;
     c64w_tile(first + min(s, nsteps - 1) * stride, tiles_x, tiles_y, b, y0, x0);
     okmask_nxt = m_valid & ~((y0 == 0 ? m_top : 0u) | (y0 + TH == Hl ? m_bot : 0u) | (x0 == 0 ? m_left : 0u) |
@@ -177,11 +187,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       cb_n[1] = *reinterpret_cast<const float4*>(pq + 4);
     }
   };
-  auto issue_unit = [&](auto SET, auto K) {
+  auto issue_unit = [&](auto SET, auto K) __attribute__((always_inline)) {
     constexpr int k = decltype(K)::value, st = decltype(SET)::value;
     h[st][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((okmask_nxt >> k) & 1u) ? voffk[k] : -1, soff_nxt, 0);
   };
-  auto adopt = [&]() {                                     // the validity mask and coefficients of the halo about to be written
+  auto adopt = [&]() __attribute__((always_inline)) {                                     // the validity mask and coefficients of the halo about to be written
     okmask = okq[0];
     if constexpr (NSET == 2) okq[0] = okq[1];
     if constexpr (PRO == 3) {                              // A = rstd P, B = Q - mean A
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       }
     }
   };
-  auto write_unit = [&](int buf, auto SET, auto K) {       // unit k of the adopted halo -> LDS buffer `buf`
+  auto write_unit = [&](int buf, auto SET, auto K) __attribute__((always_inline)) {       // unit k of the adopted halo -> LDS buffer `buf`
     constexpr int k = decltype(K)::value, st = decltype(SET)::value;
     c64w_u32x4 v = h[st][k];
     if constexpr (PRO == 3) {
@@ -226,133 +236,163 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   }
   c64w_barrier();                                          // halo 0 and the bias are in LDS
 
-  // pixel fragments: a ring of FD + 1 k-steps, read FD k-steps (4 FD MFMAs = 128 FD cycles) ahead of their use — at one k-step the
-  // LDS latency under load (> 128 cycles beside the staging writes) stalled every k-step's first MFMA
-  constexpr int FD = 2, FR = FD + 1;
-  c64w_bf16x8 fx[FR][2];                                   // [k-step % FR][pixel row]
+  // ---- the tile pipeline ----------------------------------------------------------------------------------------------------
+  // A tile is TWO phases of 36 k-steps, one per pixel row of this wave (72 MFMAs each: channel halves alternate, so back-to-back
+  // MFMAs never share an accumulator).  Every k-step is two pinned issue slots:
+  //     MFMA (row, half 0) + the fragment read FD k-steps ahead        MFMA (row, half 1) + one SIDE piece
+  // and the side pieces of a phase are the epilogue of the row the PREVIOUS phase finished (bias rode in with the accumulators:
+  // pack, statistics, lane-half swap, 16-byte stores — 12 pieces; after row 1 the statistics' butterfly and the accumulator atomics
+  // — 6 pieces) and this thread's halo units of the next tile (transform + ds_write, then the reload of the same registers).  Measured
+  // on the first form of this kernel (whole-tile MFMA phase, then a serial epilogue; -DPRG_C64W_EXP ablations,
+  // profiles/r06_c64w_ablations.txt): MFMAs alone 57 us, everything but the MFMAs 57 us, serial sum 76.7 us at the level-0 launch
+  // (conv3x3_c64_kernel: 73.0; its MFMA phase and its epilogue add up the same way).
+  constexpr int FD = 2, FR = FD + 1;                       // fragment ring: read FD k-steps (2 FD MFMAs) ahead
+  c64w_bf16x8 fx[FR];
   auto frag_off = [](int ks) { const int tap = ks >> 2, c = ks & 3; return ((tap / 3) * HP + (tap % 3)) * ROWB + c * 32; };
-  auto first_frags = [&](const char* xb0) {
-#pragma unroll
-    for (int j = 0; j < FD; ++j) {
-      fx[j][0] = *reinterpret_cast<const c64w_bf16x8*>(xb0 + frag_off(j));
-      fx[j][1] = *reinterpret_cast<const c64w_bf16x8*>(xb0 + HP * ROWB + frag_off(j));
-    }
-  };
-  first_frags(smem + x0off);
-  auto tile = [&](int s, auto SETW) {                      // halo s+1 lives in register set SETW
-    const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off;
-    const int nbuf = (s + 1) & 1;
-    adopt();                                               // halo s+1: loaded NSET tiles ago, written during this tile
-    issue_head(s + 1 + NSET);
-    // the accumulators START at the bias (conv_c64.hip, round 5)
-    c64w_f32x16 acc[2][2];                                 // [pixel row][channel half]
+  c64w_f32x16 acc[2][2];                                   // [pixel row][channel half]; row r is busy from its phase to the end of its epilogue
+  float V[2][8];                                           // [channel half][sum | sumsq][q]: statistics of the tile being stored
+  uint32_t pk[8];
+  float A4[4], B2[2], Dred = 0.0f;
+  char* obase_e = nullptr;                                 // output address / image of the tile whose rows are being stored
+  int tb_e = 0;
+  const size_t orow = (size_t)d.Wout * 128;                // output bytes per image row
+  auto acc_init = [&](auto PT) __attribute__((always_inline)) {                           // the accumulators START at the bias (conv_c64.hip, round 5)
+    constexpr int pt = decltype(PT)::value;
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const float* const biasp = bias_lds + h2 * 32 + 4 * hi;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 b4 = *reinterpret_cast<const float4*>(biasp + 8 * q);
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) { acc[pt][h2][4 * q] = b4.x; acc[pt][h2][4 * q + 1] = b4.y; acc[pt][h2][4 * q + 2] = b4.z; acc[pt][h2][4 * q + 3] = b4.w; }
+        acc[pt][h2][4 * q] = b4.x; acc[pt][h2][4 * q + 1] = b4.y; acc[pt][h2][4 * q + 2] = b4.z; acc[pt][h2][4 * q + 3] = b4.w;
       }
     }
+  };
+  // epilogue piece P (0 .. 11) of pixel row PT: per channel half four (pack + statistics) pieces and two (swap + store) pieces.
+  // Lane holds pixel (row 2 wave + pt, col l31), channels h2 * 32 + 8 q + 4 hi + {0..3} (conv3x3_c64_kernel's epilogue).
+  auto epi_piece = [&](auto PT, auto P) __attribute__((always_inline)) {
+    constexpr int pt = decltype(PT)::value, p = decltype(P)::value, h2 = p / 6, r6 = p % 6;
+    if constexpr ((PRG_C64W_EXP & 4) != 0) {
+      if constexpr (p == 0) asm volatile("" ::"v"(acc[pt][0]), "v"(acc[pt][1]));
+      return;
+    }
+    if constexpr (r6 < 4) {
+      constexpr int q = r6;
+      if constexpr (pt == 0 && q == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) V[h2][j] = 0.0f;
+      }
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[pt][h2][4 * q + r];
+        V[h2][q] += v[r];
+        V[h2][4 + q] = fmaf(v[r], v[r], V[h2][4 + q]);
+      }
+      pk[2 * q] = O16 ? h16_pack(v[0], v[1]) : c64w_pack(v[0], v[1]);
+      pk[2 * q + 1] = O16 ? h16_pack(v[2], v[3]) : c64w_pack(v[2], v[3]);
+    } else {
+      // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: after the swap lane half 0 has all 8
+      // channels of chunk 2m, half 1 those of chunk 2m+1: one 16-byte store each
+      constexpr int m = r6 - 4;
+      const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * m], pk[4 * m + 2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * m + 1], pk[4 * m + 3], false, false);
+      const c64w_u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+      *reinterpret_cast<c64w_u32x4*>(obase_e + h2 * 64 + pt * orow + m * 32) = o;
+    }
+  };
+  // statistics piece P (0 .. 5) of the stored tile: per channel half the halving butterfly of conv3x3_c64_kernel in three pieces
+  // (fixed order, deterministic), then one no-return 64-bit integer atomic per wave total
+  auto stat_piece = [&](auto P) __attribute__((always_inline)) {
+    constexpr int p = decltype(P)::value, h2 = p / 3, r3 = p % 3;
+    if constexpr ((PRG_C64W_EXP & 4) != 0) return;
+    if (!fuse_stats) return;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    if constexpr (r3 == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) A4[j] = (b0 ? V[h2][4 + j] : V[h2][j]) + c64w_dpp<0xB1>(b0 ? V[h2][j] : V[h2][4 + j]);        // lane ^ 1
+#pragma unroll
+      for (int j = 0; j < 2; ++j) B2[j] = (b1 ? A4[2 + j] : A4[j]) + c64w_dpp<0x4E>(b1 ? A4[j] : A4[2 + j]);                    // lane ^ 2
+    } else if constexpr (r3 == 1) {
+      float D = (b2 ? B2[1] : B2[0]) + c64w_swz<4>(b2 ? B2[0] : B2[1]);
+      D += c64w_swz<8>(D);
+      D += c64w_swz<16>(D);
+      D += __shfl_xor(D, 32, 64);
+      Dred = D;
+    } else {
+      // lane (< 8) holds the wave total of value i = 4 b0 + 2 b1 + b2 = [sq][q]: 8-channel chunk q of this channel half.
+      // Fold the chunks of one group (per = cpg / 8 <= 4 inside a half; 8 = both halves: each half adds its own total).
+      float D = Dred;
+      const int per = gn_per > 4 ? 4 : gn_per;
+      if (per >= 2) D += c64w_swz<4>(D);                   // q ^ 1  (lane bit 2)
+      if (per >= 4) D += c64w_dpp<0x4E>(D);                // q ^ 2  (lane bit 1)
+      const int i = (lane & 1) * 4 + (lane & 2) + ((lane >> 2) & 1);
+      const int q = i & 3;
+      if (lane < 8 && (q & (per - 1)) == 0) {
+        const int grp = (h2 * 4 + q) / gn_per;
+        int which = i >> 2;
+        asm volatile("" : "+v"(which));
+        gn_acc_add(L.gn_acc, L.gn_groups, tb_e, grp, which, D);
+      }
+    }
+  };
+  // one phase: pixel row PT of tile s (halo buffer s & 1); `prev` = the previous phase left a row to store
+  auto phase = [&](auto PT, auto SETW, int s, auto PREV) __attribute__((always_inline)) {
+    constexpr int pt = decltype(PT)::value;
+    constexpr bool prev = decltype(PREV)::value != 0;
+    const char* const xb = smem + (size_t)(s & 1) * AH_BYTES + x0off + pt * HP * ROWB;
+    const char* const xo = smem + (size_t)(s & 1) * AH_BYTES + x0off + (1 - pt) * HP * ROWB;   // (phase 0 prefetches row 1's first fragments)
+    const int nbuf = (s + 1) & 1;
+    acc_init(PT);
     __builtin_amdgcn_sched_barrier(0);
-    // 36 k-steps x 4 pinned slots: (MFMA row 0 / half 0, next fragment of row 0) (row 0 / half 1, next fragment of row 1)
-    // (row 1 / half 0, staging: transform + write unit ks / 3 of halo s+1 at ks % 3 == 0) (row 1 / half 1, staging: reload that unit
-    // for halo s+2 at ks % 3 == 1)
     w_static_for<36>([&](auto KS) {
       constexpr int ks = decltype(KS)::value, tap = ks >> 2, c = ks & 3, cur = ks % FR, nks = ks + FD, nxt = nks % FR;
-      constexpr int ntap = (nks < 36 ? nks : 0) >> 2, nc = nks & 3;
-      constexpr int toff = ((ntap / 3) * HP + (ntap % 3)) * ROWB + nc * 32;
-      acc[0][0] = mma(wf[0][tap][c], fx[cur][0], acc[0][0]);
-      if constexpr (nks < 36) fx[nxt][0] = *reinterpret_cast<const c64w_bf16x8*>(xb + toff);
+      acc[pt][0] = mma(wf[0][tap][c], fx[cur], acc[pt][0]);
+      if constexpr (!(PRG_C64W_EXP & 8)) {
+        if constexpr (nks < 36) fx[nxt] = *reinterpret_cast<const c64w_bf16x8*>(xb + frag_off(nks < 36 ? nks : 0));
+        else if constexpr (pt == 0) fx[nxt] = *reinterpret_cast<const c64w_bf16x8*>(xo + frag_off(nks - 36));
+      }
       __builtin_amdgcn_sched_barrier(0);
-      acc[0][1] = mma(wf[1][tap][c], fx[cur][0], acc[0][1]);
-      if constexpr (nks < 36) fx[nxt][1] = *reinterpret_cast<const c64w_bf16x8*>(xb + HP * ROWB + toff);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[1][0] = mma(wf[0][tap][c], fx[cur][1], acc[1][0]);
-      if constexpr (ks % 3 == 0 && ks / 3 < KU) write_unit(nbuf, SETW, WI<(ks / 3 < KU ? ks / 3 : 0)>());
-      __builtin_amdgcn_sched_barrier(0);
-      acc[1][1] = mma(wf[1][tap][c], fx[cur][1], acc[1][1]);
-      if constexpr (ks % 3 == 1 && ks / 3 < KU) issue_unit(SETW, WI<(ks / 3 < KU ? ks / 3 : 0)>());
+      acc[pt][1] = mma(wf[1][tap][c], fx[cur], acc[pt][1]);
+      // side pieces.  k-steps 0-11: the other row's epilogue; phase 0 then has the statistics (12-17) and halo units 0-5 (18-35: write
+      // at 18 + 3 j, reload at 19 + 3 j); phase 1 has halo units 6-10 (12 + 3 j, 13 + 3 j)
+      if constexpr (ks < 12) {
+        if constexpr (prev) epi_piece(WI<1 - pt>(), KS);
+      } else if constexpr (pt == 0 && ks < 18) {
+        if constexpr (prev) stat_piece(WI<(ks < 18 ? ks - 12 : 0)>());
+      } else if constexpr (!(PRG_C64W_EXP & 2)) {
+        constexpr int base = pt == 0 ? 18 : 12, u0 = pt == 0 ? 0 : 6, j = (ks - base) / 3, r = (ks - base) % 3, u = u0 + j;
+        if constexpr (u < KU && r == 0) write_unit(nbuf, SETW, WI<(u < KU ? u : 0)>());
+        if constexpr (u < KU && r == 1) issue_unit(SETW, WI<(u < KU ? u : 0)>());
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
+  };
+  auto tile = [&](int s, auto SETW, auto FIRST) __attribute__((always_inline)) {          // halo s+1 lives in register set SETW; FIRST: no previous tile to store
+    adopt();                                               // halo s+1: loaded NSET tiles ago, written during this tile
+    issue_head(s + 1 + NSET);
+    phase(WI<0>(), SETW, s, WI<(decltype(FIRST)::value ? 0 : 1)>());   // row 0; stores row 1 of tile s - 1 and finishes its statistics
     int tb, ty0, tx0;
     c64w_tile(first + s * stride, tiles_x, tiles_y, tb, ty0, tx0);
+    tb_e = tb;
+    obase_e = reinterpret_cast<char*>(L.out) + ((((size_t)tb * d.Hout + ty0 + wave * 2) * d.Wout + tx0 + l31) * 64 + 8 * hi) * 2;
+    phase(WI<1>(), SETW, s, WI<1>());                      // row 1; stores row 0 of this tile
     c64w_barrier();                                        // halo s+1 is written; nobody reads buffer s & 1 any more
-    if (s + 1 < nsteps) first_frags(smem + (size_t)nbuf * AH_BYTES + x0off);   // the next tile's first fragments, behind the epilogue
-    // ---- epilogue (conv3x3_c64_kernel's, per channel half): lane holds pixel (row 2 wave + pt, col l31), channels
-    //      h2 * 32 + 8 q + 4 hi + {0..3} ----
-    const size_t orow = (size_t)d.Wout * 128;              // output bytes per image row
+    if (s + 1 < nsteps) {                                  // the next tile's first fragments (row 0)
+      const char* const xn = smem + (size_t)((s + 1) & 1) * AH_BYTES + x0off;
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      float V[8];                                          // [sum | sumsq][q]
-#pragma unroll
-      for (int q = 0; q < 8; ++q) V[q] = 0.0f;
-      char* const obase = reinterpret_cast<char*>(L.out) +
-                          ((((size_t)tb * d.Hout + ty0 + wave * 2) * d.Wout + tx0 + l31) * 64 + h2 * 32 + 8 * hi) * 2;
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        uint32_t pk[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[pt][h2][4 * q + r];
-            V[q] += v[r];
-            V[4 + q] = fmaf(v[r], v[r], V[4 + q]);
-          }
-          pk[2 * q] = O16 ? h16_pack(v[0], v[1]) : c64w_pack(v[0], v[1]);
-          pk[2 * q + 1] = O16 ? h16_pack(v[2], v[3]) : c64w_pack(v[2], v[3]);
-        }
-        // lanes l and l + 32 hold the two channel quads of the same pixel and 8-channel chunk q: after the swap lane half 0 has all 8
-        // channels of chunk 2m, half 1 those of chunk 2m+1: one 16-byte store each
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * m], pk[4 * m + 2], false, false);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * m + 1], pk[4 * m + 3], false, false);
-          const c64w_u32x4 o = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
-          *reinterpret_cast<c64w_u32x4*>(obase + pt * orow + m * 32) = o;
-        }
-      }
-      if (fuse_stats) {
-        // 8 full-wave sums with a halving butterfly (conv_c64.hip): fixed order, deterministic
-        const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-        float A4[4], B2[2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) A4[j] = (b0 ? V[4 + j] : V[j]) + c64w_dpp<0xB1>(b0 ? V[j] : V[4 + j]);        // lane ^ 1
-#pragma unroll
-        for (int j = 0; j < 2; ++j) B2[j] = (b1 ? A4[2 + j] : A4[j]) + c64w_dpp<0x4E>(b1 ? A4[j] : A4[2 + j]);    // lane ^ 2
-        float D = (b2 ? B2[1] : B2[0]) + c64w_swz<4>(b2 ? B2[0] : B2[1]);
-        D += c64w_swz<8>(D);
-        D += c64w_swz<16>(D);
-        D += __shfl_xor(D, 32, 64);
-        // lane (< 8) holds the wave total of value i = 4 b0 + 2 b1 + b2 = [sq][q]: 8-channel chunk q of this channel half.
-        // Fold the chunks of one group (per = cpg / 8 <= 4 inside a half; 8 = both halves: each half adds its own total).
-        const int per = gn_per > 4 ? 4 : gn_per;
-        if (per >= 2) D += c64w_swz<4>(D);                 // q ^ 1  (lane bit 2)
-        if (per >= 4) D += c64w_dpp<0x4E>(D);              // q ^ 2  (lane bit 1)
-        const int i = (lane & 1) * 4 + (lane & 2) + ((lane >> 2) & 1);
-        const int q = i & 3;
-        if (lane < 8 && (q & (per - 1)) == 0) {
-          const int grp = (h2 * 4 + q) / gn_per;
-          int which = i >> 2;
-          asm volatile("" : "+v"(which));
-          gn_acc_add(L.gn_acc, L.gn_groups, tb, grp, which, D);
-        }
-      }
+      for (int j = 0; j < FD; ++j) fx[j] = *reinterpret_cast<const c64w_bf16x8*>(xn + frag_off(j));
     }
     if constexpr (NSET == 2) okq[1] = okmask_nxt; else okq[0] = okmask_nxt;
   };
-  if constexpr (NSET == 2) {
-    for (int s = 0; s < nsteps; s += 2) {
-      tile(s, WI<1>());
-      if (s + 1 < nsteps) tile(s + 1, WI<0>());
-    }
-  } else {
-    for (int s = 0; s < nsteps; ++s) tile(s, WI<0>());
-  }
+#pragma unroll
+  for (int j = 0; j < FD; ++j) fx[j] = *reinterpret_cast<const c64w_bf16x8*>(smem + x0off + frag_off(j));
+  static_assert(NSET == 1, "the tile loop below walks one register set");
+  tile(0, WI<0>(), WI<1>());
+  for (int s = 1; s < nsteps; ++s) tile(s, WI<0>(), WI<0>());
+  // the last tile's second row and statistics
+  w_static_for<12>([&](auto P) { epi_piece(WI<1>(), P); });
+  w_static_for<6>([&](auto P) { stat_piece(P); });
 }
 
 }  // namespace
