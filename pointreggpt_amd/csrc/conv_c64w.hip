@@ -55,7 +55,9 @@ constexpr int NPT = 256;                                               // every 
 constexpr int RPP = NPT / 8;                                           // halo rows per pass
 constexpr int KU = (HALO + RPP - 1) / RPP;                             // 11 units per thread
 constexpr size_t AH_BYTES = (size_t)KU * RPP * ROWB;                   // 352 rows: the units past the halo end land in spare rows
-constexpr size_t C64W_LDS = 2 * AH_BYTES + 64 * sizeof(float);         // + the bias
+constexpr int NLT = 2;                                                 // taps (the last NLT) whose weights live in LDS instead of registers
+constexpr size_t WL_BYTES = (size_t)NLT * 4 * 2 * 1024;                // [tap][k-step][channel half][lane] x 16 B
+constexpr size_t C64W_LDS = 2 * AH_BYTES + 64 * sizeof(float) + WL_BYTES;   // + the bias + those weights
 
 __device__ inline uint32_t c64w_pack(float a, float b) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -107,18 +109,28 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   if (nsteps == 0) return;
 
   const int l31 = lane & 31, hi = lane >> 5;
-  // ---- weights of channels h2 * 32 + l31: 9 taps x 4 k-steps; lane half hi takes k = 16 c + 8 hi .. + 7 ----
-  c64w_bf16x8 wf[2][9][4];
+  // ---- weights of channels h2 * 32 + l31: 9 taps x 4 k-steps; lane half hi takes k = 16 c + 8 hi .. + 7.  Taps 0 .. 8 - NLT stay in
+  //      registers for the whole launch (224); the fragments of the last NLT taps are identical in every wave and live in LDS (16 KB),
+  //      read two k-steps ahead like the pixels (0.72 LDS reads per MFMA instead of 0.5): with all 288 resident the two-phase pipeline
+  //      below spilled, and a spill reload is a scratch load behind `s_waitcnt vmcnt(0)` — it waits for every halo load in flight ----
+  constexpr int NRT = 9 - NLT;
+  const bf16_t* const wsrc = PRO == 3 ? reinterpret_cast<const bf16_t*>(L.w_f16) : L.w;
+  auto wptr = [&](int h2, int tap, int c) {
+    return wsrc + ((size_t)(tap * d.kchunks + (c >> 1)) * d.CoutPad + h2 * 32 + l31) * 32 + (c & 1) * 16 + hi * 8;
+  };
+  c64w_bf16x8 wf[2][NRT][4];
 #pragma unroll
   for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < NRT; ++tap)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16_t* const wsrc = PRO == 3 ? reinterpret_cast<const bf16_t*>(L.w_f16) : L.w;
-        const bf16_t* p = wsrc + ((size_t)(tap * d.kchunks + (c >> 1)) * d.CoutPad + h2 * 32 + l31) * 32 + (c & 1) * 16 + hi * 8;
-        wf[h2][tap][c] = *reinterpret_cast<const c64w_bf16x8*>(p);
-      }
+      for (int c = 0; c < 4; ++c) wf[h2][tap][c] = *reinterpret_cast<const c64w_bf16x8*>(wptr(h2, tap, c));
+  char* const wlds = smem + 2 * AH_BYTES + 64 * sizeof(float);
+#pragma unroll
+  for (int f = 0; f < NLT * 4 * 2 / 4; ++f) {              // wave w stores fragments w, w + 4, ...
+    const int idx = wave + 4 * f, h2 = idx & 1, c = (idx >> 1) & 3, tl = idx >> 3;
+    *reinterpret_cast<c64w_bf16x8*>(wlds + (size_t)idx * 1024 + lane * 16) = *reinterpret_cast<const c64w_bf16x8*>(wptr(h2, NRT + tl, c));
+  }
   float* const bias_lds = reinterpret_cast<float*>(smem + 2 * AH_BYTES);
   if (tid < 64) bias_lds[tid] = L.bias[tid];               // visible after the prologue barrier
   const int gn_per = fuse_stats ? (64 / L.gn_groups) >> 3 : 1;   // 8-channel chunks per group (1, 2, 4 or 8)
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   // profiles/r06_c64w_ablations.txt): MFMAs alone 57 us, everything but the MFMAs 57 us, serial sum 76.7 us at the level-0 launch
   // (conv3x3_c64_kernel: 73.0; its MFMA phase and its epilogue add up the same way).
   constexpr int FD = 2, FR = FD + 1;                       // fragment ring: read FD k-steps (2 FD MFMAs) ahead
-  c64w_bf16x8 fx[FR];
+  c64w_bf16x8 fx[FR], wl[FR][2];                           // pixels; the LDS-resident taps' weights (both channel halves)
   auto frag_off = [](int ks) { const int tap = ks >> 2, c = ks & 3; return ((tap / 3) * HP + (tap % 3)) * ROWB + c * 32; };
   c64w_f32x16 acc[2][2];                                   // [pixel row][channel half]; row r is busy from its phase to the end of its epilogue
   float V[2][8];                                           // [channel half][sum | sumsq][q]: statistics of the tile being stored
@@ -347,13 +359,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __builtin_amdgcn_sched_barrier(0);
     w_static_for<36>([&](auto KS) {
       constexpr int ks = decltype(KS)::value, tap = ks >> 2, c = ks & 3, cur = ks % FR, nks = ks + FD, nxt = nks % FR;
-      acc[pt][0] = mma(wf[0][tap][c], fx[cur], acc[pt][0]);
+      acc[pt][0] = mma(tap < NRT ? wf[0][tap < NRT ? tap : 0][c] : wl[cur][0], fx[cur], acc[pt][0]);
       if constexpr (!(PRG_C64W_EXP & 8)) {
         if constexpr (nks < 36) fx[nxt] = *reinterpret_cast<const c64w_bf16x8*>(xb + frag_off(nks < 36 ? nks : 0));
         else if constexpr (pt == 0) fx[nxt] = *reinterpret_cast<const c64w_bf16x8*>(xo + frag_off(nks - 36));
+        if constexpr (nks < 36 && (nks >> 2) >= NRT) {
+          constexpr int widx = (((nks >> 2) - NRT) * 4 + (nks & 3)) * 2;
+          wl[nxt][0] = *reinterpret_cast<const c64w_bf16x8*>(wlds + (size_t)widx * 1024 + lane * 16);
+          wl[nxt][1] = *reinterpret_cast<const c64w_bf16x8*>(wlds + (size_t)(widx + 1) * 1024 + lane * 16);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-      acc[pt][1] = mma(wf[1][tap][c], fx[cur], acc[pt][1]);
+      acc[pt][1] = mma(tap < NRT ? wf[1][tap < NRT ? tap : 0][c] : wl[cur][1], fx[cur], acc[pt][1]);
       // side pieces.  k-steps 0-11: the other row's epilogue; phase 0 then has the statistics (12-17) and halo units 0-5 (18-35: write
       // at 18 + 3 j, reload at 19 + 3 j); phase 1 has halo units 6-10 (12 + 3 j, 13 + 3 j)
       if constexpr (ks < 12) {
