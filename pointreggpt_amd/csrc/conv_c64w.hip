@@ -16,6 +16,8 @@
 // outputs are bit-identical; the GroupNorm statistics are per-wave float totals added into the fixed-point accumulators, and a
 // wave now covers 64 pixels x 64 channels instead of 128 x 32, so the statistics differ in the last bits (as between any two of the
 // bf16 kernels).  Only the accumulator form of the statistics (ConvLaunch::gn_acc) is implemented; other launches keep conv_c64.
+// OUTCOME (profiles/r06_c64w_ablations.txt): 76-79 us against conv3x3_c64_kernel's 71-73 at the level-0 launch in every form tried — the
+// side work does not hide behind the MFMAs of a single in-order stream.  Opt-in (PRG_CONV_C64W=1), off by default.
 #include <atomic>
 #include <cstdlib>
 
@@ -415,9 +417,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 }  // namespace
 
 // Returns 1 when it launched, 0 when the shape / mode is not covered (the caller goes on to conv3x3_c64_kernel), negative on error.
-// PRG_CONV_C64W: 1 (default) on, 0 off.
+// PRG_CONV_C64W: 0 (default) off — the same-box A/B (profiles/r06_c64w_ablations.txt) has this kernel at 76-79 us against
+// conv3x3_c64_kernel's 71-73 at the level-0 launch; 1 selects it (tests/test_gpu_parity.py::test_c64w_kernel_matches_the_c64_kernel).
 int try_launch_conv3x3_c64w(const ConvLaunch<bf16_t>& L, hipStream_t s, int* gn_nsplit_out, int* coef_done, int* acc_done) {
-  static const int enabled = [] { const char* e = std::getenv("PRG_CONV_C64W"); return e ? std::atoi(e) : 1; }();
+  static const int enabled = [] { const char* e = std::getenv("PRG_CONV_C64W"); return e ? std::atoi(e) : 0; }();
   if (!enabled) return 0;
   const ConvDesc& d = L.d;
   if (!(d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)) return 0;

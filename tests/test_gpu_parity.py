@@ -1066,7 +1066,7 @@ def test_block_pair_h16_against_float64(hip, B, Cin, C, H, Wd):
 def test_c64w_kernel_matches_the_c64_kernel(tmp_path):
     """Round 6: conv3x3_c64w_kernel (one 512-register wave per SIMD holding the weights of all 64 output channels: 0.5 fragment reads
     per MFMA) runs conv3x3_c64_kernel's MFMA sequence per accumulator — the plain 64 -> 64 convolution must give the SAME BITS with
-    the kernel on (default) and off (PRG_CONV_C64W=0) at a shape that selects it (two 8 x 32 tiles per CU), on images with every
+    the kernel on (PRG_CONV_C64W=1; it is off by default: profiles/r06_c64w_ablations.txt) and off at a shape that selects it (two 8 x 32 tiles per CU), on images with every
     kind of border tile; the ResnetBlock pair (f16 tensor in between, statistics in the epilogue, folded prologue) agrees to the
     last-bit differences of the GroupNorm statistics (a wave totals 64 pixels x 64 channels instead of 128 x 32)."""
     import os

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_c64w_ab.sh <tag> [rounds]: same-box A/B of conv3x3_c64w_kernel (PRG_CONV_C64W=1, default) against conv3x3_c64_kernel (=0): bf16
+# tools/gpu_c64w_ab.sh <tag> [rounds]: same-box A/B of conv3x3_c64w_kernel (PRG_CONV_C64W=1; default 0) against conv3x3_c64_kernel (=0): bf16
 # micro-bench shapes, the kernel's tests, then the whole bf16 pipeline (bench.py, 200 transitions)
 cd $GRAFT_REPO_ROOT
 T=$1; N=${2:-2}
