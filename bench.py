@@ -48,7 +48,7 @@ EVIDENCE = {"profiles": "profiles/README.md lists every file with its command an
                         "bench line + sidecar, the GPU test log",
             "ab_records": "profiles/*_ab_* compare alternating runs of the same binary on the same box (box to box the same binary "
                           "spreads +-4 %)",
-            "power": "profiles/r05_power_clock_mfma_busy_per_mode.json (socket power, shader clock, pairs per joule, MFMA-busy per mode)"}
+            "power": "profiles/r06_power_clock_mfma_busy_per_mode.json (socket power, shader clock, pairs per joule, MFMA-busy per mode)"}
 LINE_LIMIT = 4096          # bytes of the contract line (the driver keeps a bounded stdout tail and parses its last line)
 SIDECAR = "bench_full.json"
 

@@ -63,4 +63,4 @@ for dt in ("bf16", "mxfp8", "f16x3", "fp32"):
 json.dump(out, open("gpurun_out/power_modes.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-rm -rf $O/power_pmc_bf16 $O/power_pmc_mxfp8 $O/power_pmc_f16x3
+rm -rf $O/power_pmc_bf16 $O/power_pmc_mxfp8 $O/power_pmc_f16x3 $O/power_pmc_fp32
