@@ -89,7 +89,7 @@ __device__ inline void flush_acc(f32x16 (&acc)[TM][2], f32x16 (&tot)[TM][2]) {
 template <int TH, int TW, int NS>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(
     const ConvLaunch<float> L, const int tiles_x, const int tiles_y, const int tiles_n, const int fuse_stats) {
-  constexpr int NW = 4, BN = 64, TM = 1;
+  constexpr int NW = 4, BN = 64;
   constexpr int CH = 32;                       // channels per chunk: one LDS row = 64 B of hi halves + 64 B of lo halves
   constexpr int HP = TW + 2, HALO = (TH + 2) * HP;
   constexpr int PITCH = 144;                   // halo pixel pitch in bytes (128 + 16: consecutive pixels on distinct 16-byte slots)
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 
   double gs, gq;
-  auto row_to_m = [&](int r) -> int64_t {
+  [[maybe_unused]] auto row_to_m = [&](int r) -> int64_t {
     const int p = wave * 32 + r;
     return ((int64_t)b * d.Hout + y0 + p / TW) * d.Wout + x0 + p % TW;
   };
@@ -1452,7 +1452,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_kernel(const ConvLaun
 // ---------------------------------------------------------------------------------------------
 template <int TH, int TW>
 static int launch_split_halo(const ConvLaunch<float>& L, hipStream_t s, int fuse_stats, int* nsplit) {
-  constexpr int HALO = (TH + 2) * (TW + 2);
+  [[maybe_unused]] constexpr int HALO = (TH + 2) * (TW + 2);
   constexpr int RSTRIDE = ((TW + 2) * 144 + 255) / 256 * 256, HB = (TH + 2) * RSTRIDE;
   constexpr int NS = (2 * HB + 3 * 8192) * 2 <= 160 * 1024 ? 3 : 2;   // weight ring slots: two workgroups must fit a CU
   const ConvDesc& d = L.d;

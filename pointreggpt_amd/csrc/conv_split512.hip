@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, hi = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;               // pixel half (eight tile rows) x channel half
-  const int nchunks = (d.C0 + d.C1) / CH, niter = nchunks * NT;
+  const int nchunks = (d.C0 + d.C1) / CH;
   const size_t wstep = (size_t)d.CoutPad * 128;
   const char* wtile = reinterpret_cast<const char*>(L.w_split + (size_t)tn * BN * 64);
   const int Hs = d.Hout, Ws = d.Wout;
