@@ -8,11 +8,11 @@
 //
 // Here the weights never touch LDS again after the prologue: a consumer wave owns 32 output channels and keeps their
 // 9 x 64 weights as 36 MFMA A-fragments in registers (144 VGPRs) for the whole launch; its B operands are the pixels of
-// a 128-pixel half tile read from the halo (16 ds_read_b128 per 16 MFMAs, as before, but no weight reads, no weight
-// ring, no per-tap barrier).  The workgroup (512 threads, 256 registers per lane) is
+// a 128-pixel half tile read from the halo (round 6: every fragment read once and used for the three taps of its column —
+// 72 ds_read_b128 per 144 MFMAs; no weight reads, no weight ring, no per-tap barrier).  The workgroup (512 threads, 256 registers per lane) is
 //
 //   waves 0-3  CONSUMERS (2 pixel halves x 2 channel halves of a 8 x 32 pixel x 64 channel tile): 144 MFMAs per tile,
-//              fragments prefetched one call ahead; epilogue = bias, GroupNorm partial sums (the deterministic butterfly
+//              fragments prefetched three reads ahead; epilogue = bias, GroupNorm partial sums (the deterministic butterfly
 //              of conv_ws.hip), bf16 and DIRECT stores: a v_permlane32_swap pairs the two lane halves' channel quads, so
 //              every lane stores 16 contiguous bytes (no LDS stage, nothing for the producers to drain);
 //   waves 4-7  PRODUCERS: write halo s+1 (loaded a whole step earlier; optional fused GroupNorm + (scale+1, shift) + SiLU
@@ -39,7 +39,8 @@ namespace {
 
 // Timing experiments only (results become garbage): -DPRG_C64_EXP=1 consumers skip fragment reads + MFMAs, 2 producers skip
 // the halo loads / writes, 4 no epilogue, 8 no priority raise, 32 producers skip only the prologue arithmetic, 256 SiLU
-// without transcendentals, 512 consumers issue half their fragment reads (upper bound of a 0.5-reads-per-MFMA form).
+// without transcendentals, 512 consumers issue half their fragment reads (pairs of MFMAs share a fragment), 1024 the round-5 consumer
+// loop (one read per MFMA) instead of the row-reuse loop, 2048 (with 1024) all the reads but MFMA pairs sharing their operands.
 #ifndef PRG_C64_EXP
 #define PRG_C64_EXP 0
 #endif
@@ -51,6 +52,7 @@ constexpr int RPP = NPT / 8;                                           // halo r
 constexpr int KU = (HALO + RPP - 1) / RPP;                             // 11 units per producer thread
 constexpr size_t AH_BYTES = (size_t)KU * RPP * ROWB;                   // 352 rows: the units past the halo end land in spare rows
 constexpr size_t C64_LDS = 2 * AH_BYTES + 64 * sizeof(float);          // + the bias
+constexpr bool kRowReuse = (PRG_C64_EXP & 1024) == 0;                 // -DPRG_C64_EXP=1024: the round-5 consumer loop (one read per MFMA), for A/B builds
 
 __device__ inline float c64_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ inline float c64_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -218,50 +220,84 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           for (int pt = 0; pt < 4; ++pt) { acc[pt][4 * q] = b4.x; acc[pt][4 * q + 1] = b4.y; acc[pt][4 * q + 2] = b4.z; acc[pt][4 * q + 3] = b4.w; }
         }
       }
-      c64_bf16x8 fx[2][4];
+      if constexpr (kRowReuse) {
+        // Round 6: ROW REUSE.  Tap (dy, dx) of pixel row pt reads halo row pt + dy: the twelve (pt, dy) pairs of one (dx, k-step) touch
+        // only SIX halo rows.  The four accumulators are independent chains, so they are skewed by one tap row: fragment (halo row r,
+        // dx, c) is read ONCE and feeds acc[r] at tap (0, dx), acc[r-1] at (1, dx) and acc[r-2] at (2, dx) back to back — 72 reads
+        // per tile instead of 144 (0.5 ds_read_b128 per MFMA), no extra registers, and every accumulator still sees its MFMAs in
+        // tap-major order: the outputs are bit-identical.  Measured -1.0 ... -1.5 % per launch (profiles/r06_ab_c64_row_reuse.txt): the
+        // reads are a small term — the kernel is bound by the energy of its MFMAs on a power-capped part, not by LDS
+        // (profiles/r06_c64_half_reads_bound.txt).  Ring of four fragments, three ahead.
+        constexpr int FD = 3, FR = 4, NF = (PRG_C64_EXP & 1) ? 0 : 72;
+        c64_bf16x8 fr[FR];
+        auto foff = [](int n) { return ((n / 12) * HP + (n / 4) % 3) * ROWB + (n & 3) * 32; };   // n = (r * 3 + dx) * 4 + c
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) fx[0][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB);
+        for (int j = 0; j < FD && j < NF; ++j) fr[j] = *reinterpret_cast<const c64_bf16x8*>(xb + foff(j));
 #pragma unroll
-      for (int tap = 0; tap < ((PRG_C64_EXP & 1) ? 0 : 9); ++tap) {
+        for (int n = 0; n < NF; ++n) {
+          const int r = n / 12, dx = (n / 4) % 3, c = n & 3;
+          if (n + FD < NF) fr[(n + FD) % FR] = *reinterpret_cast<const c64_bf16x8*>(xb + foff(n + FD));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int cur = (tap * 4 + c) & 1, nxt = cur ^ 1;
-          const int ntap = c == 3 ? tap + 1 : tap, nc = c == 3 ? 0 : c + 1;   // the call after this one
-          if (ntap < 9) {
-            const int toff = ((ntap / 3) * HP + (ntap % 3)) * ROWB + nc * 32;
-            if constexpr ((PRG_C64_EXP & 64) != 0) {         // variant: the next call's four reads first, then the four MFMAs
+          for (int dy = 0; dy < 3; ++dy) {
+            const int pt = r - dy;
+            if (pt >= 0 && pt < 4) acc[pt] = mma(wf[dy * 3 + dx][c], fr[n % FR], acc[pt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        c64_bf16x8 fx[2][4];
 #pragma unroll
-              for (int pt = 0; pt < 4; ++pt) fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
-              __builtin_amdgcn_sched_barrier(0);
+        for (int pt = 0; pt < 4; ++pt) fx[0][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB);
 #pragma unroll
-              for (int pt = 0; pt < 4; ++pt)
-                acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
-              __builtin_amdgcn_sched_barrier(0);
-            } else if constexpr ((PRG_C64_EXP & 128) != 0) { // variant: leave the interleave to the compiler
+        for (int tap = 0; tap < ((PRG_C64_EXP & 1) ? 0 : 9); ++tap) {
 #pragma unroll
-              for (int pt = 0; pt < 4; ++pt) {
-                fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
-                acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
-              }
-            } else if constexpr ((PRG_C64_EXP & 512) != 0) { // timing experiment: HALF the fragment reads (0.5 per MFMA; garbage results)
+          for (int c = 0; c < 4; ++c) {
+            const int cur = (tap * 4 + c) & 1, nxt = cur ^ 1;
+            const int ntap = c == 3 ? tap + 1 : tap, nc = c == 3 ? 0 : c + 1;   // the call after this one
+            if (ntap < 9) {
+              const int toff = ((ntap / 3) * HP + (ntap % 3)) * ROWB + nc * 32;
+              if constexpr ((PRG_C64_EXP & 64) != 0) {         // variant: the next call's four reads first, then the four MFMAs
 #pragma unroll
-              for (int pt = 0; pt < 4; ++pt) {
-                if ((pt & 1) == 0) fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
-                acc[pt] = mma(wf[tap][c], fx[cur][pt & ~1], acc[pt]);
+                for (int pt = 0; pt < 4; ++pt) fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+                  acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
+                __builtin_amdgcn_sched_barrier(0);
+              } else if constexpr ((PRG_C64_EXP & 128) != 0) { // variant: leave the interleave to the compiler
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                  fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+                  acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
+                }
+              } else if constexpr ((PRG_C64_EXP & 2048) != 0) { // timing experiment: ALL the reads, but MFMA pairs share their operands (garbage results)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                  fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+                  asm volatile("" ::"v"(fx[cur][pt]));      // (the fragment is waited for where its MFMA would consume it)
+                  acc[pt] = mma(wf[tap][c], fx[cur][pt & ~1], acc[pt]);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              } else if constexpr ((PRG_C64_EXP & 512) != 0) { // timing experiment: HALF the fragment reads (0.5 per MFMA; garbage results)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                  if ((pt & 1) == 0) fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+                  acc[pt] = mma(wf[tap][c], fx[cur][pt & ~1], acc[pt]);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              } else {
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                  fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+                  acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
               }
             } else {
 #pragma unroll
-              for (int pt = 0; pt < 4; ++pt) {
-                fx[nxt][pt] = *reinterpret_cast<const c64_bf16x8*>(xb + pt * HP * ROWB + toff);
+              for (int pt = 0; pt < 4; ++pt)
                 acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
-                __builtin_amdgcn_sched_barrier(0);
-              }
             }
-          } else {
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
-              acc[pt] = mma(wf[tap][c], fx[cur][pt], acc[pt]);
           }
         }
       }
