@@ -48,7 +48,9 @@ EVIDENCE = {"profiles": "profiles/README.md lists every file with its command an
                         "bench line + sidecar, the GPU test log",
             "ab_records": "profiles/*_ab_* compare alternating runs of the same binary on the same box (box to box the same binary "
                           "spreads +-4 %)",
-            "power": "profiles/r06_power_clock_mfma_busy_per_mode.json (socket power, shader clock, pairs per joule, MFMA-busy per mode)"}
+            "power": "profiles/r06_power_clock_mfma_busy_per_mode.json (socket power, shader clock, pairs per joule, MFMA-busy per mode)",
+            "what_bounds_the_convs": "profiles/r06_c64_half_reads_bound.txt (control experiment: every LDS read kept, MFMA pairs on identical operands = -23 %: "
+                                     "MFMA switching energy under the power cap, not LDS traffic or issue slots)"}
 LINE_LIMIT = 4096          # bytes of the contract line (the driver keeps a bounded stdout tail and parses its last line)
 SIDECAR = "bench_full.json"
 
