@@ -39,8 +39,8 @@ namespace {
 
 // Timing experiments only (results become garbage): -DPRG_C64_EXP=1 consumers skip fragment reads + MFMAs, 2 producers skip
 // the halo loads / writes, 4 no epilogue, 8 no priority raise, 32 producers skip only the prologue arithmetic, 256 SiLU
-// without transcendentals, 512 consumers issue half their fragment reads (pairs of MFMAs share a fragment), 1024 the round-5 consumer
-// loop (one read per MFMA) instead of the row-reuse loop, 2048 (with 1024) all the reads but MFMA pairs sharing their operands.
+// without transcendentals, 1024 the round-5 consumer loop (one read per MFMA) instead of the row-reuse loop; with 1024: 512 half the
+// fragment reads (pairs of MFMAs share a fragment), 2048 all the reads but MFMA pairs sharing their operands (both with opaque accumulators).
 #ifndef PRG_C64_EXP
 #define PRG_C64_EXP 0
 #endif
@@ -220,14 +220,20 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvLaunch<bf16_
           for (int pt = 0; pt < 4; ++pt) { acc[pt][4 * q] = b4.x; acc[pt][4 * q + 1] = b4.y; acc[pt][4 * q + 2] = b4.z; acc[pt][4 * q + 3] = b4.w; }
         }
       }
+      if constexpr ((PRG_C64_EXP & (512 | 2048)) != 0) {
+        // the shared-operand timing experiments: make the accumulators opaque, or the compiler proves acc[1] == acc[0] and acc[3] == acc[2]
+        // (identical initial values, identical MFMA chains) and DROPS half the MFMAs — which is what the first version of these experiments
+        // measured (74 v_mfma instead of 144 in the ISA; profiles/r06_c64_half_reads_bound.txt)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) asm volatile("" : "+v"(acc[pt]));
+      }
       if constexpr (kRowReuse) {
         // Round 6: ROW REUSE.  Tap (dy, dx) of pixel row pt reads halo row pt + dy: the twelve (pt, dy) pairs of one (dx, k-step) touch
         // only SIX halo rows.  The four accumulators are independent chains, so they are skewed by one tap row: fragment (halo row r,
         // dx, c) is read ONCE and feeds acc[r] at tap (0, dx), acc[r-1] at (1, dx) and acc[r-2] at (2, dx) back to back — 72 reads
         // per tile instead of 144 (0.5 ds_read_b128 per MFMA), no extra registers, and every accumulator still sees its MFMAs in
         // tap-major order: the outputs are bit-identical.  Measured -1.0 ... -1.5 % per launch (profiles/r06_ab_c64_row_reuse.txt): the
-        // reads are a small term — the kernel is bound by the energy of its MFMAs on a power-capped part, not by LDS
-        // (profiles/r06_c64_half_reads_bound.txt).  Ring of four fragments, three ahead.
+        // fragment reads are a small term of this kernel (profiles/r06_c64_half_reads_bound.txt).  Ring of four fragments, three ahead.
         constexpr int FD = 3, FR = 4, NF = (PRG_C64_EXP & 1) ? 0 : 72;
         c64_bf16x8 fr[FR];
         auto foff = [](int n) { return ((n / 12) * HP + (n / 4) % 3) * ROWB + (n & 3) * 32; };   // n = (r * 3 + dx) * 4 + c

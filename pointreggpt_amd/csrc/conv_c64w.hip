@@ -2,10 +2,10 @@
 //
 // conv3x3_c64_kernel (conv_c64.hip) gives a consumer wave 32 output channels: their 9 x 64 weights fill 144 of its 256 registers, and
 // (until the row-reuse loop of round 6) every pixel fragment it read from LDS fed ONE MFMA, the two channel-half waves reading the same
-// pixels twice.  A timing experiment that halved those reads ran the level-0 launch in 54.5 us instead of 73.0, which was read as "bound by
-// LDS operand traffic" and motivated this kernel; a later control (all the reads kept, MFMA pairs multiplying identical operands: the
-// same 56 us) showed the saving was the MFMAs' switching energy on a power-capped part, not the reads
-// (profiles/r06_c64_half_reads_bound.txt).  The kernel is kept as the measured record of the one-wave-per-SIMD form on the bf16 path.
+// pixels twice.  A timing experiment that halved those reads ran the level-0 launch in 54.5 us instead of 73.0, was read as "bound by LDS
+// operand traffic" and motivated this kernel.  The experiment was invalid — its paired accumulator chains were identical and hipcc dropped
+// half the MFMAs; repeated correctly, half the reads are worth 3-4.5 % (profiles/r06_c64_half_reads_bound.txt).  The kernel is kept as the
+// measured record of the one-wave-per-SIMD form on the bf16 path.
 // Here a 256-thread workgroup owns a CU with one 512-register wave per SIMD:
 //   * a wave keeps the weights of ALL 64 output channels (72 A fragments, 288 registers: hipcc places them across the VGPR and
 //     AccVGPR halves of the unified file) and owns 64 pixels (two rows of the 8 x 32 tile): every pixel fragment feeds TWO MFMAs
